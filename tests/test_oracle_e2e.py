@@ -1,0 +1,65 @@
+"""Oracle post-logits pipeline vs the reference on synthetic log-probs (CPU)."""
+
+import gzip
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from synth import synth_logits
+
+
+@pytest.fixture(scope="module")
+def cases(golden_dir):
+    return json.load(gzip.open(golden_dir / "e2e_cases.json.gz"))
+
+
+def logprobs_of(recipe):
+    lg = synth_logits(recipe["ids"], recipe["T"], seed=recipe["seed"], noise=recipe["noise"],
+                      boost=recipe["boost"], rep=recipe["rep"])
+    return torch.log_softmax(torch.from_numpy(lg), dim=-1).numpy()
+
+
+def test_e2e_cases(oracle, cases):
+    assert len(cases) >= 9
+    for c in cases:
+        lp = logprobs_of(c["recipe"])
+        assert oracle.greedy_ids(lp) == c["greedy_ids"], c["name"]
+        assert oracle.greedy_decode(lp) == c["transcript"], c["name"]
+        res = oracle.predict_logprobs(lp)
+        g = c["result"]
+        assert (res["surah"], res["ayah"], res["ayah_end"], res["source"]) == (
+            g["surah"], g["ayah"], g["ayah_end"], g["source"]), c["name"]
+        assert res["score"] == g["score"], c["name"]
+        if "cand_keys" not in c:
+            continue
+        cs, cp, sc, _ = oracle.build_candidates(c["transcript"])
+        keys = [list(oracle.key_of(int(a), int(b))) for a, b in zip(cs, cp)]
+        assert keys == c["cand_keys"], c["name"]
+        win, loss, cl, fs = oracle.ctc_rerank(lp, cs, cp, sc)
+        want = np.array([np.inf if x is None else x for x in c["ctc_loss"]], dtype=np.float64)
+        fin = np.isfinite(want)
+        assert (np.isfinite(loss) == fin).all(), c["name"]
+        assert cl.tolist() == c["ctc_len"], c["name"]
+        if fin.any():
+            # tolerance stated by north_star for CTC log-probs is 1e-2; the C restatement of
+            # ATen's float32 recursion is in practice bit-identical on this image
+            assert np.abs(loss[fin] - want[fin]).max() <= 1e-3, c["name"]
+            idl = [oracle.token_ids(int(a), int(b)) for a, b, f in zip(cs, cp, fin) if f]
+            lt = oracle.ctc_loss_torch(lp, idl)
+            assert np.abs(lt - want[fin]).max() <= 1e-4, c["name"]
+        order = sorted((i for i in range(len(cs)) if np.isfinite(loss[i])), key=lambda i: -fs[i])
+        assert [keys[i] for i in order[:20]] == c["ranked_keys"], c["name"]
+        assert np.allclose([fs[i] for i in order[:20]], c["ranked_final"], atol=1e-6), c["name"]
+
+
+def test_gate_is_stricter_than_feasibility(oracle):
+    """2L+1 <= T, not CTC feasibility (c2c-direct/run.py:332)."""
+    ids = oracle.token_ids(0, 1)
+    L = len(ids)
+    lp = torch.log_softmax(torch.from_numpy(synth_logits(ids.tolist(), 2 * L, 1, 1.0, 8.0, 1)), -1).numpy()
+    cs, cp, sc = np.array([0], np.int32), np.array([1], np.int32), np.zeros(1)
+    win, loss, cl, fs = oracle.ctc_rerank(lp, cs, cp, sc)
+    assert win == -1 and np.isinf(loss[0])
+    assert np.isfinite(oracle.ctc_loss_c(lp, ids))
