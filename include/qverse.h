@@ -1,0 +1,171 @@
+/*
+ * qverse.h -- C ABI of libqverse.so, the MI355X-native replacement for the numerics of
+ * the reference's c2c-direct-mixed hot path (paths relative to yazinsai/offline-tarteel):
+ *
+ *   audio_signal f32[B,N] --qv_forward--> log-probs f32[B,T,1025]
+ *        replaces  onnxruntime InferenceSession.run(None, {"audio_signal","length"})
+ *                  experiments/c2c-direct-mixed/run.py:55-63, .../c2c-direct-mixed-tta/run.py:74-79
+ *   log-probs --qv_decode_retrieve_rerank--> (surah, ayah, ayah_end, score, source)
+ *        replaces  _greedy_decode        experiments/c2c-direct/run.py:187-204
+ *                  _build_candidates     experiments/c2c-direct/run.py:251-311
+ *                  QuranDB.match_verse / search  shared/quran_db.py:92-99,244-371
+ *                  _ctc_rerank (torch F.ctc_loss) experiments/c2c-direct/run.py:314-380
+ *                  decision logic        experiments/c2c-direct-mixed/run.py:96-133
+ *   qv_predict_batch = both, back to back on one stream (what predict() does per file,
+ *        experiments/c2c-direct-mixed/run.py:66-133, for a whole batch).
+ *
+ * Conventions
+ *   - plain C, no torch types.  Pointers named *_dev are DEVICE pointers owned by the
+ *     caller (e.g. PyTorch-ROCm tensors); the library never frees or retains them.
+ *     Pointers named *_host are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Entry points
+ *     enqueue work on it; only functions documented as synchronous wait for it.
+ *   - every function returns 0 on success or a QV_ERR_* code; qv_last_error() gives text.
+ *     The Python binding turns non-zero into an exception, so the runner's per-sample
+ *     try/except (benchmark/runner.py:322-325) yields the reference's empty prediction.
+ *   - one engine per process per GPU; calls on one engine must not overlap in time unless
+ *     they are enqueued on the same stream (the TTA plugin batches its 0.9x/1.1x passes into
+ *     one call instead of calling from two threads, cf. c2c-direct-mixed-tta/run.py:129-130).
+ */
+#ifndef QVERSE_H
+#define QVERSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QV_VOCAB 1025
+#define QV_BLANK 1024
+#define QV_MAX_TRANSCRIPT 1024 /* normalised transcript chars handled on device */
+
+enum {
+    QV_OK = 0,
+    QV_ERR_ARG = 1,        /* bad argument / unsupported knob */
+    QV_ERR_IO = 2,         /* tables or weights file missing / malformed (FileNotFoundError) */
+    QV_ERR_HIP = 3,        /* HIP runtime error */
+    QV_ERR_CAPACITY = 4,   /* batch / length exceeds what the engine was created for */
+    QV_ERR_NO_MODEL = 5    /* forward requested but engine has no weights */
+};
+
+enum { QV_SOURCE_NONE = 0, QV_SOURCE_TEXT = 1, QV_SOURCE_CTC = 2 };
+
+/* flags in qv_result.flags */
+enum {
+    QV_FLAG_EMPTY_TRANSCRIPT = 1,   /* greedy decode produced nothing -> _empty("") */
+    QV_FLAG_TRANSCRIPT_TRUNCATED = 2,/* > QV_MAX_TRANSCRIPT chars: prediction withheld (surah 0) */
+    QV_FLAG_USED_CTC = 4,           /* gate failed (base.score < threshold): rerank ran */
+    QV_FLAG_CAND_OVERFLOW = 8       /* candidate list clipped at engine capacity */
+};
+
+typedef struct qv_engine qv_engine;
+
+/* Weight precision of the acoustic model resident in HBM. */
+enum { QV_PREC_FP16 = 0, QV_PREC_MIXED_INT4_INT8 = 1 };
+
+typedef struct {
+    int32_t struct_size;        /* sizeof(qv_config), for forward compatibility */
+    int32_t device;             /* HIP device ordinal */
+    const char *tables_path;    /* qverse_tables.bin (tools/build_tables.py) */
+    const char *weights_path;   /* flat weight file (tools/convert_weights.py) or NULL */
+    uint64_t random_weights_seed; /* used when weights_path == NULL and with_model != 0 */
+    int32_t with_model;         /* 0: post-logits stages only */
+    int32_t precision;          /* QV_PREC_* */
+    int32_t max_batch;          /* capacity: utterances per call */
+    int32_t max_samples;        /* capacity: samples per utterance (480000 = 30 s) */
+    /* CTC_DIRECT_* knobs, experiments/c2c-direct/run.py:62-74 (same defaults) */
+    int32_t top_text;           /* CTC_DIRECT_TOP_TEXT        100 */
+    int32_t top_span_refs;      /* CTC_DIRECT_TOP_SPAN_REFS    80 */
+    int32_t max_span;           /* CTC_DIRECT_MAX_SPAN          6 (table limit 6) */
+    double threshold;           /* CTC_DIRECT_THRESHOLD       0.80 */
+    double text_weight;         /* CTC_DIRECT_TEXT_WEIGHT      0.0 (only 0.0 supported on device) */
+    double span_penalty;        /* CTC_DIRECT_SPAN_PENALTY     0.5 */
+    int32_t skip_unused_passes; /* 1: skip search()/pass-3 when the gate passes (their output is
+                                   unused by the mixed plugin); 0: literal */
+} qv_config;
+
+/* One prediction; mirrors the dict of experiments/c2c-direct-mixed/run.py:126-133. */
+typedef struct {
+    int32_t surah, ayah, ayah_end;  /* 0,0,0 = no match (_empty) */
+    int32_t source;                 /* QV_SOURCE_* */
+    double score;                   /* unrounded; the mixed plugin rounds to 4 dp, TTA does not */
+    double base_score;              /* match_verse score (0 if none) */
+    float ctc_norm_loss;            /* winner's loss / len when source == CTC */
+    int32_t n_tokens;               /* greedy token count */
+    int32_t n_chars;                /* normalised transcript length */
+    int32_t n_candidates;           /* candidates scored by the rerank (0 if gate passed) */
+    int32_t flags;                  /* QV_FLAG_* */
+    int32_t t_frames;               /* encoder frames of this utterance */
+} qv_result;
+
+void qv_config_default(qv_config *cfg);
+int qv_create(const qv_config *cfg, qv_engine **out);
+void qv_destroy(qv_engine *e);
+const char *qv_last_error(const qv_engine *e); /* e may be NULL: last create() error */
+
+/* Encoder frames produced for n_samples of 16 kHz audio (three stride-2 stages over
+ * floor(n/160)+1 mel frames). */
+int32_t qv_frames_for_samples(int64_t n_samples);
+
+/* Acoustic model.  audio_dev: f32[B, n_max] row-major, rows zero-padded past lengths_host[b].
+ * logprobs_dev: f32[B, t_max, 1025] with t_max >= qv_frames_for_samples(max length); rows
+ * t >= T[b] are left untouched.  t_out_host[b] receives T[b] (computed on the host, no sync). */
+int qv_forward(qv_engine *e, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
+               int64_t n_max, float *logprobs_dev, int32_t t_max, int32_t *t_out_host, void *stream);
+
+/* Post-logits stages on log-probs already in HBM.  t_host[b] = valid frames of row b.
+ * results_host: qv_result[B]; greedy_ids_host (optional, may be NULL): i32[B, t_max] collapsed
+ * token ids (-1 padded) for host-side transcript text.  SYNCHRONOUS: returns after the results
+ * have been copied back (one stream sync at the end, none in between). */
+int qv_decode_retrieve_rerank(qv_engine *e, const float *logprobs_dev, const int32_t *t_host,
+                              int32_t batch, int32_t t_max, qv_result *results_host,
+                              int32_t *greedy_ids_host, void *stream);
+
+/* Asynchronous variant: results stay in an engine-owned device buffer; fetch with
+ * qv_fetch_results() after the stream (or an event) has completed. */
+int qv_decode_retrieve_rerank_async(qv_engine *e, const float *logprobs_dev, const int32_t *t_host,
+                                    int32_t batch, int32_t t_max, void *stream);
+int qv_fetch_results(qv_engine *e, int32_t batch, int32_t t_max, qv_result *results_host,
+                     int32_t *greedy_ids_host, void *stream);
+
+/* forward + post-logits on the engine's own log-prob workspace.  SYNCHRONOUS like above. */
+int qv_predict_batch(qv_engine *e, const float *audio_dev, const int64_t *lengths_host,
+                     int32_t batch, int64_t n_max, qv_result *results_host,
+                     int32_t *greedy_ids_host, void *stream);
+int qv_predict_batch_async(qv_engine *e, const float *audio_dev, const int64_t *lengths_host,
+                           int32_t batch, int64_t n_max, void *stream);
+
+/* Device pointer of the packed (surah, ayah, ayah_end, float-bits(score)) i32[B,4] rows of the
+ * last async call -- the payload of the per-batch RCCL all-gather. */
+const int32_t *qv_packed_results_dev(qv_engine *e);
+
+/* ---- stage-level entry points used by the parity tests (each SYNCHRONOUS) ------------- */
+
+/* match_verse/search/pass-3/_build_candidates for one already-normalised transcript given
+ * as alphabet codes.  Outputs: base (start verse index, span, score); candidate list in
+ * reference order as (start index, span, text score).  cand_cap = capacity of the arrays. */
+int qv_debug_retrieve(qv_engine *e, const uint8_t *codes_host, int32_t n_codes,
+                      int32_t *base_start, int32_t *base_span, double *base_score,
+                      int32_t *cand_start, int32_t *cand_span, double *cand_score,
+                      int32_t cand_cap, int32_t *n_cand, int32_t *runner_idx, double *runner_score,
+                      int32_t *n_runners, void *stream);
+
+/* CTC negative log-likelihood (float32 alpha recursion) of n target sequences against one
+ * [T,1025] log-prob matrix in HBM.  targets_host: concatenated u16 ids, lens_host[n]. */
+int qv_debug_ctc_loss(qv_engine *e, const float *logprobs_dev, int32_t t_frames,
+                      const uint16_t *targets_host, const int32_t *lens_host, int32_t n,
+                      float *loss_host, void *stream);
+
+/* Intermediate activations of the acoustic model for the layer-wise parity tests.
+ * what: 0 = normalised mel features f32[B, t_mel_max, 80]; 1 = subsampling output
+ * f32[B, t_max, 512]; 2 = encoder output after layer `layer` f32[B, t_max, 512]. */
+int qv_debug_forward_tap(qv_engine *e, int32_t what, int32_t layer, float *out_dev, void *stream);
+
+/* Library build info: "gfx950;hip-x.y;..." */
+const char *qv_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QVERSE_H */

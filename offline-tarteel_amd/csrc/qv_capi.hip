@@ -1,0 +1,396 @@
+// qv_capi.hip -- C ABI entry points (include/qverse.h), engine lifetime, table upload.
+
+#include "qv_common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <fstream>
+#include <mutex>
+
+static std::string g_create_error;
+
+void qv_set_error(qv_engine *e, const std::string &msg) {
+    if (e) e->last_error = msg;
+    else g_create_error = msg;
+}
+
+extern "C" const char *qv_last_error(const qv_engine *e) {
+    return e ? e->last_error.c_str() : g_create_error.c_str();
+}
+
+extern "C" const char *qv_build_info(void) {
+    static char buf[128];
+    snprintf(buf, sizeof buf, "libqverse gfx950 hip-%d.%d", HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
+    return buf;
+}
+
+extern "C" void qv_config_default(qv_config *c) {
+    memset(c, 0, sizeof *c);
+    c->struct_size = (int32_t)sizeof(qv_config);
+    c->device = 0;
+    c->with_model = 1;
+    c->precision = QV_PREC_FP16;
+    c->max_batch = 64;
+    c->max_samples = 480000;
+    c->random_weights_seed = 20260630ull;
+    c->top_text = 100;
+    c->top_span_refs = 80;
+    c->max_span = 6;
+    c->threshold = 0.80;
+    c->text_weight = 0.0;
+    c->span_penalty = 0.5;
+    c->skip_unused_passes = 1;
+}
+
+extern "C" int32_t qv_frames_for_samples(int64_t n) {
+    int64_t t = n / 160 + 1;  // STFT center=True, hop 160
+    for (int i = 0; i < 3; ++i) t = (t + 2 - 3) / 2 + 1;  // conv k3 s2 p1
+    return (int32_t)t;
+}
+
+// ------------------------------------------------------------------ blob reader --------
+struct Blob {
+    std::vector<uint8_t> data;
+    const void *get(const char *name, size_t *nbytes = nullptr) const {
+        uint32_t n;
+        memcpy(&n, data.data() + 8, 4);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint8_t *e = data.data() + 16 + 40 * (size_t)i;
+            if (strncmp((const char *)e, name, 24) == 0) {
+                uint64_t off, nb;
+                memcpy(&off, e + 24, 8);
+                memcpy(&nb, e + 32, 8);
+                if (off + nb > data.size()) return nullptr;
+                if (nbytes) *nbytes = (size_t)nb;
+                return data.data() + off;
+            }
+        }
+        return nullptr;
+    }
+};
+
+template <typename T>
+static int upload(qv_engine *eng, const T *host, size_t count, const T **dev) {
+    void *p = nullptr;
+    QV_HIP(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+    eng->allocs.push_back(p);
+    if (count) QV_HIP(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T *)p;
+    return QV_OK;
+}
+
+template <typename T>
+static int dalloc(qv_engine *eng, size_t count, T **dev) {
+    void *p = nullptr;
+    QV_HIP(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+    QV_HIP(hipMemset(p, 0, std::max<size_t>(count * sizeof(T), 16)));
+    eng->allocs.push_back(p);
+    *dev = (T *)p;
+    return QV_OK;
+}
+
+#define QV_TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int load_tables(qv_engine *eng, const char *path) {
+    Blob blob;
+    {
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        if (!f) { qv_set_error(eng, std::string("cannot open tables file: ") + (path ? path : "(null)")); return QV_ERR_IO; }
+        std::streamsize sz = f.tellg();
+        f.seekg(0);
+        blob.data.resize((size_t)sz);
+        if (!f.read((char *)blob.data.data(), sz) || sz < 16 || memcmp(blob.data.data(), "QVTB0001", 8)) {
+            qv_set_error(eng, "tables file malformed (bad magic)");
+            return QV_ERR_IO;
+        }
+    }
+    const char *need[] = {"meta", "surah", "ayah", "surah_start", "surah_len", "clean_off", "clean", "alt_off", "alt",
+                          "nobsm_off", "nobsm", "clean_nw", "alt_nw", "nobsm_nw", "tok_off", "tok", "piece_off",
+                          "piece_codes", "tri_keys", "tri_idf", "vtri_off", "vtri"};
+    for (const char *n : need)
+        if (!blob.get(n)) { qv_set_error(eng, std::string("tables file lacks section ") + n); return QV_ERR_IO; }
+    const int32_t *meta = (const int32_t *)blob.get("meta");
+    int N = meta[0], NS = meta[1], K = meta[2], NT = meta[6];
+    if (K > QV_NSYM || meta[3] != QV_MAX_SPAN || meta[4] != QV_VOCAB) {
+        qv_set_error(eng, "tables file incompatible (alphabet/max_span/vocab)");
+        return QV_ERR_IO;
+    }
+    QvTables &t = eng->tab;
+    t.n_verses = N; t.n_surah = NS; t.n_tri = NT;
+    const uint8_t *surah = (const uint8_t *)blob.get("surah");
+    const uint16_t *ayah = (const uint16_t *)blob.get("ayah");
+    eng->h_surah.assign(surah, surah + N);
+    eng->h_ayah.assign(ayah, ayah + N);
+    QV_TRY(upload(eng, surah, N, &t.surah));
+    QV_TRY(upload(eng, ayah, N, &t.ayah));
+    QV_TRY(upload(eng, (const int32_t *)blob.get("surah_start"), NS + 1, &t.surah_start));
+    QV_TRY(upload(eng, (const int32_t *)blob.get("surah_len"), NS, &t.surah_len));
+    const uint32_t *coff = (const uint32_t *)blob.get("clean_off"), *aoff = (const uint32_t *)blob.get("alt_off"),
+                   *noff = (const uint32_t *)blob.get("nobsm_off");
+    const uint8_t *ctxt = (const uint8_t *)blob.get("clean"), *atxt = (const uint8_t *)blob.get("alt"),
+                  *ntxt = (const uint8_t *)blob.get("nobsm");
+    // padded clean array: verse texts separated by one space
+    std::vector<uint8_t> cpad;
+    std::vector<uint32_t> cpo(N), apo(N);
+    std::vector<uint16_t> clen(N), alen(N), nlen(N);
+    std::vector<int32_t> nrank(N, -1);
+    int n_nobsm = 0;
+    for (int v = 0; v < N; ++v) {
+        cpo[v] = (uint32_t)cpad.size();
+        clen[v] = (uint16_t)(coff[v + 1] - coff[v]);
+        cpad.insert(cpad.end(), ctxt + coff[v], ctxt + coff[v + 1]);
+        cpad.push_back(0);
+        apo[v] = aoff[v];
+        alen[v] = (uint16_t)(aoff[v + 1] - aoff[v]);
+        nlen[v] = (uint16_t)(noff[v + 1] - noff[v]);
+        if (nlen[v]) {
+            nrank[v] = n_nobsm++;
+            // the no-bismillah text must be a suffix of the clean text (it is clean[len(BSM):].strip())
+            if (nlen[v] > clen[v] || memcmp(ntxt + noff[v], ctxt + coff[v + 1] - nlen[v], nlen[v]) != 0) {
+                qv_set_error(eng, "tables: no_bsm text is not a suffix of text_clean");
+                return QV_ERR_IO;
+            }
+        }
+    }
+    cpad.resize(cpad.size() + 64, 0);
+    QV_TRY(upload(eng, cpad.data(), cpad.size(), &t.clean));
+    QV_TRY(upload(eng, cpo.data(), (size_t)N, &t.clean_off));
+    QV_TRY(upload(eng, clen.data(), (size_t)N, &t.clean_len));
+    QV_TRY(upload(eng, nlen.data(), (size_t)N, &t.nobsm_len));
+    QV_TRY(upload(eng, atxt, (size_t)aoff[N], &t.alt));
+    QV_TRY(upload(eng, apo.data(), (size_t)N, &t.alt_off));
+    QV_TRY(upload(eng, alen.data(), (size_t)N, &t.alt_len));
+    QV_TRY(upload(eng, (const uint16_t *)blob.get("clean_nw"), (size_t)N, &t.nw[0]));
+    QV_TRY(upload(eng, (const uint16_t *)blob.get("alt_nw"), (size_t)N, &t.nw[1]));
+    QV_TRY(upload(eng, (const uint16_t *)blob.get("nobsm_nw"), (size_t)N, &t.nw[2]));
+    QV_TRY(upload(eng, nrank.data(), (size_t)N, &t.nobsm_rank));
+    // per-text match masks
+    t.n_text = 2 * N + n_nobsm;
+    std::vector<uint32_t> pmo(t.n_text);
+    std::vector<uint64_t> pmv;
+    auto add_text = [&](int tid, const uint8_t *s, int len) {
+        int stride = qv_tmpl_w((len + 63) / 64);
+        pmo[tid] = (uint32_t)pmv.size();
+        pmv.resize(pmv.size() + (size_t)QV_NSYM * stride, 0ull);
+        uint64_t *base = pmv.data() + pmo[tid];
+        for (int i = 0; i < len; ++i)
+            if (s[i] < QV_NSYM) base[(size_t)s[i] * stride + (i >> 6)] |= 1ull << (i & 63);
+    };
+    for (int v = 0; v < N; ++v) {
+        add_text(v, ctxt + coff[v], clen[v]);
+    }
+    for (int v = 0; v < N; ++v) add_text(N + v, atxt + aoff[v], alen[v]);
+    for (int v = 0; v < N; ++v)
+        if (nlen[v]) add_text(2 * N + nrank[v], ntxt + noff[v], nlen[v]);
+    pmv.resize(pmv.size() + 16, 0ull);
+    QV_TRY(upload(eng, pmv.data(), pmv.size(), &t.pmv));
+    QV_TRY(upload(eng, pmo.data(), pmo.size(), &t.pmv_off));
+    QV_TRY(upload(eng, (const uint32_t *)blob.get("tri_keys"), (size_t)NT, &t.tri_keys));
+    QV_TRY(upload(eng, (const double *)blob.get("tri_idf"), (size_t)NT, &t.tri_idf));
+    const uint32_t *vto = (const uint32_t *)blob.get("vtri_off");
+    QV_TRY(upload(eng, vto, (size_t)N + 1, &t.vtri_off));
+    QV_TRY(upload(eng, (const uint16_t *)blob.get("vtri"), (size_t)vto[N], &t.vtri));
+    const uint32_t *to = (const uint32_t *)blob.get("tok_off");
+    QV_TRY(upload(eng, to, (size_t)N * QV_MAX_SPAN + 1, &t.tok_off));
+    QV_TRY(upload(eng, (const uint16_t *)blob.get("tok"), (size_t)to[(size_t)N * QV_MAX_SPAN], &t.tok));
+    const uint32_t *po = (const uint32_t *)blob.get("piece_off");
+    QV_TRY(upload(eng, po, (size_t)QV_VOCAB + 1, &t.piece_off));
+    QV_TRY(upload(eng, (const uint8_t *)blob.get("piece_codes"), (size_t)po[QV_VOCAB] + 16, &t.piece_codes));
+    return QV_OK;
+}
+
+static int alloc_work(qv_engine *eng) {
+    QvWork &w = eng->work;
+    int B = eng->cfg.max_batch, N = eng->tab.n_verses;
+    w.max_batch = B;
+    w.t_cap = qv_frames_for_samples(eng->cfg.max_samples) + 2;
+    size_t Bz = (size_t)B;
+    QV_TRY(dalloc(eng, Bz, &w.utt));
+    QV_TRY(dalloc(eng, Bz * w.t_cap, &w.frame_ids));
+    QV_TRY(dalloc(eng, Bz * w.t_cap, &w.greedy));
+    QV_TRY(dalloc(eng, Bz * QV_MAXQ, &w.q));
+    QV_TRY(dalloc(eng, Bz * QV_MAXQ, &w.qs));
+    QV_TRY(dalloc(eng, Bz * 2 * QV_NSYM * QV_MAXW, &w.pm));
+    QV_TRY(dalloc(eng, Bz * N, &w.cand1));
+    QV_TRY(dalloc(eng, Bz * N * 3, &w.fs));
+    QV_TRY(dalloc(eng, Bz * N, &w.p3));
+    w.search_sc = nullptr;
+    QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.runner_idx));
+    QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.runner_score));
+    QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.top_search));
+    QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.top_search_sc));
+    QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.top_p3));
+    QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.top_p3_sc));
+    QV_TRY(dalloc(eng, Bz * QV_SPAN_BLOCKS, &w.span_part_score));
+    QV_TRY(dalloc(eng, Bz * QV_SPAN_BLOCKS, &w.span_part_key));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_start));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_span));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_score));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_loss));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_final));
+    QV_TRY(dalloc(eng, Bz, &w.results));
+    QV_TRY(dalloc(eng, Bz * 4, &w.packed));
+    QV_TRY(dalloc(eng, Bz, &w.fail_list));
+    QV_TRY(dalloc(eng, (size_t)1, &w.n_fail));
+    QV_TRY(dalloc(eng, Bz, &eng->t_dev));
+    QV_HIP(hipHostMalloc((void **)&eng->t_host_scratch, sizeof(int32_t) * Bz, hipHostMallocDefault));
+    eng->logprobs_ws = nullptr;
+    if (eng->cfg.with_model) QV_TRY(dalloc(eng, Bz * w.t_cap * QV_VOCAB, &eng->logprobs_ws));
+    return QV_OK;
+}
+
+extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(qv_config)) {
+        qv_set_error(nullptr, "qv_create: bad config (struct_size mismatch?)");
+        return QV_ERR_ARG;
+    }
+    qv_engine *eng = new qv_engine();
+    eng->cfg = *cfg;
+    eng->model = nullptr;
+    eng->t_host_scratch = nullptr;
+    eng->last_batch = eng->last_tmax = 0;
+    auto fail = [&](int rc) {
+        g_create_error = eng->last_error;
+        qv_destroy(eng);
+        return rc;
+    };
+    if (cfg->max_span < 2 || cfg->max_span > QV_MAX_SPAN) { qv_set_error(eng, "CTC_DIRECT_MAX_SPAN must be in [2,6]"); return fail(QV_ERR_ARG); }
+    if (cfg->text_weight != 0.0) { qv_set_error(eng, "CTC_DIRECT_TEXT_WEIGHT != 0 is not supported on device"); return fail(QV_ERR_ARG); }
+    if (cfg->top_text < 1 || cfg->top_text > QV_RUNNER_CAP - 1) { qv_set_error(eng, "CTC_DIRECT_TOP_TEXT must be in [1,127]"); return fail(QV_ERR_ARG); }
+    if (cfg->top_span_refs < 0 || cfg->top_span_refs > 128) { qv_set_error(eng, "CTC_DIRECT_TOP_SPAN_REFS must be in [0,128]"); return fail(QV_ERR_ARG); }
+    if (cfg->max_batch < 1 || cfg->max_samples < 400) { qv_set_error(eng, "bad capacity"); return fail(QV_ERR_ARG); }
+    eng->knobs = {cfg->top_text, cfg->top_span_refs, cfg->max_span, cfg->threshold, cfg->text_weight,
+                  cfg->span_penalty, cfg->skip_unused_passes};
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
+        qv_set_error(eng, "no HIP device available (libqverse needs a gfx950 GPU; there is no CPU fallback)");
+        return fail(QV_ERR_HIP);
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) { qv_set_error(eng, "hipSetDevice failed"); return fail(QV_ERR_HIP); }
+    eng->device = cfg->device;
+    int rc = load_tables(eng, cfg->tables_path);
+    if (rc) return fail(rc);
+    rc = alloc_work(eng);
+    if (rc) return fail(rc);
+    if (cfg->with_model) {
+        rc = qv_model_create(eng, cfg, &eng->model);
+        if (rc) return fail(rc);
+    }
+    *out = eng;
+    return QV_OK;
+}
+
+extern "C" void qv_destroy(qv_engine *e) {
+    if (!e) return;
+    if (e->model) qv_model_destroy(e->model);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->t_host_scratch) (void)hipHostFree(e->t_host_scratch);
+    delete e;
+}
+
+extern "C" int qv_forward(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
+                          int64_t n_max, float *logprobs_dev, int32_t t_max, int32_t *t_out_host, void *stream) {
+    if (!eng) return QV_ERR_ARG;
+    if (!eng->model) { qv_set_error(eng, "engine created without a model (with_model = 0)"); return QV_ERR_NO_MODEL; }
+    return qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, logprobs_dev, t_max, t_out_host,
+                            (hipStream_t)stream);
+}
+
+extern "C" int qv_decode_retrieve_rerank_async(qv_engine *eng, const float *lp, const int32_t *t_host, int32_t batch,
+                                               int32_t t_max, void *stream) {
+    if (!eng || !lp || !t_host || batch < 1) return QV_ERR_ARG;
+    return qv_post_run(eng, lp, t_max, t_host, batch, (hipStream_t)stream);
+}
+
+extern "C" int qv_fetch_results(qv_engine *eng, int32_t batch, int32_t t_max, qv_result *res, int32_t *greedy_host,
+                                void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!eng || !res || batch < 1 || batch > eng->work.max_batch) return QV_ERR_ARG;
+    QV_HIP(hipMemcpyAsync(res, eng->work.results, sizeof(qv_result) * batch, hipMemcpyDeviceToHost, stream));
+    if (greedy_host) {
+        int tc = eng->work.t_cap;
+        int w = t_max < tc ? t_max : tc;
+        QV_HIP(hipMemcpy2DAsync(greedy_host, sizeof(int32_t) * t_max, eng->work.greedy, sizeof(int32_t) * tc,
+                                sizeof(int32_t) * w, batch, hipMemcpyDeviceToHost, stream));
+    }
+    QV_HIP(hipStreamSynchronize(stream));
+    for (int b = 0; b < batch; ++b) {
+        // authoritative score of a CTC winner: math.exp(-ctc_norm_loss) in host double libm,
+        // exactly what mixed/run.py:103-107 evaluates
+        if (res[b].source == QV_SOURCE_CTC) res[b].score = exp(-(double)res[b].ctc_norm_loss);
+        if (res[b].flags & QV_FLAG_TRANSCRIPT_TRUNCATED) { res[b].surah = res[b].ayah = res[b].ayah_end = 0; }
+    }
+    return QV_OK;
+}
+
+extern "C" int qv_decode_retrieve_rerank(qv_engine *eng, const float *lp, const int32_t *t_host, int32_t batch,
+                                         int32_t t_max, qv_result *res, int32_t *greedy_host, void *stream) {
+    int rc = qv_decode_retrieve_rerank_async(eng, lp, t_host, batch, t_max, stream);
+    if (rc) return rc;
+    return qv_fetch_results(eng, batch, t_max, res, greedy_host, stream);
+}
+
+extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host,
+                                      int32_t batch, int64_t n_max, void *stream) {
+    if (!eng) return QV_ERR_ARG;
+    if (!eng->model) { qv_set_error(eng, "engine created without a model (with_model = 0)"); return QV_ERR_NO_MODEL; }
+    if (batch > eng->work.max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
+    int64_t lmax = 0;
+    for (int b = 0; b < batch; ++b) lmax = std::max(lmax, lengths_host[b]);
+    int t_max = qv_frames_for_samples(lmax);
+    if (t_max > eng->work.t_cap) { qv_set_error(eng, "audio longer than engine capacity"); return QV_ERR_CAPACITY; }
+    std::vector<int32_t> t_out(batch);
+    int rc = qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, eng->logprobs_ws, t_max,
+                              t_out.data(), (hipStream_t)stream);
+    if (rc) return rc;
+    return qv_post_run(eng, eng->logprobs_ws, t_max, t_out.data(), batch, (hipStream_t)stream);
+}
+
+extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
+                                int64_t n_max, qv_result *res, int32_t *greedy_host, void *stream) {
+    int rc = qv_predict_batch_async(eng, audio_dev, lengths_host, batch, n_max, stream);
+    if (rc) return rc;
+    return qv_fetch_results(eng, batch, eng->last_tmax, res, greedy_host, stream);
+}
+
+extern "C" const int32_t *qv_packed_results_dev(qv_engine *eng) { return eng ? eng->work.packed : nullptr; }
+
+extern "C" int qv_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int32_t n_codes, int32_t *base_start,
+                                 int32_t *base_span, double *base_score, int32_t *cand_start, int32_t *cand_span,
+                                 double *cand_score, int32_t cand_cap, int32_t *n_cand, int32_t *runner_idx,
+                                 double *runner_score, int32_t *n_runners, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!eng) return QV_ERR_ARG;
+    int rc = qv_post_debug_retrieve(eng, codes_host, n_codes, stream);
+    if (rc) return rc;
+    QvUtt u;
+    QV_HIP(hipMemcpy(&u, eng->work.utt, sizeof(QvUtt), hipMemcpyDeviceToHost));
+    *base_start = u.base_start; *base_span = u.base_span; *base_score = u.base_score;
+    int n = u.n_cand < cand_cap ? u.n_cand : cand_cap;
+    *n_cand = u.n_cand;
+    if (n > 0) {
+        QV_HIP(hipMemcpy(cand_start, eng->work.cand_start, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        QV_HIP(hipMemcpy(cand_span, eng->work.cand_span, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        QV_HIP(hipMemcpy(cand_score, eng->work.cand_score, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    *n_runners = u.n_runners;
+    if (u.n_runners > 0) {
+        QV_HIP(hipMemcpy(runner_idx, eng->work.runner_idx, sizeof(int32_t) * u.n_runners, hipMemcpyDeviceToHost));
+        QV_HIP(hipMemcpy(runner_score, eng->work.runner_score, sizeof(double) * u.n_runners, hipMemcpyDeviceToHost));
+    }
+    return QV_OK;
+}
+
+extern "C" int qv_debug_ctc_loss(qv_engine *eng, const float *lp, int32_t T, const uint16_t *tg, const int32_t *lens,
+                                 int32_t n, float *loss_host, void *stream) {
+    if (!eng || n < 1) return QV_ERR_ARG;
+    return qv_post_debug_ctc(eng, lp, T, tg, lens, n, loss_host, (hipStream_t)stream);
+}
+
+extern "C" int qv_debug_forward_tap(qv_engine *eng, int32_t what, int32_t layer, float *out_dev, void *stream) {
+    if (!eng) return QV_ERR_ARG;
+    if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
+    return qv_model_tap(eng, eng->model, what, layer, out_dev, (hipStream_t)stream);
+}

@@ -1,0 +1,168 @@
+// qv_common.h -- internal declarations shared by the translation units of libqverse.so.
+// gfx950 only; no compatibility layers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qverse.h"
+
+#define QV_NSYM 40          // alphabet codes 0..39 (0 = ' '); 63 = matches nothing
+#define QV_OTHER 63
+#define QV_MAXQ QV_MAX_TRANSCRIPT
+#define QV_MAXW (QV_MAXQ / 64)
+#define QV_MAX_SPAN 6
+#define QV_CAND_CAP 2048
+#define QV_RUNNER_CAP 128
+#define QV_RAW_CAP 4096     // raw (pre-collapse) transcript code units per utterance
+#define QV_MAX_VW 11        // ceil(684 / 64): words of the longest verse text
+
+#define QV_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            qv_set_error(eng, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+            return QV_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// word counts the LCS core is instantiated for; verse match-mask rows are padded to these
+__host__ __device__ inline int qv_tmpl_w(int w) {
+    return w <= 1 ? 1 : w <= 2 ? 2 : w <= 3 ? 3 : w <= 4 ? 4 : w <= 6 ? 6 : w <= 8 ? 8 : w <= 11 ? 11 : 16;
+}
+
+struct qv_engine;
+void qv_set_error(qv_engine *e, const std::string &msg);
+
+// ------------------------------------------------------------------ static tables -----
+// Device-resident verse database (built once at qv_create from qverse_tables.bin).
+struct QvTables {
+    int n_verses, n_surah, n_tri, n_text;  // n_text = 2N + #nobsm
+    // verse identity
+    const uint8_t *surah;        // [N]
+    const uint16_t *ayah;        // [N]
+    const int32_t *surah_start;  // [n_surah+1]
+    const int32_t *surah_len;    // [n_surah]
+    // clean texts laid out back to back WITH one ' ' between consecutive verses, so every
+    // span text (first.no_bsm||clean + ' ' + rest.clean) is one contiguous slice
+    const uint8_t *clean;        // codes
+    const uint32_t *clean_off;   // [N]
+    const uint16_t *clean_len;   // [N]
+    const uint16_t *nobsm_len;   // [N] 0 = none; text = last nobsm_len codes of clean[v]
+    const uint8_t *alt;
+    const uint32_t *alt_off;     // [N]
+    const uint16_t *alt_len;     // [N]
+    const uint16_t *nw[3];       // word counts clean / alt / nobsm
+    const int32_t *nobsm_rank;   // [N] index among verses that have a no_bsm text, -1 otherwise
+    // per-text bit-parallel match masks (pattern = the verse text): text id = variant*N + v for
+    // variant 0/1, 2N + nobsm_rank for variant 2.  layout [QV_NSYM][words]
+    const uint64_t *pmv;
+    const uint32_t *pmv_off;     // [n_text] offset in u64 units
+    // trigram index (forward form)
+    const uint32_t *tri_keys;    // [n_tri] sorted packed trigrams
+    const double *tri_idf;       // [n_tri]
+    const uint32_t *vtri_off;    // [N+1]
+    const uint16_t *vtri;        // sorted trigram ids per verse
+    // CTC token table: key = v*6 + (span-1)
+    const uint32_t *tok_off;     // [N*6+1]
+    const uint16_t *tok;
+    // vocabulary pieces: normalised code strings
+    const uint32_t *piece_off;   // [1026]
+    const uint8_t *piece_codes;
+};
+
+// ------------------------------------------------------------------ per-batch state ---
+struct QvUtt {           // one per utterance, device memory (SoA would not buy anything here)
+    int32_t t_frames;
+    int32_t n_tok;
+    int32_t q_len, qs_len, q_words;
+    int32_t flags;
+    int32_t n_cand1;       // pass-1 iteration list length
+    int32_t full_scan;     // 1 if pass 1 iterates all verses
+    int32_t best1_idx;     // best single verse (index) after pass 1
+    double best1_score;
+    int32_t n_runners;
+    int32_t n_surah20;
+    int32_t surah20[20];
+    int32_t base_start, base_span;   // -1 = none
+    double base_score;
+    int32_t use_ctc;
+    int32_t n_cand;
+    int32_t win;           // winning candidate index or -1
+    float win_norm;
+};
+
+struct QvWork {
+    int max_batch, t_cap;
+    QvUtt *utt;              // [B]
+    int16_t *frame_ids;      // [B][t_cap]
+    int32_t *greedy;         // [B][t_cap]
+    uint8_t *q;              // [B][QV_MAXQ]
+    uint8_t *qs;             // [B][QV_MAXQ] spaceless
+    uint64_t *pm;            // [B][2][QV_NSYM][QV_MAXW]  (0: q, 1: spaceless q)
+    int32_t *cand1;          // [B][N]
+    double *fs;              // [B][N][3] fragment scores (clean, alt, nobsm)
+    double *p3;              // [B][N]   pass-3 score
+    double *search_sc;       // [B][N]   search score (max over clean/alt)
+    int32_t *runner_idx;     // [B][QV_RUNNER_CAP]
+    double *runner_score;    // [B][QV_RUNNER_CAP]
+    int32_t *top_search;     // [B][QV_RUNNER_CAP]
+    double *top_search_sc;
+    int32_t *top_p3;         // [B][QV_RUNNER_CAP]
+    double *top_p3_sc;
+    double *span_part_score; // [B][QV_SPAN_BLOCKS]
+    uint64_t *span_part_key; // [B][QV_SPAN_BLOCKS]
+    int32_t *cand_start;     // [B][QV_CAND_CAP]
+    int32_t *cand_span;      // [B][QV_CAND_CAP]
+    double *cand_score;      // [B][QV_CAND_CAP]
+    float *cand_loss;        // [B][QV_CAND_CAP]
+    double *cand_final;      // [B][QV_CAND_CAP]
+    qv_result *results;      // [B]
+    int32_t *packed;         // [B][4]
+    int32_t *fail_list;      // [B] compacted gate-fail utterance indices
+    int32_t *n_fail;         // [1]
+};
+
+#define QV_SPAN_BLOCKS 64
+
+struct QvKnobs {
+    int top_text, top_span_refs, max_span;
+    double threshold, text_weight, span_penalty;
+    int skip_unused;
+};
+
+// post-logits launcher (qv_postlogits.hip)
+int qv_post_run(qv_engine *eng, const float *logprobs_dev, int t_max, const int32_t *t_host, int batch,
+                hipStream_t stream);
+int qv_post_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int n, hipStream_t stream);
+int qv_post_debug_ctc(qv_engine *eng, const float *lp, int T, const uint16_t *tg, const int32_t *lens, int n,
+                      float *loss_host, hipStream_t stream);
+
+// acoustic model (qv_model.hip)
+struct QvModel;
+int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out);
+void qv_model_destroy(QvModel *m);
+int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio_dev, const int64_t *len_host, int batch,
+                     int64_t n_max, float *logprobs_dev, int t_max, int32_t *t_out_host, hipStream_t stream);
+int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out_dev, hipStream_t stream);
+
+struct qv_engine {
+    qv_config cfg;
+    QvKnobs knobs;
+    int device;
+    std::string last_error;
+    QvTables tab;                 // device pointers
+    std::vector<void *> allocs;   // everything hipMalloc'ed for tables/work
+    QvWork work;
+    QvModel *model;
+    float *logprobs_ws;           // [max_batch][t_cap][1025] engine-owned log-prob workspace
+    int32_t *t_host_scratch;      // pinned [max_batch]
+    int32_t *t_dev;               // [max_batch]
+    // host copies of small table parts used by debug/entry code
+    std::vector<uint8_t> h_surah;
+    std::vector<uint16_t> h_ayah;
+    int last_batch, last_tmax;
+};

@@ -1,0 +1,1031 @@
+// qv_postlogits.hip -- everything after the log-probs, on device:
+//   argmax -> CTC collapse -> piece expansion + normalisation  (c2c-direct/run.py:187-204)
+//   trigram-IDF candidates, fragment scores, span pass          (shared/quran_db.py:173-186,211-237,244-371)
+//   search / pass-3 / candidate assembly                        (quran_db.py:92-99; c2c-direct/run.py:251-311)
+//   CTC alpha-recursion rerank + decision                       (c2c-direct/run.py:314-380; mixed/run.py:96-133)
+//
+// Integer/byte work bound by LDS + VALU, not MFMA: the unit of work is a bit-parallel LCS
+// (Indel distance) between the transcript and a verse text or text window.  Mapping:
+//   * "one text per lane" kernels (pass 3, span pass): pattern = transcript bit-vector (<=16 x
+//     64-bit words in VGPRs), each lane streams its own verse/span text.
+//   * "one text per wave" kernel (fragment score): lanes = sliding windows of partial_ratio,
+//     pattern = the shorter string's match masks, lane 0 additionally does the full-string LCS.
+//   * CTC: one wave per (utterance, candidate), 2L+1 states laid contiguously across lanes,
+//     two DPP-style shuffles per frame.
+// All double arithmetic that feeds comparisons uses explicit _rn intrinsics (no FMA contraction)
+// so scores are bit-identical to the reference's Python floats.
+
+#include "qv_common.h"
+
+#include <math.h>
+
+#include <algorithm>
+
+namespace {
+
+// ------------------------------------------------------------------ small helpers ------
+
+__device__ __forceinline__ double ratio_from(int lcs, int la, int lb) {
+    int tot = la + lb;
+    if (tot == 0) return 1.0;
+    return __dsub_rn(1.0, __ddiv_rn((double)(tot - 2 * lcs), (double)tot));
+}
+
+__device__ __forceinline__ int wave_rank(bool pred, int lane, int &total) {
+    unsigned long long m = __ballot(pred);
+    total = __popcll(m);
+    return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// (score desc, key asc) ordering used by every stable "sorted(..., reverse=True)" emulation
+__device__ __forceinline__ bool better(double s, unsigned long long k, double s2, unsigned long long k2) {
+    return s > s2 || (s == s2 && k < k2);
+}
+
+__device__ __forceinline__ void wave_best(double &s, unsigned long long &k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double s2 = __shfl_xor(s, o);
+        unsigned long long k2 = __shfl_xor(k, o);
+        if (better(s2, k2, s, k)) { s = s2; k = k2; }
+    }
+}
+
+// block-wide best over 256 threads; result valid in all threads.  sh_s/sh_k: [4+1] scratch.
+__device__ __forceinline__ void block_best(double &s, unsigned long long &k, double *sh_s, unsigned long long *sh_k) {
+    wave_best(s, k);
+    int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh_s[w] = s; sh_k[w] = k; }
+    __syncthreads();
+    s = sh_s[0]; k = sh_k[0];
+    for (int i = 1; i < nw; ++i)
+        if (better(sh_s[i], sh_k[i], s, k)) { s = sh_s[i]; k = sh_k[i]; }
+}
+
+// ------------------------------------------------------------------ bit-parallel LCS ---
+// Hyyro/Crochemore: V all ones; per text char U = V & M; V = (V + U) | (V & ~M).
+// pm: match masks [sym][stride] (u64), W words used; text codes >= QV_NSYM match nothing.
+template <int W>
+__device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int stride, const uint8_t *__restrict__ text,
+                                        int n, int m) {
+    uint64_t V[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) V[w] = ~0ull;
+    for (int j = 0; j < n; ++j) {
+        int c = text[j];
+        const uint64_t *M = pm + (size_t)(c < QV_NSYM ? c : 0) * stride;
+        uint64_t zero_if_other = c < QV_NSYM ? ~0ull : 0ull;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint64_t v = V[w], mm = M[w] & zero_if_other;
+            uint64_t u = v & mm;
+            uint64_t s = v + u;
+            uint64_t c1 = s < v;
+            uint64_t s2 = s + carry;
+            uint64_t c2 = s2 < s;
+            carry = c1 | c2;
+            V[w] = s2 | (v & ~mm);
+        }
+    }
+    int zeros = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint64_t z = ~V[w];
+        int lo = w * 64;
+        if (m < lo + 64) z &= (m > lo) ? ((1ull << (m - lo)) - 1ull) : 0ull;
+        zeros += __popcll(z);
+    }
+    return zeros;
+}
+
+__device__ __forceinline__ int lcs_dispatch(int W, const uint64_t *pm, int stride, const uint8_t *text, int n, int m) {
+    if (n <= 0 || m <= 0) return 0;
+    if (W <= 1) return lcs_core<1>(pm, stride, text, n, m);
+    if (W <= 2) return lcs_core<2>(pm, stride, text, n, m);
+    if (W <= 3) return lcs_core<3>(pm, stride, text, n, m);
+    if (W <= 4) return lcs_core<4>(pm, stride, text, n, m);
+    if (W <= 6) return lcs_core<6>(pm, stride, text, n, m);
+    if (W <= 8) return lcs_core<8>(pm, stride, text, n, m);
+    if (W <= 11) return lcs_core<11>(pm, stride, text, n, m);
+    return lcs_core<16>(pm, stride, text, n, m);
+}
+
+// ------------------------------------------------------------------ 1. argmax ----------
+// one wave per frame; numpy argmax semantics (first maximum).
+__global__ __launch_bounds__(64) void k_argmax(const float *__restrict__ lp, int t_max, const QvUtt *__restrict__ utt,
+                                               int16_t *__restrict__ frame_ids, int t_cap) {
+    int b = blockIdx.y, t = blockIdx.x;
+    if (t >= utt[b].t_frames) return;
+    const float *row = lp + ((size_t)b * t_max + t) * QV_VOCAB;
+    int lane = threadIdx.x;
+    float best = row[lane];
+    int bi = lane;
+    for (int v = lane + 64; v < QV_VOCAB; v += 64) {
+        float x = row[v];
+        if (x > best) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float b2 = __shfl_xor(best, o);
+        int i2 = __shfl_xor(bi, o);
+        if (b2 > best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+    }
+    if (lane == 0) frame_ids[(size_t)b * t_cap + t] = (int16_t)bi;
+}
+
+// ------------------------------------------------------------------ 2. decode ----------
+// one wave per utterance: collapse, expand pieces into normalised codes, collapse
+// whitespace + strip, spaceless copy, match masks.
+__global__ __launch_bounds__(64) void k_decode(QvTables tab, QvWork wk) {
+    __shared__ uint8_t raw[QV_RAW_CAP];
+    __shared__ unsigned long long pm[2][QV_NSYM][QV_MAXW];
+    int b = blockIdx.x, lane = threadIdx.x;
+    QvUtt &u = wk.utt[b];
+    int T = u.t_frames;
+    const int16_t *fid = wk.frame_ids + (size_t)b * wk.t_cap;
+    int32_t *greedy = wk.greedy + (size_t)b * wk.t_cap;
+    int n_tok = 0;
+    for (int base = 0; base < T; base += 64) {
+        int t = base + lane;
+        int id = -1;
+        bool keep = false;
+        if (t < T) {
+            id = fid[t];
+            int prev = t > 0 ? fid[t - 1] : -1;
+            keep = id != prev && id != QV_BLANK;
+        }
+        int tot, r = wave_rank(keep, lane, tot);
+        if (keep) greedy[n_tok + r] = id;
+        n_tok += tot;
+    }
+    for (int t = n_tok + lane; t < wk.t_cap; t += 64) greedy[t] = -1;
+    __syncthreads();
+    // piece expansion
+    int n_raw = 0;
+    bool trunc = false;
+    for (int base = 0; base < n_tok; base += 64) {
+        int k = base + lane;
+        int id = k < n_tok ? greedy[k] : -1;
+        int len = id >= 0 ? (int)(tab.piece_off[id + 1] - tab.piece_off[id]) : 0;
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int x = __shfl_up(incl, o);
+            if (lane >= o) incl += x;
+        }
+        int off = n_raw + incl - len;
+        if (off + len > QV_RAW_CAP) { trunc = true; len = 0; }
+        const uint8_t *src = tab.piece_codes + (id >= 0 ? tab.piece_off[id] : 0);
+        for (int i = 0; i < len; ++i) raw[off + i] = src[i];
+        n_raw += __shfl(incl, 63);
+    }
+    trunc = __any(trunc);
+    if (n_raw > QV_RAW_CAP) n_raw = QV_RAW_CAP;
+    __syncthreads();
+    int last_ns = -1;
+    for (int i = lane; i < n_raw; i += 64)
+        if (raw[i] != 0) last_ns = i;
+    last_ns = wave_max_i(last_ns);
+    uint8_t *q = wk.q + (size_t)b * QV_MAXQ, *qs = wk.qs + (size_t)b * QV_MAXQ;
+    int qn = 0, qsn = 0, spaces = 0;
+    for (int base = 0; base < n_raw; base += 64) {
+        int i = base + lane;
+        int c = i < n_raw ? raw[i] : 0;
+        bool keep = i < n_raw && (c != 0 ? true : (i > 0 && raw[i - 1] != 0 && i < last_ns));
+        int tot, r = wave_rank(keep, lane, tot);
+        if (keep && qn + r < QV_MAXQ) q[qn + r] = (uint8_t)c;
+        bool ks = keep && c != 0;
+        int tots, rs = wave_rank(ks, lane, tots);
+        if (ks && qsn + rs < QV_MAXQ) qs[qsn + rs] = (uint8_t)c;
+        spaces += tot - tots;
+        qn += tot;
+        qsn += tots;
+    }
+    if (qn > QV_MAXQ) trunc = true;
+    int flags = 0;
+    if (trunc) { flags |= QV_FLAG_TRANSCRIPT_TRUNCATED; qn = 0; qsn = 0; }
+    else if (qn == 0) flags |= QV_FLAG_EMPTY_TRANSCRIPT;
+    // match masks
+    unsigned long long *pmf = &pm[0][0][0];
+    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) pmf[i] = 0ull;
+    __syncthreads();
+    for (int i = lane; i < qn; i += 64) {
+        int c = q[i];
+        if (c < QV_NSYM) atomicOr(&pm[0][c][i >> 6], 1ull << (i & 63));
+    }
+    for (int i = lane; i < qsn; i += 64) {
+        int c = qs[i];
+        if (c < QV_NSYM) atomicOr(&pm[1][c][i >> 6], 1ull << (i & 63));
+    }
+    __syncthreads();
+    uint64_t *gpm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
+    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) gpm[i] = pmf[i];
+    if (lane == 0) {
+        u.n_tok = n_tok;
+        u.q_len = qn;
+        u.qs_len = qsn;
+        u.q_words = qn > 0 ? spaces + 1 : 0;
+        u.flags = flags;
+        u.base_start = -1; u.base_span = 0; u.base_score = 0.0;
+        u.use_ctc = 0; u.n_cand = 0; u.win = -1; u.win_norm = 0.f;
+        u.n_cand1 = 0; u.full_scan = 0; u.n_runners = 0; u.n_surah20 = 0;
+        u.best1_idx = -1; u.best1_score = 0.0;
+    }
+}
+
+// debug path: transcript codes already in wk.q (uploaded by the host); build the rest.
+__global__ __launch_bounds__(64) void k_prepare_codes(QvWork wk, int n) {
+    __shared__ unsigned long long pm[2][QV_NSYM][QV_MAXW];
+    int lane = threadIdx.x;
+    QvUtt &u = wk.utt[0];
+    uint8_t *q = wk.q, *qs = wk.qs;
+    int qsn = 0, spaces = 0;
+    for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        int c = i < n ? q[i] : 0;
+        bool ks = i < n && c != 0;
+        int tot, r = wave_rank(ks, lane, tot);
+        if (ks) qs[qsn + r] = (uint8_t)c;
+        qsn += tot;
+        int ts;
+        wave_rank(i < n && c == 0, lane, ts);
+        spaces += ts;
+    }
+    unsigned long long *pmf = &pm[0][0][0];
+    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) pmf[i] = 0ull;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { int c = q[i]; if (c < QV_NSYM) atomicOr(&pm[0][c][i >> 6], 1ull << (i & 63)); }
+    for (int i = lane; i < qsn; i += 64) { int c = qs[i]; if (c < QV_NSYM) atomicOr(&pm[1][c][i >> 6], 1ull << (i & 63)); }
+    __syncthreads();
+    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) wk.pm[i] = pmf[i];
+    if (lane == 0) {
+        u.t_frames = 0; u.n_tok = 0; u.q_len = n; u.qs_len = qsn; u.q_words = n > 0 ? spaces + 1 : 0;
+        u.flags = n == 0 ? QV_FLAG_EMPTY_TRANSCRIPT : 0;
+        u.base_start = -1; u.base_span = 0; u.base_score = 0.0;
+        u.use_ctc = 0; u.n_cand = 0; u.win = -1; u.win_norm = 0.f;
+        u.n_cand1 = 0; u.full_scan = 0; u.n_runners = 0; u.n_surah20 = 0; u.best1_idx = -1; u.best1_score = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ 3. trigram top-50 --
+// CPython set[int] iteration order of ints inserted one by one (Objects/setobject.c: linear
+// probes 9, perturb shift 5, x4 growth at fill*5 >= mask*3); match_verse iterates
+// set(top-50) (quran_db.py:279-288) and sorts stably, so exact ties resolve in this order.
+__device__ int pyset_order(const int32_t *vals, int n, int32_t *out, int32_t *tabA, int32_t *tabB) {
+    int mask = 7;
+    int32_t *tab = tabA;
+    for (int i = 0; i <= mask; ++i) tab[i] = -1;
+    int fill = 0;
+    for (int k = 0; k < n; ++k) {
+        unsigned long long h = (unsigned long long)vals[k], perturb = h;
+        int i = (int)(h & (unsigned)mask);
+        int found = 0;
+        for (;;) {
+            int probes = (i + 9 <= mask) ? 9 : 0;
+            int e = i;
+            do {
+                if (tab[e] < 0) { tab[e] = vals[k]; ++fill; found = 1; break; }
+                if (tab[e] == vals[k]) { found = 2; break; }
+                ++e;
+            } while (probes--);
+            if (found) break;
+            perturb >>= 5;
+            i = (int)(((unsigned long long)i * 5ull + 1ull + perturb) & (unsigned)mask);
+        }
+        if (found == 1 && fill * 5 >= mask * 3) {
+            int minused = fill * 4, ns = 8;
+            while (ns <= minused) ns <<= 1;
+            int32_t *nt = (tab == tabA) ? tabB : tabA;
+            for (int z = 0; z < ns; ++z) nt[z] = -1;
+            int nmask = ns - 1;
+            for (int z = 0; z <= mask; ++z) {
+                if (tab[z] < 0) continue;
+                unsigned long long hh = (unsigned long long)tab[z], pp = hh;
+                int j = (int)(hh & (unsigned)nmask);
+                for (;;) {
+                    if (nt[j] < 0) { nt[j] = tab[z]; break; }
+                    bool placed = false;
+                    if (j + 9 <= nmask)
+                        for (int q = 1; q <= 9; ++q)
+                            if (nt[j + q] < 0) { nt[j + q] = tab[z]; placed = true; break; }
+                    if (placed) break;
+                    pp >>= 5;
+                    j = (int)(((unsigned long long)j * 5ull + 1ull + pp) & (unsigned)nmask);
+                }
+            }
+            tab = nt;
+            mask = nmask;
+        }
+    }
+    int c = 0;
+    for (int z = 0; z <= mask; ++z)
+        if (tab[z] >= 0) out[c++] = tab[z];
+    return c;
+}
+
+#define TRI_WORDS 352  // >= ceil(10243/32), multiple of 32
+
+__global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *score = (double *)smem;                            // [N]
+    uint32_t *bits = (uint32_t *)(score + tab.n_verses);       // [TRI_WORDS]
+    double *sh_s = (double *)(bits + TRI_WORDS);               // [8]
+    unsigned long long *sh_k = (unsigned long long *)(sh_s + 8);  // [8]
+    int32_t *top = (int32_t *)(sh_k + 8);                      // [64]
+    int32_t *tabA = top + 64;                                  // [256]
+    int32_t *tabB = tabA + 256;                                // [256]
+    int *cnt = (int *)(tabB + 256);
+    int b = blockIdx.x, tid = threadIdx.x;
+    QvUtt &u = wk.utt[b];
+    int m = u.q_len;
+    if (m == 0) return;
+    const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
+    for (int i = tid; i < TRI_WORDS; i += 256) bits[i] = 0;
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    for (int i = tid; i + 2 < m; i += 256) {
+        uint32_t key = ((uint32_t)q[i] << 12) | ((uint32_t)q[i + 1] << 6) | q[i + 2];
+        int lo = 0, hi = tab.n_tri - 1, id = -1;
+        while (lo <= hi) {
+            int mid = (lo + hi) >> 1;
+            uint32_t kv = tab.tri_keys[mid];
+            if (kv == key) { id = mid; break; }
+            if (kv < key) lo = mid + 1; else hi = mid - 1;
+        }
+        if (id >= 0) atomicOr(&bits[id >> 5], 1u << (id & 31));
+    }
+    __syncthreads();
+    int N = tab.n_verses, local = 0;
+    for (int v = tid; v < N; v += 256) {
+        double s = 0.0;
+        bool touched = false;
+        for (uint32_t p = tab.vtri_off[v]; p < tab.vtri_off[v + 1]; ++p) {
+            int id = tab.vtri[p];
+            if (bits[id >> 5] >> (id & 31) & 1u) { s = __dadd_rn(s, tab.tri_idf[id]); touched = true; }
+        }
+        score[v] = touched ? s : -1.0;
+        local += touched;
+    }
+    atomicAdd(cnt, local);
+    __syncthreads();
+    int touched_total = *cnt;
+    int32_t *cand1 = wk.cand1 + (size_t)b * N;
+    if (touched_total < 20) {  // quran_db.py:285-286
+        for (int v = tid; v < N; v += 256) cand1[v] = v;
+        if (tid == 0) { u.n_cand1 = N; u.full_scan = 1; }
+        return;
+    }
+    int K = touched_total < 50 ? touched_total : 50;
+    for (int r = 0; r < K; ++r) {
+        double s = -1.0;
+        unsigned long long k = ~0ull;
+        for (int v = tid; v < N; v += 256) {
+            double x = score[v];
+            if (x >= 0.0 && better(x, (unsigned long long)v, s, k)) { s = x; k = v; }
+        }
+        block_best(s, k, sh_s, sh_k);
+        if (tid == 0) { top[r] = (int32_t)k; score[k] = -2.0; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int n = pyset_order(top, K, cand1, tabA, tabB);
+        u.n_cand1 = n;
+        u.full_scan = 0;
+    }
+}
+
+// ------------------------------------------------------------------ 4. fragment score --
+// quran_db.py:211-237 (_fragment_score) with partial_ratio (:10-28) inlined.  One wave per
+// (utterance, verse text).  mode 0: texts of the pass-1 iteration list; mode 1: every text
+// of every gate-failed utterance (search()).
+struct TextRef { const uint8_t *p; int n; int nw; int tid; };
+
+__device__ __forceinline__ TextRef text_of(const QvTables &tab, int v, int variant) {
+    TextRef t;
+    if (variant == 0) { t.p = tab.clean + tab.clean_off[v]; t.n = tab.clean_len[v]; t.nw = tab.nw[0][v]; t.tid = v; }
+    else if (variant == 1) { t.p = tab.alt + tab.alt_off[v]; t.n = tab.alt_len[v]; t.nw = tab.nw[1][v]; t.tid = tab.n_verses + v; }
+    else {
+        int nl = tab.nobsm_len[v];
+        t.p = tab.clean + tab.clean_off[v] + tab.clean_len[v] - nl; t.n = nl; t.nw = tab.nw[2][v];
+        t.tid = 2 * tab.n_verses + tab.nobsm_rank[v];
+    }
+    return t;
+}
+
+__device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane) {
+    const QvUtt &u = wk.utt[b];
+    double *out = wk.fs + ((size_t)b * tab.n_verses + v) * 3 + variant;
+    if (variant == 2 && tab.nobsm_len[v] == 0) { if (lane == 0) *out = -1.0; return; }
+    TextRef t = text_of(tab, v, variant);
+    int m = u.q_len, n = t.n, qw = u.q_words, vw = t.nw;
+    const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
+    // " text " in " verse "  (word-boundary substring)
+    bool sub = false;
+    if (qw >= 3 && m <= n) {
+        for (int i = lane; i + m <= n && !sub; i += 64) {
+            if (i > 0 && t.p[i - 1] != 0) continue;
+            if (i + m < n && t.p[i + m] != 0) continue;
+            bool ok = true;
+            for (int k = 0; k < m; ++k)
+                if (q[k] != t.p[i + k] || q[k] >= QV_NSYM) { ok = false; break; }
+            sub = ok;
+        }
+        sub = __any(sub);
+    }
+    bool windows = !sub && qw >= 4 && vw >= 2;
+    // pattern = shorter string, text = (windows of) the longer one
+    const uint64_t *pm;
+    int stride, s, L;
+    const uint8_t *lt;
+    if (m <= n) { pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW; stride = QV_MAXW; s = m; lt = t.p; L = n; }
+    else { pm = tab.pmv + tab.pmv_off[t.tid]; stride = qv_tmpl_w((n + 63) >> 6); s = n; lt = q; L = m; }
+    int W = (s + 63) >> 6;
+    int nwin = windows ? (L - s + 1) : 0;
+    int full = 0, best = 0;
+    // lane 0 of round 0 carries the full-string LCS, the other lanes windows
+    int total = nwin + 1;
+    for (int base = 0; base < total; base += 64) {
+        int job = base + lane;
+        if (job >= total) continue;
+        if (job == 0) full = lcs_dispatch(W, pm, stride, lt, L, s);
+        else { int r = lcs_dispatch(W, pm, stride, lt + (job - 1), s, s); best = max(best, r); }
+    }
+    best = wave_max_i(best);
+    if (lane == 0) {
+        double fr = ratio_from(full, m, n);
+        double res = fr;
+        if (sub) res = fr > 0.98 ? fr : 0.98;
+        else if (windows) {
+            double frag = ratio_from(best, s, s);
+            if (frag > fr) {
+                double pen = __ddiv_rn((double)vw, (double)(qw > 1 ? qw : 1));
+                if (pen > 1.0) pen = 1.0;
+                double blended = __dadd_rn(__dmul_rn(0.25, fr), __dmul_rn(__dmul_rn(0.75, frag), pen));
+                res = fr > blended ? fr : blended;
+            }
+        }
+        *out = res;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode) {
+    int lane = threadIdx.x & 63;
+    int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    int b;
+    if (mode == 0) b = blockIdx.y;
+    else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
+    const QvUtt &u = wk.utt[b];
+    if (u.q_len == 0) return;
+    if (mode == 0) {
+        const int32_t *cand1 = wk.cand1 + (size_t)b * tab.n_verses;
+        int jobs = u.n_cand1 * 3;
+        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, cand1[j / 3], j % 3, lane);
+    } else {
+        int jobs = tab.n_verses * 2;  // search(): clean + alt only (quran_db.py:105-110)
+        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, j >> 1, j & 1, lane);
+    }
+}
+
+// ------------------------------------------------------------------ 5. pass-1 finalize -
+// stable descending sort of min(raw,1.0) in iteration order (quran_db.py:290-331): only the
+// first max(top_k,5) entries are ever used, selected by repeated block argmax.
+__global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, QvKnobs kn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *sc = (double *)smem;  // [n_cand1]
+    double *sh_s = sc + tab.n_verses;
+    unsigned long long *sh_k = (unsigned long long *)(sh_s + 8);
+    int b = blockIdx.x, tid = threadIdx.x;
+    QvUtt &u = wk.utt[b];
+    if (u.q_len == 0) return;
+    int n = u.n_cand1, N = tab.n_verses;
+    const int32_t *cand1 = wk.cand1 + (size_t)b * N;
+    const double *fs = wk.fs + (size_t)b * N * 3;
+    for (int p = tid; p < n; p += 256) {
+        int v = cand1[p];
+        double a = fs[v * 3], c = fs[v * 3 + 1], d = fs[v * 3 + 2];
+        double raw = a > c ? a : c;
+        if (d > raw) raw = d;
+        sc[p] = raw < 1.0 ? raw : 1.0;
+    }
+    __syncthreads();
+    int K = kn.top_text > 5 ? kn.top_text : 5;
+    if (K > n) K = n;
+    if (K > QV_RUNNER_CAP) K = QV_RUNNER_CAP;
+    int K20 = n < 20 ? n : 20;
+    int rounds = K > K20 ? K : K20;
+    int32_t *ridx = wk.runner_idx + (size_t)b * QV_RUNNER_CAP;
+    double *rsc = wk.runner_score + (size_t)b * QV_RUNNER_CAP;
+    for (int r = 0; r < rounds; ++r) {
+        double s = -1.0;
+        unsigned long long k = ~0ull;
+        for (int p = tid; p < n; p += 256) {
+            double x = sc[p];
+            if (x >= 0.0 && better(x, (unsigned long long)p, s, k)) { s = x; k = p; }
+        }
+        block_best(s, k, sh_s, sh_k);
+        if (tid == 0) {
+            int v = cand1[k];
+            sc[k] = -2.0;
+            if (r < QV_RUNNER_CAP) { ridx[r] = v; rsc[r] = s; }
+            if (r == 0) { u.best1_idx = v; u.best1_score = s; }
+            if (r < K20) {
+                int su = tab.surah[v];
+                bool seen = false;
+                for (int i = 0; i < u.n_surah20; ++i) seen |= (u.surah20[i] == su);
+                if (!seen) u.surah20[u.n_surah20++] = su;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) u.n_runners = K < kn.top_text ? K : kn.top_text;
+}
+
+// ------------------------------------------------------------------ 6. span pass -------
+// quran_db.py:334-365: every window of 2..max_span ayat of the surahs of the top 20.  One
+// span text per lane; texts are contiguous slices of the padded clean array.  A span is
+// skipped when even LCS = min(m, n) could not beat the pass-1 best (exact pruning).
+__global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs kn) {
+    __shared__ double sh_s[8];
+    __shared__ unsigned long long sh_k[8];
+    int b = blockIdx.y, tid = threadIdx.x;
+    const QvUtt &u = wk.utt[b];
+    double best = -1.0;
+    unsigned long long bkey = ~0ull;
+    if (u.q_len > 0) {
+        int m = u.q_len, W = (m + 63) >> 6;
+        const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
+        int per = kn.max_span - 1;
+        unsigned long long jbase = 0;
+        for (int si = 0; si < u.n_surah20; ++si) {
+            int s = u.surah20[si];
+            int s0 = tab.surah_start[s - 1], sl = tab.surah_len[s - 1];
+            int jobs = sl * per;
+            for (int j = blockIdx.x * 256 + tid; j < jobs; j += gridDim.x * 256) {
+                int i = j / per, span = 2 + j % per;
+                if (i + span > sl) continue;
+                int v0 = s0 + i, v1 = v0 + span - 1;
+                int nl = tab.nobsm_len[v0];
+                uint32_t start = tab.clean_off[v0] + (nl ? tab.clean_len[v0] - nl : 0);
+                int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
+                int mn = m < n ? m : n;
+                if (!(ratio_from(mn, m, n) > u.best1_score)) continue;
+                int l = lcs_dispatch(W, pm, QV_MAXW, tab.clean + start, n, m);
+                double raw = ratio_from(l, m, n);
+                double sc = raw < 1.0 ? raw : 1.0;
+                unsigned long long key = jbase + (unsigned long long)j;
+                if (better(sc, key, best, bkey)) { best = sc; bkey = key; }
+            }
+            jbase += (unsigned long long)jobs;
+        }
+    }
+    block_best(best, bkey, sh_s, sh_k);
+    if (tid == 0) {
+        wk.span_part_score[(size_t)b * QV_SPAN_BLOCKS + blockIdx.x] = best;
+        wk.span_part_key[(size_t)b * QV_SPAN_BLOCKS + blockIdx.x] = bkey;
+    }
+}
+
+// base = better of pass-1 best and span best; gate; result for the text branch.
+__global__ void k_base_final(QvTables tab, QvWork wk, QvKnobs kn, int batch, int force_ctc) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    QvUtt &u = wk.utt[b];
+    if (u.q_len == 0) return;
+    double best = -1.0;
+    unsigned long long key = ~0ull;
+    for (int i = 0; i < QV_SPAN_BLOCKS; ++i) {
+        double s = wk.span_part_score[(size_t)b * QV_SPAN_BLOCKS + i];
+        unsigned long long k = wk.span_part_key[(size_t)b * QV_SPAN_BLOCKS + i];
+        if (better(s, k, best, key)) { best = s; key = k; }
+    }
+    u.base_start = u.best1_idx; u.base_span = 1; u.base_score = u.best1_score;
+    if (best > u.best1_score) {
+        int per = kn.max_span - 1;
+        unsigned long long j = key;
+        for (int si = 0; si < u.n_surah20; ++si) {
+            int s = u.surah20[si];
+            unsigned long long jobs = (unsigned long long)tab.surah_len[s - 1] * per;
+            if (j < jobs) {
+                u.base_start = tab.surah_start[s - 1] + (int)(j / per);
+                u.base_span = 2 + (int)(j % per);
+                u.base_score = best;
+                break;
+            }
+            j -= jobs;
+        }
+    }
+    u.use_ctc = (u.base_score < kn.threshold) || force_ctc;
+    if (u.use_ctc) u.flags |= QV_FLAG_USED_CTC;
+    // the "slow list": utterances whose search()/pass-3/candidate stages must run.  With
+    // skip_unused == 0 that is every utterance, as in the reference (mixed/run.py:84 precedes
+    // the gate at :96); their output is only consumed when use_ctc is set.
+    if (u.use_ctc || !kn.skip_unused) {
+        int slot = atomicAdd(wk.n_fail, 1);
+        wk.fail_list[slot] = b;
+    }
+}
+
+// ------------------------------------------------------------------ 7. pass 3 ----------
+// c2c-direct/run.py:284-297: max(ratio(t, clean), ratio(t.spaceless, clean.spaceless)); a
+// space matches nothing in the spaceless pattern, so the spaced text is streamed for both.
+__global__ __launch_bounds__(256) void k_pass3(QvTables tab, QvWork wk) {
+    if ((int)blockIdx.y >= *wk.n_fail) return;
+    int b = wk.fail_list[blockIdx.y];
+    const QvUtt &u = wk.utt[b];
+    int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= tab.n_verses || u.q_len == 0) return;
+    int m = u.q_len, ms = u.qs_len;
+    const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
+    const uint8_t *t = tab.clean + tab.clean_off[v];
+    int n = tab.clean_len[v], ns = n - (tab.nw[0][v] - 1);
+    int l1 = lcs_dispatch((m + 63) >> 6, pm, QV_MAXW, t, n, m);
+    int l2 = lcs_dispatch((ms + 63) >> 6, pm + QV_NSYM * QV_MAXW, QV_MAXW, t, n, ms);
+    double a = ratio_from(l1, m, n), c = ratio_from(l2, ms, ns);
+    wk.p3[(size_t)b * tab.n_verses + v] = a > c ? a : c;
+}
+
+// top-k (score desc, verse index asc) of search() and pass 3
+__global__ __launch_bounds__(256) void k_topk(QvTables tab, QvWork wk, QvKnobs kn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *sc = (double *)smem;
+    double *sh_s = sc + tab.n_verses;
+    unsigned long long *sh_k = (unsigned long long *)(sh_s + 8);
+    if ((int)blockIdx.x >= *wk.n_fail) return;
+    int b = wk.fail_list[blockIdx.x], which = blockIdx.y, tid = threadIdx.x;
+    int N = tab.n_verses;
+    if (wk.utt[b].q_len == 0) return;
+    if (which == 0) {
+        const double *fs = wk.fs + (size_t)b * N * 3;
+        for (int v = tid; v < N; v += 256) { double a = fs[v * 3], c = fs[v * 3 + 1]; sc[v] = a > c ? a : c; }
+    } else {
+        const double *p3 = wk.p3 + (size_t)b * N;
+        for (int v = tid; v < N; v += 256) sc[v] = p3[v];
+    }
+    __syncthreads();
+    int K = kn.top_text < QV_RUNNER_CAP ? kn.top_text : QV_RUNNER_CAP;
+    if (K > N) K = N;
+    int32_t *oi = (which == 0 ? wk.top_search : wk.top_p3) + (size_t)b * QV_RUNNER_CAP;
+    double *os = (which == 0 ? wk.top_search_sc : wk.top_p3_sc) + (size_t)b * QV_RUNNER_CAP;
+    for (int r = 0; r < K; ++r) {
+        double s = -1.0;
+        unsigned long long k = ~0ull;
+        for (int v = tid; v < N; v += 256) {
+            double x = sc[v];
+            if (x >= 0.0 && better(x, (unsigned long long)v, s, k)) { s = x; k = v; }
+        }
+        block_best(s, k, sh_s, sh_k);
+        if (tid == 0) { oi[r] = (int32_t)k; os[r] = s; sc[k] = -2.0; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ 8. candidates ------
+// c2c-direct/run.py:251-311: ordered, de-duplicated union + span expansion of the first
+// top_span_refs single refs.  Sequential by construction (order defines CTC tie-breaks);
+// one lane per gate-failed utterance does ~2k bitmap inserts.
+__device__ __forceinline__ double py_round3(double x) {
+    // round(x, 3) for x in [0, 1]: nearest k/1000 (ties cannot occur for non-representable
+    // thousandths; exact halves x = (2k+1)/2000 are not binary fractions), then k/1000.0
+    double y = __dmul_rn(x, 1000.0);
+    double k = rint(y);
+    // correct the (rare) case where x*1000 rounded across the .5 boundary
+    double lo = __ddiv_rn(k - 0.5, 1000.0), hi = __ddiv_rn(k + 0.5, 1000.0);
+    if (x < lo) k -= 1.0; else if (x > hi) k += 1.0;
+    return __ddiv_rn(k, 1000.0);
+}
+
+__global__ __launch_bounds__(64) void k_candidates(QvTables tab, QvWork wk, QvKnobs kn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char seen[];  // [N] bit per span
+    if ((int)blockIdx.x >= *wk.n_fail) return;
+    int b = wk.fail_list[blockIdx.x], lane = threadIdx.x;
+    QvUtt &u = wk.utt[b];
+    int N = tab.n_verses;
+    for (int i = lane; i < N; i += 64) seen[i] = 0;
+    __syncthreads();
+    if (lane != 0 || u.q_len == 0) return;
+    int32_t *cs = wk.cand_start + (size_t)b * QV_CAND_CAP;
+    int32_t *cp = wk.cand_span + (size_t)b * QV_CAND_CAP;
+    double *csc = wk.cand_score + (size_t)b * QV_CAND_CAP;
+    int n = 0, nrefs = 0;
+    int32_t refs[128];
+    bool overflow = false;
+    auto add = [&](int st, int sp, double scv) {
+        unsigned char bit = (unsigned char)(1u << (sp - 1));
+        if (seen[st] & bit) return;
+        seen[st] |= bit;
+        if (n >= QV_CAND_CAP) { overflow = true; return; }
+        cs[n] = st; cp[n] = sp; csc[n] = scv; ++n;
+    };
+    auto ref = [&](int v) { if (nrefs < kn.top_span_refs && nrefs < 128) refs[nrefs++] = v; };
+    if (u.base_start >= 0) {
+        add(u.base_start, u.base_span, u.base_score);
+        ref(u.base_start);
+        const int32_t *ri = wk.runner_idx + (size_t)b * QV_RUNNER_CAP;
+        const double *rs = wk.runner_score + (size_t)b * QV_RUNNER_CAP;
+        for (int i = 0; i < u.n_runners; ++i) { add(ri[i], 1, py_round3(rs[i])); ref(ri[i]); }
+    }
+    int K = kn.top_text < QV_RUNNER_CAP ? kn.top_text : QV_RUNNER_CAP;
+    if (K > N) K = N;
+    const int32_t *ti = wk.top_search + (size_t)b * QV_RUNNER_CAP;
+    const double *ts = wk.top_search_sc + (size_t)b * QV_RUNNER_CAP;
+    for (int i = 0; i < K; ++i) { add(ti[i], 1, ts[i]); ref(ti[i]); }
+    ti = wk.top_p3 + (size_t)b * QV_RUNNER_CAP;
+    ts = wk.top_p3_sc + (size_t)b * QV_RUNNER_CAP;
+    for (int i = 0; i < K; ++i) { add(ti[i], 1, ts[i]); ref(ti[i]); }
+    for (int r = 0; r < nrefs; ++r) {
+        int v = refs[r], s = tab.surah[v], a = tab.ayah[v];
+        int s0 = tab.surah_start[s - 1], max_ayah = tab.surah_len[s - 1];
+        int lo = a - kn.max_span + 1; if (lo < 1) lo = 1;
+        int hi = a < max_ayah ? a : max_ayah;
+        for (int st = lo; st <= hi; ++st) {
+            int e0 = a > st + 1 ? a : st + 1;
+            int e1 = st + kn.max_span - 1; if (e1 > max_ayah) e1 = max_ayah;
+            for (int en = e0; en <= e1; ++en) add(s0 + st - 1, en - st + 1, 0.0);
+        }
+    }
+    u.n_cand = n;
+    if (overflow) u.flags |= QV_FLAG_CAND_OVERFLOW;
+}
+
+// ------------------------------------------------------------------ 9. CTC -------------
+// ATen LossCTC.cpp float32 alpha recursion (what F.ctc_loss runs on CPU for the reference,
+// c2c-direct/run.py:354-362).  One wave per target; state s = lane*NS + k.
+template <int NS>
+__device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tgt, int L, int lane) {
+    const float NEG = -INFINITY;
+    int S = 2 * L + 1;
+    int tok[NS];
+    bool skip_ok[NS];
+    float a[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        int s = lane * NS + k;
+        tok[k] = QV_BLANK;
+        skip_ok[k] = false;
+        if (s < S && (s & 1)) {
+            tok[k] = tgt[s >> 1];
+            skip_ok[k] = s > 1 && tgt[s >> 1] != tgt[(s >> 1) - 1];
+        }
+        a[k] = NEG;
+        if (s == 0) a[k] = lp[QV_BLANK];
+        if (s == 1) a[k] = lp[tok[k]];
+    }
+    float cur[NS], nxt[NS];
+    if (T > 1) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) cur[k] = lp[(size_t)QV_VOCAB + tok[k]];
+    }
+    for (int t = 1; t < T; ++t) {
+        if (t + 1 < T) {
+            const float *row = lp + (size_t)(t + 1) * QV_VOCAB;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) nxt[k] = row[tok[k]];
+        }
+        // previous lane's last two states
+        float p1 = __shfl_up(a[NS - 1], 1), p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1) : __shfl_up(a[NS - 1], 2);
+        if (lane == 0) { p1 = NEG; p2 = NEG; }
+        if (NS == 1 && lane == 1) p2 = NEG;
+        float na[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            int s = lane * NS + k;
+            float la1 = a[k];
+            float la2 = k >= 1 ? a[k - 1] : p1;
+            float la3 = k >= 2 ? a[k - 2] : (k == 1 ? p1 : p2);
+            if (NS == 1) la3 = p2;
+            if (!skip_ok[k]) la3 = NEG;
+            float lamax = fmaxf(la1, fmaxf(la2, la3));
+            if (lamax == NEG) lamax = 0.f;
+            float v = logf(expf(la1 - lamax) + expf(la2 - lamax) + expf(la3 - lamax)) + lamax + cur[k];
+            na[k] = s < S ? v : NEG;
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { a[k] = na[k]; cur[k] = nxt[k]; }
+    }
+    // l1 = a[S-1], l2 = a[S-2]
+    float l1 = NEG, l2 = NEG;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        int s = lane * NS + k;
+        if (s == S - 1) l1 = a[k];
+        if (s == S - 2) l2 = a[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { l1 = fmaxf(l1, __shfl_xor(l1, o)); l2 = fmaxf(l2, __shfl_xor(l2, o)); }
+    float m = fmaxf(l1, l2);
+    if (m == NEG) m = 0.f;
+    float ll = logf(expf(l1 - m) + expf(l2 - m)) + m;
+    return -ll;
+}
+
+__device__ float ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L, int lane) {
+    int S = 2 * L + 1;
+    if (S <= 64) return ctc_wave<1>(lp, T, tgt, L, lane);
+    if (S <= 128) return ctc_wave<2>(lp, T, tgt, L, lane);
+    if (S <= 192) return ctc_wave<3>(lp, T, tgt, L, lane);
+    if (S <= 256) return ctc_wave<4>(lp, T, tgt, L, lane);
+    if (S <= 384) return ctc_wave<6>(lp, T, tgt, L, lane);
+    if (S <= 512) return ctc_wave<8>(lp, T, tgt, L, lane);
+    return ctc_wave<12>(lp, T, tgt, L, lane);
+}
+
+__global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn, const float *__restrict__ lp, int t_max) {
+    if ((int)blockIdx.y >= *wk.n_fail) return;
+    int b = wk.fail_list[blockIdx.y];
+    const QvUtt &u = wk.utt[b];
+    if (!u.use_ctc) return;
+    int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    int T = u.t_frames;
+    const float *lpb = lp + (size_t)b * t_max * QV_VOCAB;
+    for (int c = wave; c < u.n_cand; c += nwave) {
+        int st = wk.cand_start[(size_t)b * QV_CAND_CAP + c], sp = wk.cand_span[(size_t)b * QV_CAND_CAP + c];
+        size_t key = (size_t)st * QV_MAX_SPAN + (sp - 1);
+        int L = (int)(tab.tok_off[key + 1] - tab.tok_off[key]);
+        float loss = INFINITY;
+        double fin = -INFINITY;
+        if (L > 0 && 2 * L + 1 <= T && 2 * L + 1 <= 768) {  // gate of c2c-direct/run.py:332
+            loss = ctc_dispatch(lpb, T, tab.tok + tab.tok_off[key], L, lane);
+            if (isinf(loss)) loss = 0.f;  // zero_infinity=True
+            float norm = __fdiv_rn(loss, (float)L);
+            // -norm + TEXT_WEIGHT*text_score - SPAN_PENALTY*(span_len-1), in Python doubles
+            double tw = __dmul_rn(kn.text_weight, wk.cand_score[(size_t)b * QV_CAND_CAP + c]);
+            fin = __dsub_rn(__dadd_rn(-(double)norm, tw), __dmul_rn(kn.span_penalty, (double)(sp - 1)));
+        }
+        if (lane == 0) {
+            wk.cand_loss[(size_t)b * QV_CAND_CAP + c] = loss;
+            wk.cand_final[(size_t)b * QV_CAND_CAP + c] = fin;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ctc_debug(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tg,
+                                                  const int32_t *__restrict__ off, int n, float *__restrict__ loss) {
+    int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= n) return;
+    int L = off[c + 1] - off[c];
+    float l = ctc_dispatch(lp, T, tg + off[c], L, lane);
+    if (lane == 0) loss[c] = l;
+}
+
+// ------------------------------------------------------------------ 10. decision -------
+// mixed/run.py:96-133.  ranked = stable sort by final desc of finite-loss candidates -> the
+// winner is the first maximum.
+__global__ __launch_bounds__(256) void k_result(QvTables tab, QvWork wk, int batch) {
+    __shared__ double sh_s[8];
+    __shared__ unsigned long long sh_k[8];
+    int b = blockIdx.x, tid = threadIdx.x;
+    QvUtt &u = wk.utt[b];
+    double best = -INFINITY;
+    unsigned long long key = ~0ull;
+    if (u.use_ctc) {
+        for (int c = tid; c < u.n_cand; c += 256) {
+            float l = wk.cand_loss[(size_t)b * QV_CAND_CAP + c];
+            if (!isfinite(l)) continue;
+            double f = wk.cand_final[(size_t)b * QV_CAND_CAP + c];
+            if (key == ~0ull || better(f, (unsigned long long)c, best, key)) { best = f; key = c; }
+        }
+    }
+    // block_best with -inf scores: "better" handles -inf vs -inf via key
+    block_best(best, key, sh_s, sh_k);
+    if (tid != 0) return;
+    qv_result r;
+    r.surah = r.ayah = r.ayah_end = 0;
+    r.source = QV_SOURCE_NONE;
+    r.score = 0.0;
+    r.base_score = u.base_start >= 0 ? u.base_score : 0.0;
+    r.ctc_norm_loss = 0.f;
+    r.n_tokens = u.n_tok;
+    r.n_chars = u.q_len;
+    r.n_candidates = u.n_cand;
+    r.flags = u.flags;
+    r.t_frames = u.t_frames;
+    if (u.q_len > 0) {
+        if (u.use_ctc && key != ~0ull) {
+            int c = (int)key;
+            int st = wk.cand_start[(size_t)b * QV_CAND_CAP + c], sp = wk.cand_span[(size_t)b * QV_CAND_CAP + c];
+            size_t tk = (size_t)st * QV_MAX_SPAN + (sp - 1);
+            int L = (int)(tab.tok_off[tk + 1] - tab.tok_off[tk]);
+            float norm = __fdiv_rn(wk.cand_loss[(size_t)b * QV_CAND_CAP + c], (float)L);
+            r.source = QV_SOURCE_CTC;
+            r.ctc_norm_loss = norm;
+            r.score = exp(-(double)norm);  // host recomputes with libm for the authoritative value
+            r.surah = tab.surah[st]; r.ayah = tab.ayah[st]; r.ayah_end = r.ayah + sp - 1;
+            u.win = c; u.win_norm = norm;
+        } else if (u.base_start >= 0) {
+            r.source = QV_SOURCE_TEXT;
+            r.score = u.base_score;
+            r.surah = tab.surah[u.base_start]; r.ayah = tab.ayah[u.base_start];
+            r.ayah_end = r.ayah + u.base_span - 1;
+        }
+    }
+    wk.results[b] = r;
+    wk.packed[b * 4 + 0] = r.surah;
+    wk.packed[b * 4 + 1] = r.ayah;
+    wk.packed[b * 4 + 2] = r.ayah_end;
+    wk.packed[b * 4 + 3] = __float_as_int((float)r.score);
+}
+
+__global__ void k_init_utts(QvWork wk, const int32_t *__restrict__ t_dev, int batch) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *wk.n_fail = 0;
+    if (b < batch) wk.utt[b].t_frames = t_dev[b];
+}
+
+}  // namespace
+
+// ====================================================================== host side =======
+
+static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_t stream) {
+    QvTables &tab = eng->tab;
+    QvWork &wk = eng->work;
+    QvKnobs kn = eng->knobs;
+    int N = tab.n_verses;
+    size_t sm_tri = (size_t)N * 8 + TRI_WORDS * 4 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 16;
+    hipLaunchKernelGGL(k_trigram, dim3(batch), dim3(256), sm_tri, stream, tab, wk);
+    hipLaunchKernelGGL(k_frag, dim3(64, batch), dim3(256), 0, stream, tab, wk, 0);
+    size_t sm_p1 = (size_t)N * 8 + 8 * 8 + 8 * 8;
+    hipLaunchKernelGGL(k_pass1_final, dim3(batch), dim3(256), sm_p1, stream, tab, wk, kn);
+    hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
+    hipLaunchKernelGGL(k_base_final, dim3((batch + 63) / 64), dim3(64), 0, stream, tab, wk, kn, batch, force_ctc);
+    // gate-failed utterances only (device-side list; blocks past n_fail exit at once)
+    hipLaunchKernelGGL(k_frag, dim3(128, batch), dim3(256), 0, stream, tab, wk, 1);
+    hipLaunchKernelGGL(k_pass3, dim3((N + 255) / 256, batch), dim3(256), 0, stream, tab, wk);
+    hipLaunchKernelGGL(k_topk, dim3(batch, 2), dim3(256), sm_p1, stream, tab, wk, kn);
+    hipLaunchKernelGGL(k_candidates, dim3(batch), dim3(64), (size_t)N, stream, tab, wk, kn);
+    return QV_OK;
+}
+
+int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_host, int batch, hipStream_t stream) {
+    QvTables &tab = eng->tab;
+    QvWork &wk = eng->work;
+    if (batch > wk.max_batch || t_max > wk.t_cap) {
+        qv_set_error(eng, "batch or frame count exceeds engine capacity");
+        return QV_ERR_CAPACITY;
+    }
+    for (int b = 0; b < batch; ++b) {
+        if (t_host[b] < 0 || t_host[b] > t_max) { qv_set_error(eng, "t_host[b] out of range"); return QV_ERR_ARG; }
+        eng->t_host_scratch[b] = t_host[b];
+    }
+    QV_HIP(hipMemcpyAsync(eng->t_dev, eng->t_host_scratch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);
+    hipLaunchKernelGGL(k_argmax, dim3(t_max, batch), dim3(64), 0, stream, lp, t_max, wk.utt, wk.frame_ids, wk.t_cap);
+    hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);
+    int rc = launch_retrieval(eng, batch, 0, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ctc, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+    hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
+    QV_HIP(hipGetLastError());
+    eng->last_batch = batch;
+    eng->last_tmax = t_max;
+    return QV_OK;
+}
+
+int qv_post_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int n, hipStream_t stream) {
+    QvWork &wk = eng->work;
+    if (n > QV_MAXQ) { qv_set_error(eng, "transcript longer than QV_MAX_TRANSCRIPT"); return QV_ERR_CAPACITY; }
+    int32_t zero = 0;
+    QV_HIP(hipMemcpyAsync(eng->t_dev, &zero, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_init_utts, dim3(1), dim3(64), 0, stream, wk, eng->t_dev, 1);
+    if (n > 0) QV_HIP(hipMemcpyAsync(wk.q, codes_host, n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_prepare_codes, dim3(1), dim3(64), 0, stream, wk, n);
+    int rc = launch_retrieval(eng, 1, 1, stream);
+    if (rc) return rc;
+    QV_HIP(hipGetLastError());
+    QV_HIP(hipStreamSynchronize(stream));
+    return QV_OK;
+}
+
+int qv_post_debug_ctc(qv_engine *eng, const float *lp, int T, const uint16_t *tg, const int32_t *lens, int n,
+                      float *loss_host, hipStream_t stream) {
+    std::vector<int32_t> off(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (lens[i] <= 0 || 2 * lens[i] + 1 > 768) { qv_set_error(eng, "target length unsupported"); return QV_ERR_ARG; }
+        off[i + 1] = off[i] + lens[i];
+    }
+    uint16_t *d_t = nullptr;
+    int32_t *d_o = nullptr;
+    float *d_l = nullptr;
+    QV_HIP(hipMalloc(&d_t, sizeof(uint16_t) * std::max(1, off[n])));
+    QV_HIP(hipMalloc(&d_o, sizeof(int32_t) * (n + 1)));
+    QV_HIP(hipMalloc(&d_l, sizeof(float) * std::max(1, n)));
+    QV_HIP(hipMemcpyAsync(d_t, tg, sizeof(uint16_t) * off[n], hipMemcpyHostToDevice, stream));
+    QV_HIP(hipMemcpyAsync(d_o, off.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_ctc_debug, dim3(n), dim3(64), 0, stream, lp, T, d_t, d_o, n, d_l);
+    QV_HIP(hipMemcpyAsync(loss_host, d_l, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
+    QV_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d_t); (void)hipFree(d_o); (void)hipFree(d_l);
+    return QV_OK;
+}

@@ -1,0 +1,328 @@
+"""ctypes binding of libqverse.so (include/qverse.h) + the host-side glue the plugin needs.
+
+PyTorch-ROCm is used for device memory and streams only: tensors are handed to the C ABI as
+raw device pointers.  There is NO CPU fallback: if the HIP library is missing or no GPU is
+visible, construction raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import LIB_PATH, TABLES_PATH
+from .normalizer import normalize_arabic
+from .tables import Tables
+
+QV_SOURCE = {0: None, 1: "text", 2: "ctc"}
+FLAG_EMPTY, FLAG_TRUNC, FLAG_USED_CTC, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
+
+
+class QvError(RuntimeError):
+    pass
+
+
+class QvConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32),
+        ("tables_path", C.c_char_p), ("weights_path", C.c_char_p),
+        ("random_weights_seed", C.c_uint64),
+        ("with_model", C.c_int32), ("precision", C.c_int32),
+        ("max_batch", C.c_int32), ("max_samples", C.c_int32),
+        ("top_text", C.c_int32), ("top_span_refs", C.c_int32), ("max_span", C.c_int32),
+        ("threshold", C.c_double), ("text_weight", C.c_double), ("span_penalty", C.c_double),
+        ("skip_unused_passes", C.c_int32),
+    ]
+
+
+class QvResult(C.Structure):
+    _fields_ = [
+        ("surah", C.c_int32), ("ayah", C.c_int32), ("ayah_end", C.c_int32), ("source", C.c_int32),
+        ("score", C.c_double), ("base_score", C.c_double), ("ctc_norm_loss", C.c_float),
+        ("n_tokens", C.c_int32), ("n_chars", C.c_int32), ("n_candidates", C.c_int32),
+        ("flags", C.c_int32), ("t_frames", C.c_int32),
+    ]
+
+
+RESULT_DTYPE = np.dtype([
+    ("surah", "<i4"), ("ayah", "<i4"), ("ayah_end", "<i4"), ("source", "<i4"),
+    ("score", "<f8"), ("base_score", "<f8"), ("ctc_norm_loss", "<f4"),
+    ("n_tokens", "<i4"), ("n_chars", "<i4"), ("n_candidates", "<i4"),
+    ("flags", "<i4"), ("t_frames", "<i4"),
+], align=True)
+assert RESULT_DTYPE.itemsize == C.sizeof(QvResult)
+
+_lib = None
+
+
+def load_library(path: Path | str | None = None) -> C.CDLL:
+    """Load libqverse.so; fail loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = Path(path or os.environ.get("QVERSE_LIB", LIB_PATH))
+    if not p.exists():
+        raise QvError(f"{p} not found: build it with `python offline-tarteel_amd/build.py` "
+                      "(hipcc, gfx950). There is no CPU fallback for this path.")
+    lib = C.CDLL(str(p))
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.qv_config_default.argtypes = [C.POINTER(QvConfig)]
+    lib.qv_config_default.restype = None
+    lib.qv_create.argtypes = [C.POINTER(QvConfig), C.POINTER(vp)]
+    lib.qv_destroy.argtypes = [vp]
+    lib.qv_destroy.restype = None
+    lib.qv_last_error.argtypes = [vp]
+    lib.qv_last_error.restype = C.c_char_p
+    lib.qv_build_info.restype = C.c_char_p
+    lib.qv_frames_for_samples.argtypes = [i64]
+    lib.qv_frames_for_samples.restype = i32
+    lib.qv_forward.argtypes = [vp, vp, vp, i32, i64, vp, i32, vp, vp]
+    lib.qv_decode_retrieve_rerank.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.qv_decode_retrieve_rerank_async.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.qv_fetch_results.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.qv_predict_batch.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp]
+    lib.qv_predict_batch_async.argtypes = [vp, vp, vp, i32, i64, vp]
+    lib.qv_packed_results_dev.argtypes = [vp]
+    lib.qv_packed_results_dev.restype = vp
+    lib.qv_debug_retrieve.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.qv_debug_ctc_loss.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
+    lib.qv_debug_forward_tap.argtypes = [vp, i32, i32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def exported_symbols() -> list[str]:
+    """Every function include/qverse.h declares (used by the CPU load/export test)."""
+    import re
+
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "qverse.h").read_text()
+    return sorted(set(re.findall(r"\b(qv_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def env_knobs() -> dict:
+    """CTC_DIRECT_* environment knobs with the reference's names and defaults
+    (experiments/c2c-direct/run.py:62-74)."""
+    return dict(
+        top_text=int(os.getenv("CTC_DIRECT_TOP_TEXT", "100")),
+        top_span_refs=int(os.getenv("CTC_DIRECT_TOP_SPAN_REFS", "80")),
+        max_span=int(os.getenv("CTC_DIRECT_MAX_SPAN", "6")),
+        threshold=float(os.getenv("CTC_DIRECT_THRESHOLD", "0.80")),
+        text_weight=float(os.getenv("CTC_DIRECT_TEXT_WEIGHT", "0.0")),
+        span_penalty=float(os.getenv("CTC_DIRECT_SPAN_PENALTY", "0.5")),
+    )
+
+
+class Engine:
+    """One engine per process per GPU (weights + verse tables resident for its lifetime)."""
+
+    def __init__(self, device: int = 0, with_model: bool = True, weights_path: str | None = None,
+                 seed: int = 20260630, precision: int = 0, max_batch: int = 64, max_samples: int = 480000,
+                 tables_path: str | None = None, skip_unused_passes: bool = True, **knobs):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise QvError("no ROCm device visible: the qverse hot path runs on MI355X only (no CPU fallback)")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = device
+        self.tables_path = str(tables_path or TABLES_PATH)
+        if not Path(self.tables_path).exists():
+            raise FileNotFoundError(self.tables_path)
+        if weights_path is not None and not Path(weights_path).exists():
+            raise FileNotFoundError(f"No weight file at {weights_path}")
+        cfg = QvConfig()
+        self.lib.qv_config_default(C.byref(cfg))
+        cfg.device = device
+        self._keep = (self.tables_path.encode(), weights_path.encode() if weights_path else None)
+        cfg.tables_path, cfg.weights_path = self._keep
+        cfg.random_weights_seed = seed
+        cfg.with_model = int(with_model)
+        cfg.precision = precision
+        cfg.max_batch = max_batch
+        cfg.max_samples = max_samples
+        cfg.skip_unused_passes = int(skip_unused_passes)
+        kn = env_knobs()
+        kn.update(knobs)
+        for k, v in kn.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = self.lib.qv_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            msg = self.lib.qv_last_error(None).decode()
+            if rc == 2:
+                raise FileNotFoundError(msg)
+            raise QvError(f"qv_create failed ({rc}): {msg}")
+        self.h = h
+        self.max_batch = max_batch
+        self.tables = Tables(self.tables_path)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.qv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- helpers ----
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise QvError(f"{what} failed ({rc}): {self.lib.qv_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def frames_for(self, n_samples: int) -> int:
+        return int(self.lib.qv_frames_for_samples(int(n_samples)))
+
+    def _results(self, res: np.ndarray, greedy: np.ndarray | None) -> list[dict]:
+        out = []
+        for b in range(len(res)):
+            r = res[b]
+            d = {
+                "surah": int(r["surah"]), "ayah": int(r["ayah"]),
+                "ayah_end": int(r["ayah_end"]) if r["surah"] else None,
+                "score": float(r["score"]), "source": QV_SOURCE[int(r["source"])],
+                "base_score": float(r["base_score"]), "ctc_norm_loss": float(r["ctc_norm_loss"]),
+                "n_candidates": int(r["n_candidates"]), "flags": int(r["flags"]),
+                "t_frames": int(r["t_frames"]), "use_ctc": bool(r["flags"] & FLAG_USED_CTC),
+            }
+            if greedy is not None:
+                ids = greedy[b, : int(r["n_tokens"])].tolist()
+                d["greedy_ids"] = ids
+                d["transcript"] = self.transcript_of(ids)
+            out.append(d)
+        return out
+
+    def transcript_of(self, ids) -> str:
+        """c2c-direct/run.py:201-204: ids_to_text(...).strip() then normalize_arabic."""
+        if not ids:
+            return ""
+        return normalize_arabic(self.tables.ids_to_text(ids).strip())
+
+    # ---------------------------------------------------------------- stages -----
+    def forward(self, audio, lengths):
+        """audio: float32 cuda tensor [B, N] (zero padded); lengths: int sequence.
+        Returns (log_probs [B, Tmax, 1025] cuda float32, T list)."""
+        torch = self.torch
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.is_contiguous()
+        B, N = audio.shape
+        ln = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        assert len(ln) == B and ln.max() <= N
+        t_max = self.frames_for(int(ln.max()))
+        lp = torch.empty((B, t_max, 1025), dtype=torch.float32, device=audio.device)
+        t_out = np.zeros(B, dtype=np.int32)
+        rc = self.lib.qv_forward(self.h, C.c_void_p(audio.data_ptr()), ln.ctypes.data_as(C.c_void_p), B, N,
+                                 C.c_void_p(lp.data_ptr()), t_max, t_out.ctypes.data_as(C.c_void_p), self._stream())
+        self._check(rc, "qv_forward")
+        return lp, t_out.tolist()
+
+    def decode_retrieve_rerank(self, log_probs, t_frames, want_text: bool = True) -> list[dict]:
+        torch = self.torch
+        assert log_probs.is_cuda and log_probs.dtype == torch.float32 and log_probs.is_contiguous()
+        B, t_max, V = log_probs.shape
+        assert V == 1025
+        t = np.ascontiguousarray(np.asarray(t_frames, dtype=np.int32))
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        greedy = np.full((B, t_max), -1, dtype=np.int32) if want_text else None
+        rc = self.lib.qv_decode_retrieve_rerank(
+            self.h, C.c_void_p(log_probs.data_ptr()), t.ctypes.data_as(C.c_void_p), B, t_max,
+            res.ctypes.data_as(C.c_void_p),
+            greedy.ctypes.data_as(C.c_void_p) if greedy is not None else None, self._stream())
+        self._check(rc, "qv_decode_retrieve_rerank")
+        return self._results(res, greedy)
+
+    def predict_batch(self, audio, lengths, want_text: bool = True) -> list[dict]:
+        torch = self.torch
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.is_contiguous()
+        B, N = audio.shape
+        ln = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        t_max = self.frames_for(int(ln.max()))
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        greedy = np.full((B, t_max), -1, dtype=np.int32) if want_text else None
+        rc = self.lib.qv_predict_batch(
+            self.h, C.c_void_p(audio.data_ptr()), ln.ctypes.data_as(C.c_void_p), B, N,
+            res.ctypes.data_as(C.c_void_p),
+            greedy.ctypes.data_as(C.c_void_p) if greedy is not None else None, self._stream())
+        self._check(rc, "qv_predict_batch")
+        return self._results(res, greedy)
+
+    def predict_batch_async(self, audio, lengths):
+        B, N = audio.shape
+        ln = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        rc = self.lib.qv_predict_batch_async(self.h, C.c_void_p(audio.data_ptr()),
+                                             ln.ctypes.data_as(C.c_void_p), B, N, self._stream())
+        self._check(rc, "qv_predict_batch_async")
+
+    def packed_results(self, batch: int):
+        """int32 cuda tensor view [batch, 4] = (surah, ayah, ayah_end, float-bits(score)) of the
+        last async call (the payload of the per-batch all-gather)."""
+        torch = self.torch
+        ptr = self.lib.qv_packed_results_dev(self.h)
+        out = torch.empty((batch, 4), dtype=torch.int32, device=f"cuda:{self.device}")
+        # device-to-device copy out of the engine-owned buffer on the current stream
+        import ctypes
+
+        hip = _hip_runtime()
+        rc = hip.hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), batch * 16, 3, self._stream())
+        if rc != 0:
+            raise QvError(f"hipMemcpyAsync failed ({rc})")
+        return out
+
+    # ---------------------------------------------------------------- debug ------
+    def debug_retrieve(self, transcript: str) -> dict:
+        """match_verse + candidate assembly for an already-normalised transcript."""
+        codes = np.ascontiguousarray(self.tables.encode(transcript))
+        cap = 2048
+        bs, bp, nc, nr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        bsc = C.c_double()
+        cs = np.zeros(cap, np.int32)
+        cp = np.zeros(cap, np.int32)
+        csc = np.zeros(cap, np.float64)
+        ri = np.zeros(128, np.int32)
+        rs = np.zeros(128, np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.qv_debug_retrieve(self.h, p(codes), len(codes), C.byref(bs), C.byref(bp), C.byref(bsc),
+                                        p(cs), p(cp), p(csc), cap, C.byref(nc), p(ri), p(rs), C.byref(nr),
+                                        self._stream())
+        self._check(rc, "qv_debug_retrieve")
+        n = min(nc.value, cap)
+        return {"base_start": bs.value, "base_span": bp.value, "base_score": bsc.value,
+                "cand_start": cs[:n].copy(), "cand_span": cp[:n].copy(), "cand_score": csc[:n].copy(),
+                "runner_idx": ri[: nr.value].copy(), "runner_score": rs[: nr.value].copy()}
+
+    def debug_ctc_loss(self, log_probs_2d, id_lists) -> np.ndarray:
+        assert log_probs_2d.is_cuda and log_probs_2d.dim() == 2 and log_probs_2d.is_contiguous()
+        tg = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint16) for x in id_lists]))
+        lens = np.ascontiguousarray(np.array([len(x) for x in id_lists], np.int32))
+        out = np.zeros(len(id_lists), np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.qv_debug_ctc_loss(self.h, C.c_void_p(log_probs_2d.data_ptr()), log_probs_2d.shape[0],
+                                        p(tg), p(lens), len(id_lists), p(out), self._stream())
+        self._check(rc, "qv_debug_ctc_loss")
+        return out
+
+    def forward_tap(self, what: int, layer: int, shape):
+        out = self.torch.empty(shape, dtype=self.torch.float32, device=f"cuda:{self.device}")
+        rc = self.lib.qv_debug_forward_tap(self.h, what, layer, C.c_void_p(out.data_ptr()), self._stream())
+        self._check(rc, "qv_debug_forward_tap")
+        return out
+
+
+_hip = None
+
+
+def _hip_runtime():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    return _hip

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: the HIP library builds, loads and exports every
+symbol include/qverse.h declares (no compute calls without a GPU)."""
+
+import ctypes
+
+import pytest
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    import importlib.util
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("_qv_build", str(root / "offline-tarteel_amd" / "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    lib_path = b.build()
+    lib = ctypes.CDLL(str(lib_path))
+    from offline_tarteel_amd.engine import exported_symbols
+
+    syms = exported_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"libqverse.so lacks {s}"
+    lib.qv_build_info.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.qv_build_info()
+    lib.qv_frames_for_samples.argtypes = [ctypes.c_int64]
+    assert lib.qv_frames_for_samples(160000) == 126
+    assert lib.qv_frames_for_samples(80000) == 63
+    assert lib.qv_frames_for_samples(480000) == 376
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from offline_tarteel_amd.engine import Engine, QvError
+
+    with pytest.raises(QvError):
+        Engine(with_model=False)
+
+
+def test_product_never_imports_oracle():
+    from pathlib import Path
+
+    pkg = Path(__file__).resolve().parent.parent / "offline-tarteel_amd"
+    for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
+        txt = p.read_text(encoding="utf-8", errors="ignore")
+        assert "oracle" not in txt.lower() or p.name == "build.py", p

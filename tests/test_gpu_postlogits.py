@@ -1,0 +1,149 @@
+"""HIP post-logits stages vs the CPU oracle / reference fixtures, through the C ABI (GPU)."""
+
+import gzip
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from synth import synth_logits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from offline_tarteel_amd.engine import Engine
+
+    eng = Engine(device=0, with_model=False, max_batch=16)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def ret_cases(golden_dir):
+    return json.load(gzip.open(golden_dir / "retrieval_cases.json.gz"))
+
+
+@pytest.fixture(scope="module")
+def e2e_cases(golden_dir):
+    return json.load(gzip.open(golden_dir / "e2e_cases.json.gz"))
+
+
+def lp_of(recipe):
+    lg = synth_logits(recipe["ids"], recipe["T"], seed=recipe["seed"], noise=recipe["noise"],
+                      boost=recipe["boost"], rep=recipe["rep"])
+    return torch.log_softmax(torch.from_numpy(lg), dim=-1)
+
+
+def test_ctc_loss_kernel_vs_torch(engine, oracle):
+    """float32 alpha recursion: |loss - F.ctc_loss| <= 1e-3 absolute (north_star: 1e-2)."""
+    rng = np.random.default_rng(0)
+    for T, noise in ((20, 1.0), (63, 2.0), (126, 1.0), (251, 3.0), (376, 1.0)):
+        ids0 = oracle.token_ids(int(rng.integers(0, 6236)), 1).tolist()
+        lp = torch.log_softmax(torch.from_numpy(synth_logits(ids0, T, seed=T, noise=noise, boost=5.0, rep=2)), -1)
+        targets = []
+        for _ in range(40):
+            L = int(rng.integers(1, max(2, (T - 1) // 2 + 1)))
+            t = rng.integers(0, 1024, size=L)
+            if rng.random() < 0.5 and L > 2:
+                t[1] = t[0]  # repeated token -> no skip transition
+            targets.append(t.astype(np.uint16))
+        targets.append(np.asarray(ids0[: max(1, (T - 1) // 2)], np.uint16))
+        want = oracle.ctc_loss_torch(lp.numpy(), targets)
+        got = engine.debug_ctc_loss(lp.cuda().contiguous(), targets)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max() / 100), (T, np.abs(got - want).max())
+
+
+def test_retrieval_matches_reference_fixtures(engine, oracle, ret_cases):
+    from oracle.oracle import normalize_arabic
+
+    checked = 0
+    for c in ret_cases:
+        t = c["transcript"]
+        if normalize_arabic(t) != t or c["name"] == "garbage_40":
+            continue  # device entry takes normalised transcripts (greedy decode output always is)
+        r = engine.debug_retrieve(t)
+        g = c["match"]
+        key = engine.tables.key_of(r["base_start"], r["base_span"])
+        want_end = g["ayah_end"] if g["ayah_end"] is not None else g["ayah"]
+        assert key == (g["surah"], g["ayah"], want_end), c["name"]
+        assert r["base_score"] == g["score"], c["name"]
+        run = [[int(engine.tables.surah[i]), int(engine.tables.ayah[i]), round(float(s), 3)]
+               for i, s in zip(r["runner_idx"], r["runner_score"])]
+        assert run == g["runners_up"], c["name"]
+        keys = [list(engine.tables.key_of(int(a), int(b))) for a, b in zip(r["cand_start"], r["cand_span"])]
+        assert keys == c["candidates"], c["name"]
+        assert r["cand_score"].tolist() == c["cand_scores"], c["name"]
+        checked += 1
+    assert checked >= 18
+
+
+def test_retrieval_matches_oracle_on_tie_case(engine, oracle, ret_cases):
+    c = [x for x in ret_cases if x["name"] == "garbage_40"][0]
+    r = engine.debug_retrieve(c["transcript"])
+    cs, cp, sc, m = oracle.build_candidates(c["transcript"])
+    assert (r["base_start"], r["base_span"], r["base_score"]) == (m.start, m.span, m.score)
+    assert r["cand_start"].tolist() == cs.tolist() and r["cand_span"].tolist() == cp.tolist()
+    assert r["cand_score"].tolist() == sc.tolist()
+
+
+def test_end_to_end_fixtures_batched(engine, oracle, e2e_cases):
+    """all e2e fixtures in ONE ragged batch: greedy ids, transcript, winner, score."""
+    lps = [lp_of(c["recipe"]) for c in e2e_cases]
+    t_max = max(x.shape[0] for x in lps)
+    B = len(lps)
+    batch = torch.full((B, t_max, 1025), -50.0)
+    for b, x in enumerate(lps):
+        batch[b, : x.shape[0]] = x
+    res = engine.decode_retrieve_rerank(batch.cuda().contiguous(), [x.shape[0] for x in lps])
+    for c, r in zip(e2e_cases, res):
+        g = c["result"]
+        assert r["greedy_ids"] == c["greedy_ids"], c["name"]
+        assert r["transcript"] == c["transcript"], c["name"]
+        assert (r["surah"], r["ayah"], r["ayah_end"], r["source"]) == (
+            g["surah"], g["ayah"], g["ayah_end"], g["source"]), c["name"]
+        if g["source"] == "text":
+            assert r["score"] == g["score_raw"], c["name"]
+        elif g["source"] == "ctc":
+            assert abs(r["score"] - g["score_raw"]) <= 1e-3 * max(g["score_raw"], 1e-3), c["name"]
+            assert round(r["score"], 4) == g["score"] or abs(r["score"] - g["score_raw"]) < 1e-6, c["name"]
+        if "use_ctc" in c:
+            assert r["use_ctc"] == c["use_ctc"], c["name"]
+            if c["use_ctc"]:
+                assert r["n_candidates"] == c["n_candidates"], c["name"]
+
+
+def test_random_transcripts_vs_oracle(engine, oracle):
+    """seeded perturbed verses / spans: device == oracle for base + full candidate list."""
+    import random
+
+    from oracle.oracle import normalize_arabic
+
+    rnd = random.Random(11)
+    letters = [ch for ch in oracle.alphabet if ch != " "][:28]
+    for it in range(12):
+        v = rnd.randrange(6236)
+        span = rnd.choice([1, 1, 2, 3])
+        last = int(oracle.t["surah_start"][oracle.surah[v]]) - 1
+        span = max(1, min(span, last - v + 1))
+        text = " ".join(oracle.verse_text(v + k) for k in range(span))
+        rate = rnd.choice([0.0, 0.1, 0.3, 0.6])
+        out = []
+        for ch in text:
+            x = rnd.random()
+            if x < rate / 3:
+                continue
+            out.append(rnd.choice(letters) if x < 2 * rate / 3 else ch)
+        # the device entry takes normalised transcripts (what greedy decode always produces)
+        t = normalize_arabic(" ".join("".join(out).split())[:900])
+        if not t:
+            continue
+        r = engine.debug_retrieve(t)
+        cs, cp, sc, m = oracle.build_candidates(t)
+        assert (r["base_start"], r["base_span"], r["base_score"]) == (m.start, m.span, m.score), (it, t)
+        assert r["cand_start"].tolist() == cs.tolist(), it
+        assert r["cand_span"].tolist() == cp.tolist(), it
+        assert r["cand_score"].tolist() == sc.tolist(), it
