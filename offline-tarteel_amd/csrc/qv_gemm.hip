@@ -1,0 +1,169 @@
+// qv_gemm.hip -- fused-epilogue f16 GEMM on v_mfma_f32_32x32x16_f16 (see qv_kernels.h).
+
+#include "qv_kernels.h"
+
+#include <stdio.h>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+    // direct global->LDS, 16 B per lane; LDS destination = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+}  // namespace
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WN = BN / 2;   // columns per wave
+    constexpr int NF = WN / 32;  // 32-wide B fragments per wave
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t *sA0 = (half_t *)smem, *sA1 = (half_t *)(smem + A_BYTES);
+    half_t *sB0 = (half_t *)(smem + 2 * A_BYTES), *sB1 = (half_t *)(smem + 2 * A_BYTES + B_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD
+    // a contiguous run of tiles that share the A row panel so its private L2 sees the reuse.
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gx + blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
+
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    auto stage = [&](int kt, half_t *sA, half_t *sB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int chunk = wave * 4 + q;
+            int row = chunk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ (row & 7);
+            int grow = m0 + row;
+            grow = grow < g.M ? grow : g.M - 1;
+            glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            int chunk = wave * (BN / 32) + q;
+            int row = chunk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ (row & 7);
+            glds16(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8, sB + chunk * 512);
+        }
+    };
+
+    stage(0, sA0, sB0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        half_t *sA = (kt & 1) ? sA1 : sA0, *sB = (kt & 1) ? sB1 : sB0;
+        if (kt + 1 < nk) stage(kt + 1, (kt & 1) ? sA0 : sA1, (kt & 1) ? sB0 : sB1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 a[2], b[NF];
+            int c = ks * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int row = wm * 64 + i * 32 + (lane & 31);
+                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                int row = wn * WN + j * 32 + (lane & 31);
+                b[j] = *(const half8 *)(sB + row * 64 + ((c ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue ----------
+    const int colb = n0 + wn * WN + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= g.M) continue;
+            if (EPI == EPI_GLU) {
+                // W rows interleaved in 32-channel groups: [a(32) | gate(32)] per 64 columns
+                float av = acc[i][0][r] + g.bias[colb];
+                float gv = acc[i][NF - 1][r] + g.bias[colb + 32];
+                int oc = ((n0 + wn * WN) >> 1) + (lane & 31);
+                ((half_t *)g.out)[(size_t)row * g.ldo + oc] = (half_t)(av * sigmoidf_(gv));
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                int col = colb + j * 32;
+                float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
+                if (EPI == EPI_F16) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)v;
+                else if (EPI == EPI_F16_SWISH) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)(v * sigmoidf_(v));
+                else if (EPI == EPI_F16_RELU) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)(v > 0.f ? v : 0.f);
+                else if (EPI == EPI_RESID) {
+                    float *o = (float *)g.out + (size_t)row * g.ldo + col;
+                    *o = *o + g.alpha * v;
+                } else if (EPI == EPI_F32) ((float *)g.out)[(size_t)row * g.ldo + col] = g.alpha * v;
+                else if (EPI == EPI_QKV) {
+                    if (col < 2 * QV_D) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)v;
+                    else {
+                        int hd = col - 2 * QV_D;  // h*64 + d
+                        int b = row / g.t_max, t = row - b * g.t_max;
+                        ((half_t *)g.out2)[((size_t)b * QV_D + hd) * g.t_pad + t] = (half_t)v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int BN>
+static void launch_one(const GemmArgs &g, hipStream_t s) {
+    dim3 grid(g.N / BN, (g.M + 127) / 128);
+    size_t lds = 2 * (128 * 64 * 2) + 2 * (BN * 64 * 2);
+    hipLaunchKernelGGL((k_gemm<EPI, BN>), grid, dim3(256), lds, s, g);
+}
+
+void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
+    if (g.K % 64 != 0 || g.N % 64 != 0) {
+        fprintf(stderr, "launch_gemm: unsupported shape N=%d K=%d\n", g.N, g.K);
+        abort();
+    }
+    // narrow-N GEMMs on few row panels get 64-wide tiles so the grid still covers the chip
+    bool narrow = (g.N % 128 != 0) || ((g.N / 128) * ((g.M + 127) / 128) < 512 && epi != EPI_GLU);
+    switch (epi) {
+#define CASE(E)                                                   \
+    case E:                                                       \
+        if (narrow) launch_one<E, 64>(g, s);                      \
+        else launch_one<E, 128>(g, s);                            \
+        break;
+        CASE(EPI_F16)
+        CASE(EPI_F16_SWISH)
+        CASE(EPI_F16_RELU)
+        CASE(EPI_RESID)
+        CASE(EPI_F32)
+        CASE(EPI_QKV)
+#undef CASE
+        case EPI_GLU: launch_one<EPI_GLU, 128>(g, s); break;
+        default: abort();
+    }
+}

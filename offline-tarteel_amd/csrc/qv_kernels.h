@@ -1,0 +1,55 @@
+// qv_kernels.h -- device kernels of the acoustic model (FastConformer-CTC forward), gfx950.
+//
+// Layout conventions (row = one encoder frame of one utterance, M = B * t_max rows):
+//   residual stream   f32 [M][512]
+//   GEMM operands     f16, A [M][K] row-major, W [N][K] row-major ("NT": both K-contiguous, the
+//                     natural MFMA fragment order: a lane reads 8 consecutive k of one row)
+//   accumulation      f32 in MFMA accumulators; bias / activation / residual fused in the epilogue
+//
+// GEMM: 128 x BN x 64 tiles, 256 threads (4 waves as 2 x 2), v_mfma_f32_32x32x16_f16, operands
+// staged with direct global->LDS loads (16 B per lane).  LDS rows are 128 B; the 16-B chunk index
+// is XOR-swizzled with (row & 7) ON THE GLOBAL SOURCE ADDRESS (the LDS write of a direct load is
+// lane-linear) and on the fragment read, which makes the ds_read_b128 fragment reads conflict-free.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define QV_D 512
+#define QV_H 8
+#define QV_DK 64
+#define QV_FF 2048
+#define QV_NMEL 80
+#define QV_SUBC 256
+
+enum {
+    EPI_F16 = 0,        // out f16 = acc + bias
+    EPI_F16_SWISH = 1,  // out f16 = swish(acc + bias)
+    EPI_F16_RELU = 2,   // out f16 = relu(acc + bias)
+    EPI_GLU = 3,        // out f16 [M][N/2]: (acc_a + b_a) * sigmoid(acc_g + b_g), W rows pre-interleaved
+    EPI_RESID = 4,      // out f32 [M][N] = out + alpha * (acc + bias)   (in place on the residual stream)
+    EPI_F32 = 5,        // out f32 = alpha * (acc + bias)
+    EPI_QKV = 6         // N = 1536: q,k -> f16 [M][1024] (+bias), v -> transposed f16 Vt[b][h][64][t_pad]
+};
+
+struct GemmArgs {
+    const half_t *A;      // [M][lda]
+    const half_t *W;      // [N][ldw]
+    const float *bias;    // [N] or nullptr
+    void *out;
+    void *out2;           // EPI_QKV: Vt
+    int M, N, K, lda, ldw, ldo;
+    float alpha;
+    int t_max, t_pad;     // EPI_QKV
+};
+
+template <int EPI, int BN>
+__global__ void k_gemm(GemmArgs g);
+
+void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);

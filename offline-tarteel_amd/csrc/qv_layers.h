@@ -1,0 +1,29 @@
+// qv_layers.h -- launchers of the non-GEMM kernels (qv_layers.hip).
+#pragma once
+
+#include "qv_kernels.h"
+
+struct FrontendTab {
+    const float *window;    // [512] symmetric Hann(400) zero-padded to n_fft, centred
+    const float2 *twiddle;  // [256] exp(-2 pi i m / 512)
+    const int32_t *mel_lo;  // [80] first FFT bin of each filter
+    const int32_t *mel_cnt; // [80] number of bins (<= 32)
+    const float *mel_w;     // [80][32]
+};
+
+void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
+                   int tm_max, int batch, hipStream_t s);
+void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const float *w, const float *bias, half_t *out,
+                  int t1_max, int batch, hipStream_t s);
+void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,
+                     half_t *out, int tout_max, int fout, int batch, hipStream_t s);
+void launch_mask_rows(half_t *x, int t_max, int row_elems, const int32_t *len, int batch, hipStream_t s);
+void launch_layernorm(const float *x, const float *g, const float *b, half_t *y, int M, hipStream_t s);
+void launch_layernorm2(float *x, const float *g1, const float *b1, const float *g2, const float *b2, half_t *y, int M,
+                       hipStream_t s);
+void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s);
+void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
+                      const int32_t *len, half_t *out, int t_max, int t_pad, int batch, hipStream_t s);
+void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, half_t *y, int t_max, int batch,
+                     hipStream_t s);
+void launch_logsoftmax(const float *logits, int ld, float *out, int M, hipStream_t s);

@@ -1,0 +1,483 @@
+// qv_layers.hip -- non-GEMM kernels of the FastConformer forward: log-mel front-end, strided
+// conv subsampling, LayerNorm, rel-pos attention, depthwise conv, log-softmax.
+//
+// All of them are HBM/LDS-bound elementwise or small-reduction kernels except the attention,
+// which runs QK^T, the rel-pos term and PV on v_mfma_f32_32x32x16_f16 with operands read
+// straight from HBM/L2 in fragment order (K-contiguous 16-B loads; V is produced already
+// transposed by the QKV GEMM epilogue so that PV's B operand is K-contiguous too).
+
+#include "qv_layers.h"
+
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------ front-end ----------
+// One wave per STFT frame: pre-emphasis + reflect padding + Hann window on load, 512-point
+// radix-2 Stockham FFT in LDS (9 passes, 4 butterflies per lane per pass), power spectrum,
+// sparse mel projection (each filter touches <= 32 bins), log(x + 2^-24).
+__global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio, int64_t n_max,
+                                                const int32_t *__restrict__ n_samples, const FrontendTab ft,
+                                                float *__restrict__ feats, int tm_max) {
+    __shared__ float2 buf[4][2][512];
+    __shared__ float pw[4][264];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, t = blockIdx.x * 4 + wave;
+    const int n = n_samples[b];
+    const int tm = n / 160 + 1;
+    if (t >= tm) return;  // frames past the utterance are zeroed by the normalisation kernel
+    const float *x = audio + (size_t)b * n_max;
+    float2 *A = buf[wave][0], *Bf = buf[wave][1];
+    for (int i = lane; i < 512; i += 64) {
+        int s = t * 160 - 256 + i;
+        if (s < 0) s = -s;
+        if (s >= n) s = 2 * (n - 1) - s;
+        s = s < 0 ? 0 : s;
+        float y = x[s] - (s > 0 ? 0.97f * x[s - 1] : 0.f);
+        A[i] = make_float2(y * ft.window[i], 0.f);
+    }
+    // Stockham autosort, radix 2: pass p (len = 1 << p): out[j*2*len + k] , out[... + len]
+    float2 *src = A, *dst = Bf;
+    for (int p = 0; p < 9; ++p) {
+        int len = 1 << p;  // half-size of the butterflies produced so far
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 256; i += 64) {
+            int k = i & (len - 1), j = i >> p;  // j: group, k: index within group
+            float2 u = src[j * len + k], v = src[j * len + k + 256];
+            // twiddle w = exp(-2 pi i * k / (2 len))
+            float2 w = ft.twiddle[k * (256 >> p)];
+            float2 vw = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            dst[j * 2 * len + k] = make_float2(u.x + vw.x, u.y + vw.y);
+            dst[j * 2 * len + k + len] = make_float2(u.x - vw.x, u.y - vw.y);
+        }
+        float2 *tmp = src; src = dst; dst = tmp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < 257; k += 64) {
+        float2 z = src[k];
+        float mag = sqrtf(z.x * z.x + z.y * z.y);
+        pw[wave][k] = mag * mag;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *out = feats + ((size_t)b * tm_max + t) * QV_NMEL;
+    for (int m = lane; m < QV_NMEL; m += 64) {
+        int lo = ft.mel_lo[m], cnt = ft.mel_cnt[m];
+        const float *w = ft.mel_w + m * 32;
+        float acc = 0.f;
+        for (int k = 0; k < cnt; ++k) acc += w[k] * pw[wave][lo + k];
+        out[m] = logf(acc + 5.9604644775390625e-08f);
+    }
+}
+
+// per-feature mean / unbiased std over the valid frames, normalise in place, zero the padding.
+__global__ __launch_bounds__(320) void k_melnorm(float *__restrict__ feats, const int32_t *__restrict__ n_samples,
+                                                 int tm_max) {
+    __shared__ float part[4][QV_NMEL], mean_s[QV_NMEL], rstd_s[QV_NMEL];
+    const int b = blockIdx.x, f = threadIdx.x % QV_NMEL, g = threadIdx.x / QV_NMEL;  // 4 time groups
+    const int tm = n_samples[b] / 160 + 1;
+    float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    float s = 0.f;
+    for (int t = g; t < tm; t += 4) s += x[t * QV_NMEL + f];
+    part[g][f] = s;
+    __syncthreads();
+    if (g == 0) mean_s[f] = (part[0][f] + part[1][f] + part[2][f] + part[3][f]) / (float)tm;
+    __syncthreads();
+    float mu = mean_s[f];
+    s = 0.f;
+    for (int t = g; t < tm; t += 4) { float d = x[t * QV_NMEL + f] - mu; s += d * d; }
+    part[g][f] = s;
+    __syncthreads();
+    if (g == 0) rstd_s[f] = 1.f / (sqrtf((part[0][f] + part[1][f] + part[2][f] + part[3][f]) / (float)(tm - 1)) + 1e-5f);
+    __syncthreads();
+    float rs = rstd_s[f];
+    for (int t = g; t < tm_max; t += 4) {
+        float v = x[t * QV_NMEL + f];
+        x[t * QV_NMEL + f] = t < tm ? (v - mu) * rs : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ subsampling --------
+// conv0: Conv2d(1->256, 3x3, s2, p1) + ReLU on [B][Tm][80] -> channels-last f16 [B][T1][40][256].
+// One thread = one (t1, f1) position x 8 channels.
+__global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_in,
+                                               const float *__restrict__ w, const float *__restrict__ bias,
+                                               half_t *__restrict__ out, int t1_max) {
+    const int b = blockIdx.z, t1 = blockIdx.y, tid = threadIdx.x;
+    const int tin = len_in[b];
+    const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    for (int idx = tid; idx < 40 * 32; idx += 256) {
+        int f1 = idx >> 5, c0 = (idx & 31) * 8;
+        float in[9];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                int t = 2 * t1 - 1 + dt, f = 2 * f1 - 1 + df;
+                in[dt * 3 + df] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? x[t * QV_NMEL + f] : 0.f;
+            }
+        half8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float acc = bias[c0 + c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc += w[(c0 + c) * 9 + k] * in[k];
+            o[c] = (half_t)(acc > 0.f ? acc : 0.f);
+        }
+        *(half8 *)(out + (((size_t)b * t1_max + t1) * 40 + f1) * QV_SUBC + c0) = o;
+    }
+}
+
+// depthwise Conv2d(256, 3x3, s2, p1, groups=256) on channels-last f16; rows t >= len_in[b] read as 0.
+__global__ __launch_bounds__(256) void k_dwconv2d(const half_t *__restrict__ in, int tin_max, int fin,
+                                                  const int32_t *__restrict__ len_in, const float *__restrict__ w,
+                                                  const float *__restrict__ bias, half_t *__restrict__ out, int tout_max,
+                                                  int fout) {
+    const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
+    const int tin = len_in[b];
+    for (int idx = tid; idx < fout * 32; idx += 256) {
+        int fo = idx >> 5, c0 = (idx & 31) * 8;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = bias[c0 + c];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                int t = 2 * to - 1 + dt, f = 2 * fo - 1 + df;
+                if (t < 0 || t >= tin || f < 0 || f >= fin) continue;
+                half8 v = *(const half8 *)(in + (((size_t)b * tin_max + t) * fin + f) * QV_SUBC + c0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += w[(c0 + c) * 9 + dt * 3 + df] * (float)v[c];
+            }
+        half8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
+        *(half8 *)(out + (((size_t)b * tout_max + to) * fout + fo) * QV_SUBC + c0) = o;
+    }
+}
+
+// zero rows t >= len[b] of a channels-last f16 activation (so the next strided stage and the
+// out-projection see exactly what the unpadded single-utterance run sees)
+__global__ void k_mask_rows(half_t *__restrict__ x, int t_max, int row_elems, const int32_t *__restrict__ len) {
+    const int b = blockIdx.z, t = blockIdx.y;
+    if (t < len[b]) return;
+    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    half_t *p = x + ((size_t)b * t_max + t) * row_elems;
+    for (int i = threadIdx.x * 8; i < row_elems; i += blockDim.x * 8) *(half8 *)(p + i) = z;
+}
+
+// ------------------------------------------------------------------ LayerNorm ----------
+// one wave per row of 512: f32 in -> f16 out (GEMM operand).  Two-pass variance in registers.
+__device__ __forceinline__ void ln_row(const float v[8], const float *__restrict__ gam, const float *__restrict__ bet, int lane,
+                                       float o[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    float mu = wave_sum(s) * (1.f / QV_D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { float d = v[i] - mu; q += d * d; }
+    float rs = rsqrtf(wave_sum(q) * (1.f / QV_D) + 1e-5f);
+    f32x4 g0 = *(const f32x4 *)(gam + lane * 8), g1 = *(const f32x4 *)(gam + lane * 8 + 4);
+    f32x4 b0 = *(const f32x4 *)(bet + lane * 8), b1 = *(const f32x4 *)(bet + lane * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * g0[i] + b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * g1[i] + b1[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ gam,
+                                                   const float *__restrict__ bet, half_t *__restrict__ y, int M) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *p = x + (size_t)row * QV_D + lane * 8;
+    f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}, o[8];
+    ln_row(v, gam, bet, lane, o);
+    half8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (half_t)o[i];
+    *(half8 *)(y + (size_t)row * QV_D + lane * 8) = h;
+}
+
+// x <- LN_out(x) (f32, in place: the next layer's residual stream), y <- LN_next(x) (f16)
+__global__ __launch_bounds__(256) void k_layernorm2(float *__restrict__ x, const float *__restrict__ g1, const float *__restrict__ b1,
+                                                    const float *__restrict__ g2, const float *__restrict__ b2,
+                                                    half_t *__restrict__ y, int M) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float *p = x + (size_t)row * QV_D + lane * 8;
+    f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}, o[8], o2[8];
+    ln_row(v, g1, b1, lane, o);
+    *(f32x4 *)p = f32x4{o[0], o[1], o[2], o[3]};
+    *(f32x4 *)(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    if (y) {
+        ln_row(o, g2, b2, lane, o2);
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (half_t)o2[i];
+        *(half8 *)(y + (size_t)row * QV_D + lane * 8) = h;
+    }
+}
+
+// f32 -> f16 copy of the final encoder output (CTC head operand)
+__global__ void k_to_half(const float *__restrict__ x, half_t *__restrict__ y, size_t n8) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    f32x4 a = *(const f32x4 *)(x + i * 8), c = *(const f32x4 *)(x + i * 8 + 4);
+    half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)c[0], (half_t)c[1], (half_t)c[2], (half_t)c[3]};
+    *(half8 *)(y + i * 8) = h;
+}
+
+// ------------------------------------------------------------------ attention ----------
+// RelPositionMultiHeadAttention core for one (utterance, head): flash-style online softmax over
+// 32-key tiles, one wave per 32-query tile.
+//   AC[i,j]  = (q_i + u) . k_j
+//   BD[i,j]  = (q_i + v) . p_{T-1-i+j}          (rel_shift of the [T, 2T-1] product)
+//   out      = softmax((AC + BD) / 8, keys < len) V
+// The BD tile is produced as two 32-wide MFMA tiles over the 63 relative positions the tile
+// touches and skewed into place with ds_bpermute (row ii of the accumulator lives in a fixed
+// register, so the skew is a per-register lane rotation).
+__global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
+                                                   const half_t *__restrict__ pos, int pos_ld, const float *__restrict__ bias_u,
+                                                   const float *__restrict__ bias_v, const int32_t *__restrict__ len,
+                                                   half_t *__restrict__ out, int t_max, int t_pad) {
+    __shared__ __attribute__((aligned(16))) half_t pbuf[4][32 * 40];  // P tile relayout, row stride 40 halves
+    const int b = blockIdx.y, h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int T = len[b];
+    const int l31 = lane & 31, hi = lane >> 5;
+    const half_t *qb = qk + (size_t)b * t_max * (2 * QV_D) + h * QV_DK;            // q row stride 1024
+    const half_t *kb = qb + QV_D;
+    const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;                  // [64][t_pad]
+    const half_t *pb = pos + h * QV_DK;                                             // [2*t_max-1][pos_ld]
+    const int n_qt = (T + 31) >> 5, n_kt = (T + 31) >> 5;
+    for (int qt = wave; qt < (t_max + 31) / 32; qt += 4) {
+        const int i0 = qt * 32;
+        half_t *orow = out + ((size_t)b * t_max + i0) * QV_D + h * QV_DK;
+        if (qt >= n_qt) {
+            // padded query rows: defined output (zeros)
+            for (int r = 0; r < 32 && i0 + r < t_max; ++r)
+                if (lane < 8) *(half8 *)(orow + (size_t)r * QV_D + lane * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            continue;
+        }
+        // A fragments of (q+u) and (q+v): row = i0 + l31 (clamped), d = ks*16 + hi*8 .. +7
+        half8 au[4], av[4];
+        {
+            int qi = i0 + l31;
+            qi = qi < t_max ? qi : t_max - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int d = ks * 16 + hi * 8;
+                half8 qv8 = *(const half8 *)(qb + (size_t)qi * (2 * QV_D) + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float qf = (float)qv8[e];
+                    au[ks][e] = (half_t)(qf + bias_u[h * QV_DK + d + e]);
+                    av[ks][e] = (half_t)(qf + bias_v[h * QV_DK + d + e]);
+                }
+            }
+        }
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        float mrow[16], lrow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const int j0 = kt * 32;
+            f32x16 s, r0acc, r1acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; r0acc[r] = 0.f; r1acc[r] = 0.f; }
+            int kj = j0 + l31;
+            kj = kj < t_max ? kj : t_max - 1;
+            // relative-position rows for this tile: rr0 + c, c in [0,64)
+            const int rr0 = t_max - 1 - i0 - 31 + j0;
+            int pr0 = rr0 + l31, pr1 = rr0 + 32 + l31;
+            pr0 = pr0 < 0 ? 0 : (pr0 > 2 * t_max - 2 ? 2 * t_max - 2 : pr0);
+            pr1 = pr1 < 0 ? 0 : (pr1 > 2 * t_max - 2 ? 2 * t_max - 2 : pr1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int d = ks * 16 + hi * 8;
+                half8 kf = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
+                half8 p0 = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
+                half8 p1 = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(au[ks], kf, s, 0, 0, 0);
+                r0acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p0, r0acc, 0, 0, 0);
+                r1acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p1, r1acc, 0, 0, 0);
+            }
+            // skew: S[ii][jj] += raw[ii][31 - ii + jj]
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ii = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                int cc = 31 - ii + l31;               // 0..62
+                int srcl = (cc & 31) + 32 * hi;
+                float a0 = __shfl(r0acc[r], srcl), a1 = __shfl(r1acc[r], srcl);
+                float bd = cc < 32 ? a0 : a1;
+                float sc = (s[r] + bd) * 0.125f;
+                p[r] = (j0 + l31 < T) ? sc : -1e30f;
+            }
+            // online softmax: row ii lives in register r of the 32 lanes sharing `hi`
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float mx = p[r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float mnew = fmaxf(mrow[r], mx);
+                float corr = __expf(mrow[r] - mnew);
+                float e = (j0 + l31 < T) ? __expf(p[r] - mnew) : 0.f;
+                float sum = e;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                lrow[r] = lrow[r] * corr + sum;
+                mrow[r] = mnew;
+                o0[r] *= corr;
+                o1[r] *= corr;
+                p[r] = e;
+            }
+            // P (C layout) -> LDS [ii][jj] -> A fragments
+            half_t *pw_ = pbuf[wave];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ii = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                pw_[ii * 40 + l31] = (half_t)p[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 pa = *(const half8 *)(pw_ + l31 * 40 + ks * 16 + hi * 8);
+                int jj = j0 + ks * 16 + hi * 8;  // < t_pad (t_pad is a multiple of 32)
+                half8 v0 = *(const half8 *)(vb + (size_t)l31 * t_pad + jj);
+                half8 v1 = *(const half8 *)(vb + (size_t)(32 + l31) * t_pad + jj);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v0, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v1, o1, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int ii = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (i0 + ii >= t_max) continue;
+            float inv = (i0 + ii < T) ? 1.f / lrow[r] : 0.f;
+            orow[(size_t)ii * QV_D + l31] = (half_t)(o0[r] * inv);
+            orow[(size_t)ii * QV_D + 32 + l31] = (half_t)(o1[r] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ conv module --------
+// depthwise Conv1d(512, k=9, pad 4) + folded BatchNorm + Swish on f16 [M][512]; input frames
+// t >= len[b] read as zero (the reference zeroes padded frames after GLU).
+__global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, const float *__restrict__ w /*[512][9]*/,
+                                                  const float *__restrict__ bias, const int32_t *__restrict__ len,
+                                                  half_t *__restrict__ y, int t_max) {
+    const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= t_max) return;
+    const int T = len[b], c0 = lane * 8;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = bias[c0 + c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int tt = t + k - 4;
+        if (tt < 0 || tt >= T) continue;
+        half8 v = *(const half8 *)(x + ((size_t)b * t_max + tt) * QV_D + c0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += w[(c0 + c) * 9 + k] * (float)v[c];
+    }
+    half8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] * sigmoidf_(acc[c]));
+    *(half8 *)(y + ((size_t)b * t_max + t) * QV_D + c0) = o;
+}
+
+// ------------------------------------------------------------------ log-softmax --------
+// logits f32 [M][ld] (first 1025 valid) -> log-probs f32 [B][t_max][1025]; one wave per row.
+__global__ __launch_bounds__(256) void k_logsoftmax(const float *__restrict__ logits, int ld, float *__restrict__ out, int M) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *p = logits + (size_t)row * ld;
+    float v[17];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < 1025 ? p[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) s += (lane + 64 * i < 1025) ? expf(v[i] - mx) : 0.f;
+    float lse = mx + logf(wave_sum(s));
+    float *o = out + (size_t)row * 1025;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        int c = lane + 64 * i;
+        if (c < 1025) o[c] = v[i] - lse;
+    }
+}
+
+}  // namespace
+
+// ====================================================================== launchers ======
+
+void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
+                   int tm_max, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_logmel, dim3((tm_max + 3) / 4, batch), dim3(256), 0, s, audio, n_max, n_samples, ft, feats, tm_max);
+    hipLaunchKernelGGL(k_melnorm, dim3(batch), dim3(320), 0, s, feats, n_samples, tm_max);
+}
+
+void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const float *w, const float *bias, half_t *out,
+                  int t1_max, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv0, dim3(1, t1_max, batch), dim3(256), 0, s, feats, tm_max, len_in, w, bias, out, t1_max);
+}
+
+void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,
+                     half_t *out, int tout_max, int fout, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_dwconv2d, dim3(1, tout_max, batch), dim3(256), 0, s, in, tin_max, fin, len_in, w, bias, out,
+                       tout_max, fout);
+}
+
+void launch_mask_rows(half_t *x, int t_max, int row_elems, const int32_t *len, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_rows, dim3(1, t_max, batch), dim3(256), 0, s, x, t_max, row_elems, len);
+}
+
+void launch_layernorm(const float *x, const float *g, const float *b, half_t *y, int M, hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, M);
+}
+
+void launch_layernorm2(float *x, const float *g1, const float *b1, const float *g2, const float *b2, half_t *y, int M,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm2, dim3((M + 3) / 4), dim3(256), 0, s, x, g1, b1, g2, b2, y, M);
+}
+
+void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s) {
+    size_t n8 = n / 8;
+    hipLaunchKernelGGL(k_to_half, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, x, y, n8);
+}
+
+void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
+                      const int32_t *len, half_t *out, int t_max, int t_pad, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, out, t_max, t_pad);
+}
+
+void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, half_t *y, int t_max, int batch,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_dwconv1d, dim3((t_max + 3) / 4, batch), dim3(256), 0, s, x, w, bias, len, y, t_max);
+}
+
+void launch_logsoftmax(const float *logits, int ld, float *out, int M, hipStream_t s) {
+    hipLaunchKernelGGL(k_logsoftmax, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, out, M);
+}

@@ -1,6 +1,563 @@
-// placeholder, replaced by the acoustic model
+// qv_model.hip -- FastConformer-CTC acoustic model: weights, HBM layout, forward schedule.
+//
+// Replaces the reference's onnxruntime call (experiments/c2c-direct-mixed/run.py:55-63).  The
+// architecture is the public NeMo definition of stt_ar_fastconformer_hybrid_large_pcd's CTC
+// branch; tensor names follow the NeMo state dict so that a converted
+// checkpoint (tools/convert_weights.py) drops in.  Without a weight file the engine fills the
+// same tensors with a seeded integer-hash init that oracle/fastconformer_ref.py reproduces
+// bit-for-bit, so the HIP forward can be checked against the fp32 PyTorch restatement.
+//
+// HBM residency (per GPU, fp16 weights): ~218 MB weights + activations for the whole batch;
+// every activation buffer is allocated once at qv_create for (max_batch, max_samples).
+
 #include "qv_common.h"
-int qv_model_create(qv_engine *eng, const qv_config *, QvModel **) { qv_set_error(eng, "model not built"); return QV_ERR_NO_MODEL; }
-void qv_model_destroy(QvModel *) {}
-int qv_model_forward(qv_engine *eng, QvModel *, const float *, const int64_t *, int, int64_t, float *, int, int32_t *, hipStream_t) { return QV_ERR_NO_MODEL; }
-int qv_model_tap(qv_engine *eng, QvModel *, int, int, float *, hipStream_t) { return QV_ERR_NO_MODEL; }
+#include "qv_layers.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <fstream>
+#include <map>
+#include <unordered_map>
+
+#define N_LAYERS 17
+#define HEAD_N 1152  // 1025 padded to a multiple of 128
+
+namespace {
+
+// ------------------------------------------------------------------ weight source ------
+struct HostWeights {
+    std::unordered_map<std::string, std::vector<float>> t;
+    const std::vector<float> &get(const std::string &n) const {
+        auto it = t.find(n);
+        if (it == t.end()) { fprintf(stderr, "qverse: missing weight %s\n", n.c_str()); abort(); }
+        return it->second;
+    }
+};
+
+struct Shape { std::string name; std::vector<int> dims; };
+
+std::vector<Shape> weight_shapes() {
+    std::vector<Shape> s;
+    auto add = [&](const std::string &n, std::vector<int> d) { s.push_back({n, d}); };
+    const char *pe = "encoder.pre_encode.";
+    add(std::string(pe) + "conv.0.weight", {QV_SUBC, 1, 3, 3}); add(std::string(pe) + "conv.0.bias", {QV_SUBC});
+    add(std::string(pe) + "conv.2.weight", {QV_SUBC, 1, 3, 3}); add(std::string(pe) + "conv.2.bias", {QV_SUBC});
+    add(std::string(pe) + "conv.3.weight", {QV_SUBC, QV_SUBC, 1, 1}); add(std::string(pe) + "conv.3.bias", {QV_SUBC});
+    add(std::string(pe) + "conv.5.weight", {QV_SUBC, 1, 3, 3}); add(std::string(pe) + "conv.5.bias", {QV_SUBC});
+    add(std::string(pe) + "conv.6.weight", {QV_SUBC, QV_SUBC, 1, 1}); add(std::string(pe) + "conv.6.bias", {QV_SUBC});
+    add(std::string(pe) + "out.weight", {QV_D, QV_SUBC * 10}); add(std::string(pe) + "out.bias", {QV_D});
+    add("ctc_decoder.decoder_layers.0.weight", {QV_VOCAB, QV_D, 1}); add("ctc_decoder.decoder_layers.0.bias", {QV_VOCAB});
+    for (int i = 0; i < N_LAYERS; ++i) {
+        std::string p = "encoder.layers." + std::to_string(i) + ".";
+        for (const char *ln : {"norm_feed_forward1", "norm_self_att", "norm_conv", "norm_feed_forward2", "norm_out"}) {
+            add(p + ln + ".weight", {QV_D}); add(p + ln + ".bias", {QV_D});
+        }
+        for (const char *ff : {"feed_forward1", "feed_forward2"}) {
+            add(p + ff + ".linear1.weight", {QV_FF, QV_D}); add(p + ff + ".linear1.bias", {QV_FF});
+            add(p + ff + ".linear2.weight", {QV_D, QV_FF}); add(p + ff + ".linear2.bias", {QV_D});
+        }
+        for (const char *lin : {"linear_q", "linear_k", "linear_v", "linear_out"}) {
+            add(p + "self_attn." + lin + ".weight", {QV_D, QV_D}); add(p + "self_attn." + lin + ".bias", {QV_D});
+        }
+        add(p + "self_attn.linear_pos.weight", {QV_D, QV_D});
+        add(p + "self_attn.pos_bias_u", {QV_H, QV_DK}); add(p + "self_attn.pos_bias_v", {QV_H, QV_DK});
+        add(p + "conv.pointwise_conv1.weight", {2 * QV_D, QV_D, 1}); add(p + "conv.pointwise_conv1.bias", {2 * QV_D});
+        add(p + "conv.depthwise_conv.weight", {QV_D, 1, 9}); add(p + "conv.depthwise_conv.bias", {QV_D});
+        add(p + "conv.batch_norm.weight", {QV_D}); add(p + "conv.batch_norm.bias", {QV_D});
+        add(p + "conv.batch_norm.running_mean", {QV_D}); add(p + "conv.batch_norm.running_var", {QV_D});
+        add(p + "conv.pointwise_conv2.weight", {QV_D, QV_D, 1}); add(p + "conv.pointwise_conv2.bias", {QV_D});
+    }
+    return s;
+}
+
+bool ends_with(const std::string &s, const char *suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// seeded init: integer hash -> Irwin-Hall(4 bytes) -> affine; exact in f32 and mirrored by
+// oracle/fastconformer_ref.py::random_weights
+void init_random(HostWeights &hw, uint64_t seed) {
+    for (const Shape &sh : weight_shapes()) {
+        size_t n = 1;
+        for (int d : sh.dims) n *= (size_t)d;
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (unsigned char c : sh.name) h = (h ^ c) * 0x100000001B3ull;
+        uint64_t key = h ^ (seed * 0x9E3779B97F4A7C15ull);
+        float off = 0.f, sc = 0.f;
+        bool ab = false;
+        const std::string &nm = sh.name;
+        if (ends_with(nm, "running_var")) { off = 1.f; sc = 0.1f; ab = true; }
+        else if (ends_with(nm, "running_mean")) { off = 0.f; sc = 0.1f; }
+        else if (nm.find(".norm_") != std::string::npos || nm.find("batch_norm") != std::string::npos) {
+            if (ends_with(nm, "weight")) { off = 1.f; sc = 0.1f; } else { off = 0.f; sc = 0.1f; }
+        } else if (ends_with(nm, "bias") || nm.find("pos_bias") != std::string::npos) { off = 0.f; sc = 0.1f; }
+        else { size_t fan_in = n / (size_t)sh.dims[0]; sc = 1.0f / sqrtf((float)fan_in); }
+        std::vector<float> v(n);
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t x = (uint64_t)i + key + 0x9E3779B97F4A7C15ull;
+            uint64_t z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+            int s4 = (int)(z & 0xFF) + (int)((z >> 8) & 0xFF) + (int)((z >> 16) & 0xFF) + (int)((z >> 24) & 0xFF) - 510;
+            float zn = (float)s4 * (1.0f / 147.8f);
+            if (ab) zn = fabsf(zn);
+            float prod = sc * zn;
+            v[i] = off + prod;
+        }
+        hw.t[nm] = std::move(v);
+    }
+}
+
+// flat weight file: "QVWT0001", u32 count, then per tensor {u32 name_len, name, u32 numel, f32 data}
+int load_weight_file(qv_engine *eng, const char *path, HostWeights &hw) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { qv_set_error(eng, std::string("No weight file at ") + path); return QV_ERR_IO; }
+    char magic[8];
+    uint32_t cnt = 0;
+    f.read(magic, 8);
+    f.read((char *)&cnt, 4);
+    if (!f || memcmp(magic, "QVWT0001", 8)) { qv_set_error(eng, "weight file malformed (bad magic)"); return QV_ERR_IO; }
+    for (uint32_t i = 0; i < cnt; ++i) {
+        uint32_t nl = 0, ne = 0;
+        f.read((char *)&nl, 4);
+        if (!f || nl > 512) { qv_set_error(eng, "weight file malformed"); return QV_ERR_IO; }
+        std::string name(nl, '\0');
+        f.read(&name[0], nl);
+        f.read((char *)&ne, 4);
+        std::vector<float> v(ne);
+        f.read((char *)v.data(), (std::streamsize)ne * 4);
+        if (!f) { qv_set_error(eng, "weight file truncated"); return QV_ERR_IO; }
+        hw.t[name] = std::move(v);
+    }
+    for (const Shape &sh : weight_shapes()) {
+        size_t n = 1;
+        for (int d : sh.dims) n *= (size_t)d;
+        auto it = hw.t.find(sh.name);
+        if (it == hw.t.end() || it->second.size() != n) {
+            qv_set_error(eng, "weight file lacks tensor or wrong size: " + sh.name);
+            return QV_ERR_IO;
+        }
+    }
+    return QV_OK;
+}
+
+struct LayerW {
+    const float *ln_g[5], *ln_b[5];  // ff1, att, conv, ff2, out
+    const half_t *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *qkv_w, *out_w, *pw1_w, *pw2_w;
+    const float *ff1_b1, *ff1_b2, *ff2_b1, *ff2_b2, *qkv_b, *out_b, *pw1_b, *pw2_b;
+    const float *bias_u, *bias_v, *dw_w, *dw_b;
+};
+
+}  // namespace
+
+struct QvModel {
+    std::vector<void *> allocs;
+    FrontendTab ft;
+    const float *c0_w, *c0_b, *dw2_w, *dw2_b, *dw5_w, *dw5_b, *pw3_b, *pw6_b, *sub_out_b, *head_b;
+    const half_t *pw3_w, *pw6_w, *sub_out_w, *head_w, *pos_w;
+    LayerW L[N_LAYERS];
+    // capacities
+    int max_batch, tm_cap, t1_cap, t2_cap, t3_cap;
+    // activations
+    float *feats, *x, *logits;
+    half_t *c0, *c1, *c1p, *c2, *c2p, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
+    int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3
+    int32_t *lens_host;  // pinned
+    std::map<int, half_t *> pos_cache;  // t_max -> projected positions f16 [2*t_max-1][17*512]
+    bool save_taps;
+    float *tap_x;        // [N_LAYERS+1][M][512] when save_taps
+    int last_batch, last_tmax, last_tm_max;
+};
+
+namespace {
+
+template <typename T>
+int up(qv_engine *eng, QvModel *m, const std::vector<T> &h, const T **dev) {
+    void *p = nullptr;
+    QV_HIP(hipMalloc(&p, std::max<size_t>(h.size() * sizeof(T), 16)));
+    m->allocs.push_back(p);
+    QV_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T *)p;
+    return QV_OK;
+}
+
+template <typename T>
+int dal(qv_engine *eng, QvModel *m, size_t count, T **dev) {
+    void *p = nullptr;
+    QV_HIP(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+    QV_HIP(hipMemset(p, 0, std::max<size_t>(count * sizeof(T), 16)));
+    m->allocs.push_back(p);
+    *dev = (T *)p;
+    return QV_OK;
+}
+
+std::vector<half_t> to_half(const std::vector<float> &v) {
+    std::vector<half_t> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = (half_t)v[i];
+    return h;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int build_frontend(qv_engine *eng, QvModel *m) {
+    // symmetric Hann(400) centred in 512
+    std::vector<float> win(512, 0.f);
+    for (int i = 0; i < 400; ++i) win[56 + i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / 399.0));
+    std::vector<float2> tw(256);
+    for (int k = 0; k < 256; ++k) tw[k] = make_float2((float)cos(-2.0 * M_PI * k / 512.0), (float)sin(-2.0 * M_PI * k / 512.0));
+    // Slaney mel filterbank (librosa.filters.mel, htk=False, norm='slaney'), f64 then f32
+    auto hz_to_mel = [](double f) {
+        const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = 1000.0 / f_sp, logstep = log(6.4) / 27.0;
+        return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+    };
+    auto mel_to_hz = [](double mm) {
+        const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = 1000.0 / f_sp, logstep = log(6.4) / 27.0;
+        return mm >= min_log_mel ? min_log_hz * exp(logstep * (mm - min_log_mel)) : f_sp * mm;
+    };
+    double mlo = hz_to_mel(0.0), mhi = hz_to_mel(8000.0);
+    std::vector<double> mel_f(QV_NMEL + 2);
+    for (int i = 0; i < QV_NMEL + 2; ++i) mel_f[i] = mel_to_hz(mlo + (mhi - mlo) * i / (QV_NMEL + 1));
+    std::vector<int32_t> lo(QV_NMEL), cnt(QV_NMEL);
+    std::vector<float> w(QV_NMEL * 32, 0.f);
+    for (int i = 0; i < QV_NMEL; ++i) {
+        double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int first = -1, last = -1;
+        std::vector<float> row(257);
+        for (int k = 0; k < 257; ++k) {
+            double fk = 8000.0 * k / 256.0;
+            double lower = (fk - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            double upper = (mel_f[i + 2] - fk) / (mel_f[i + 2] - mel_f[i + 1]);
+            double v = std::max(0.0, std::min(lower, upper));
+            row[k] = (float)(v * enorm);
+            if (row[k] > 0.f) { if (first < 0) first = k; last = k; }
+        }
+        if (first < 0) { first = 0; last = 0; }
+        if (last - first + 1 > 32) { qv_set_error(eng, "mel filter wider than 32 bins"); return QV_ERR_ARG; }
+        lo[i] = first; cnt[i] = last - first + 1;
+        for (int k = first; k <= last; ++k) w[i * 32 + (k - first)] = row[k];
+    }
+    TRY(up(eng, m, win, &m->ft.window));
+    TRY(up(eng, m, tw, &m->ft.twiddle));
+    TRY(up(eng, m, lo, &m->ft.mel_lo));
+    TRY(up(eng, m, cnt, &m->ft.mel_cnt));
+    TRY(up(eng, m, w, &m->ft.mel_w));
+    return QV_OK;
+}
+
+int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
+    const std::string pe = "encoder.pre_encode.";
+    TRY(up(eng, m, hw.get(pe + "conv.0.weight"), &m->c0_w));
+    TRY(up(eng, m, hw.get(pe + "conv.0.bias"), &m->c0_b));
+    TRY(up(eng, m, hw.get(pe + "conv.2.weight"), &m->dw2_w));
+    TRY(up(eng, m, hw.get(pe + "conv.2.bias"), &m->dw2_b));
+    TRY(up(eng, m, to_half(hw.get(pe + "conv.3.weight")), &m->pw3_w));
+    TRY(up(eng, m, hw.get(pe + "conv.3.bias"), &m->pw3_b));
+    TRY(up(eng, m, hw.get(pe + "conv.5.weight"), &m->dw5_w));
+    TRY(up(eng, m, hw.get(pe + "conv.5.bias"), &m->dw5_b));
+    TRY(up(eng, m, to_half(hw.get(pe + "conv.6.weight")), &m->pw6_w));
+    TRY(up(eng, m, hw.get(pe + "conv.6.bias"), &m->pw6_b));
+    {
+        // Linear(2560 -> 512): NeMo flattens [C=256][F=10] as c*10+f; activations here are
+        // channels-last [F][C], so permute K to f*256+c
+        const std::vector<float> &w = hw.get(pe + "out.weight");
+        std::vector<half_t> p((size_t)QV_D * 2560);
+        for (int n = 0; n < QV_D; ++n)
+            for (int c = 0; c < QV_SUBC; ++c)
+                for (int f = 0; f < 10; ++f) p[(size_t)n * 2560 + f * QV_SUBC + c] = (half_t)w[(size_t)n * 2560 + c * 10 + f];
+        TRY(up(eng, m, p, &m->sub_out_w));
+        TRY(up(eng, m, hw.get(pe + "out.bias"), &m->sub_out_b));
+    }
+    {
+        const std::vector<float> &w = hw.get("ctc_decoder.decoder_layers.0.weight");
+        const std::vector<float> &b = hw.get("ctc_decoder.decoder_layers.0.bias");
+        std::vector<half_t> p((size_t)HEAD_N * QV_D, (half_t)0.f);
+        std::vector<float> pb(HEAD_N, 0.f);
+        for (size_t i = 0; i < (size_t)QV_VOCAB * QV_D; ++i) p[i] = (half_t)w[i];
+        for (int i = 0; i < QV_VOCAB; ++i) pb[i] = b[i];
+        TRY(up(eng, m, p, &m->head_w));
+        TRY(up(eng, m, pb, &m->head_b));
+    }
+    std::vector<half_t> posw((size_t)N_LAYERS * QV_D * QV_D);
+    for (int i = 0; i < N_LAYERS; ++i) {
+        std::string p = "encoder.layers." + std::to_string(i) + ".";
+        LayerW &L = m->L[i];
+        const char *lns[5] = {"norm_feed_forward1", "norm_self_att", "norm_conv", "norm_feed_forward2", "norm_out"};
+        for (int k = 0; k < 5; ++k) {
+            TRY(up(eng, m, hw.get(p + lns[k] + ".weight"), &L.ln_g[k]));
+            TRY(up(eng, m, hw.get(p + lns[k] + ".bias"), &L.ln_b[k]));
+        }
+        TRY(up(eng, m, to_half(hw.get(p + "feed_forward1.linear1.weight")), &L.ff1_w1));
+        TRY(up(eng, m, hw.get(p + "feed_forward1.linear1.bias"), &L.ff1_b1));
+        TRY(up(eng, m, to_half(hw.get(p + "feed_forward1.linear2.weight")), &L.ff1_w2));
+        TRY(up(eng, m, hw.get(p + "feed_forward1.linear2.bias"), &L.ff1_b2));
+        TRY(up(eng, m, to_half(hw.get(p + "feed_forward2.linear1.weight")), &L.ff2_w1));
+        TRY(up(eng, m, hw.get(p + "feed_forward2.linear1.bias"), &L.ff2_b1));
+        TRY(up(eng, m, to_half(hw.get(p + "feed_forward2.linear2.weight")), &L.ff2_w2));
+        TRY(up(eng, m, hw.get(p + "feed_forward2.linear2.bias"), &L.ff2_b2));
+        {
+            std::vector<float> w, b;
+            for (const char *lin : {"linear_q", "linear_k", "linear_v"}) {
+                const auto &ww = hw.get(p + "self_attn." + lin + ".weight");
+                const auto &bb = hw.get(p + "self_attn." + lin + ".bias");
+                w.insert(w.end(), ww.begin(), ww.end());
+                b.insert(b.end(), bb.begin(), bb.end());
+            }
+            TRY(up(eng, m, to_half(w), &L.qkv_w));
+            TRY(up(eng, m, b, &L.qkv_b));
+        }
+        TRY(up(eng, m, to_half(hw.get(p + "self_attn.linear_out.weight")), &L.out_w));
+        TRY(up(eng, m, hw.get(p + "self_attn.linear_out.bias"), &L.out_b));
+        TRY(up(eng, m, hw.get(p + "self_attn.pos_bias_u"), &L.bias_u));
+        TRY(up(eng, m, hw.get(p + "self_attn.pos_bias_v"), &L.bias_v));
+        {
+            const auto &pw = hw.get(p + "self_attn.linear_pos.weight");
+            for (size_t k = 0; k < pw.size(); ++k) posw[(size_t)i * QV_D * QV_D + k] = (half_t)pw[k];
+        }
+        {
+            // GLU pairing: 64-column groups = [32 value channels | their 32 gate channels]
+            const auto &w = hw.get(p + "conv.pointwise_conv1.weight");
+            const auto &b = hw.get(p + "conv.pointwise_conv1.bias");
+            std::vector<half_t> pwm((size_t)2 * QV_D * QV_D);
+            std::vector<float> pb(2 * QV_D);
+            for (int g = 0; g < QV_D / 32; ++g)
+                for (int j = 0; j < 32; ++j) {
+                    int ra = g * 32 + j, rg = QV_D + g * 32 + j;
+                    int da = g * 64 + j, dg = g * 64 + 32 + j;
+                    for (int k = 0; k < QV_D; ++k) {
+                        pwm[(size_t)da * QV_D + k] = (half_t)w[(size_t)ra * QV_D + k];
+                        pwm[(size_t)dg * QV_D + k] = (half_t)w[(size_t)rg * QV_D + k];
+                    }
+                    pb[da] = b[ra];
+                    pb[dg] = b[rg];
+                }
+            TRY(up(eng, m, pwm, &L.pw1_w));
+            TRY(up(eng, m, pb, &L.pw1_b));
+        }
+        {
+            // fold eval-mode BatchNorm into the depthwise conv
+            const auto &w = hw.get(p + "conv.depthwise_conv.weight");
+            const auto &b = hw.get(p + "conv.depthwise_conv.bias");
+            const auto &g = hw.get(p + "conv.batch_norm.weight");
+            const auto &be = hw.get(p + "conv.batch_norm.bias");
+            const auto &mu = hw.get(p + "conv.batch_norm.running_mean");
+            const auto &var = hw.get(p + "conv.batch_norm.running_var");
+            std::vector<float> fw((size_t)QV_D * 9), fb(QV_D);
+            for (int c = 0; c < QV_D; ++c) {
+                float s = g[c] / sqrtf(var[c] + 1e-5f);
+                for (int k = 0; k < 9; ++k) fw[(size_t)c * 9 + k] = w[(size_t)c * 9 + k] * s;
+                fb[c] = (b[c] - mu[c]) * s + be[c];
+            }
+            TRY(up(eng, m, fw, &L.dw_w));
+            TRY(up(eng, m, fb, &L.dw_b));
+        }
+        TRY(up(eng, m, to_half(hw.get(p + "conv.pointwise_conv2.weight")), &L.pw2_w));
+        TRY(up(eng, m, hw.get(p + "conv.pointwise_conv2.bias"), &L.pw2_b));
+    }
+    TRY(up(eng, m, posw, &m->pos_w));
+    return QV_OK;
+}
+
+int stage_len(int t) { return (t + 2 - 3) / 2 + 1; }
+
+// projected relative positions for every layer, cached per t_max (weights are fixed)
+int get_pos(qv_engine *eng, QvModel *m, int t_max, hipStream_t stream, const half_t **out) {
+    auto it = m->pos_cache.find(t_max);
+    if (it != m->pos_cache.end()) { *out = it->second; return QV_OK; }
+    int R = 2 * t_max - 1;
+    std::vector<half_t> pe((size_t)R * QV_D);
+    for (int r = 0; r < R; ++r) {
+        float pos = (float)(t_max - 1 - r);
+        for (int i = 0; i < QV_D / 2; ++i) {
+            float div = expf((float)(2 * i) * -(logf(10000.0f) / (float)QV_D));
+            pe[(size_t)r * QV_D + 2 * i] = (half_t)sinf(pos * div);
+            pe[(size_t)r * QV_D + 2 * i + 1] = (half_t)cosf(pos * div);
+        }
+    }
+    half_t *d_pe = nullptr, *d_out = nullptr;
+    QV_HIP(hipMalloc((void **)&d_pe, pe.size() * sizeof(half_t)));
+    QV_HIP(hipMalloc((void **)&d_out, (size_t)R * N_LAYERS * QV_D * sizeof(half_t)));
+    QV_HIP(hipMemcpyAsync(d_pe, pe.data(), pe.size() * sizeof(half_t), hipMemcpyHostToDevice, stream));
+    GemmArgs g = {};
+    g.A = d_pe; g.W = m->pos_w; g.bias = nullptr; g.out = d_out;
+    g.M = R; g.N = N_LAYERS * QV_D; g.K = QV_D; g.lda = QV_D; g.ldw = QV_D; g.ldo = N_LAYERS * QV_D; g.alpha = 1.f;
+    launch_gemm(EPI_F16, g, stream);
+    QV_HIP(hipStreamSynchronize(stream));
+    QV_HIP(hipFree(d_pe));
+    m->allocs.push_back(d_out);
+    m->pos_cache[t_max] = d_out;
+    *out = d_out;
+    return QV_OK;
+}
+
+}  // namespace
+
+int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
+    if (cfg->precision != QV_PREC_FP16) {
+        qv_set_error(eng, "only QV_PREC_FP16 weights are implemented (int4/int8 weight path: next round)");
+        return QV_ERR_ARG;
+    }
+    QvModel *m = new QvModel();
+    *out = m;  // owned by the engine from here on (qv_destroy frees it on failure too)
+    HostWeights hw;
+    if (cfg->weights_path && cfg->weights_path[0]) TRY(load_weight_file(eng, cfg->weights_path, hw));
+    else init_random(hw, cfg->random_weights_seed);
+    TRY(build_frontend(eng, m));
+    TRY(prepare_weights(eng, m, hw));
+    int B = cfg->max_batch;
+    m->max_batch = B;
+    m->tm_cap = cfg->max_samples / 160 + 1;
+    m->t1_cap = stage_len(m->tm_cap);
+    m->t2_cap = stage_len(m->t1_cap);
+    m->t3_cap = stage_len(m->t2_cap);
+    size_t Bz = (size_t)B, M = Bz * m->t3_cap;
+    int t_pad_cap = (m->t3_cap + 31) / 32 * 32;
+    TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
+    TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
+    TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1));
+    TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1p));
+    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2));
+    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2p));
+    TRY(dal(eng, m, M * QV_D, &m->x));
+    TRY(dal(eng, m, M * QV_D, &m->ln));
+    TRY(dal(eng, m, M * QV_FF, &m->hbuf));
+    TRY(dal(eng, m, M * 2 * QV_D, &m->qk));
+    TRY(dal(eng, m, Bz * QV_D * t_pad_cap, &m->vt));
+    TRY(dal(eng, m, M * QV_D, &m->att));
+    TRY(dal(eng, m, M * QV_D, &m->glu));
+    TRY(dal(eng, m, M * QV_D, &m->dw));
+    TRY(dal(eng, m, M * QV_D, &m->xh));
+    TRY(dal(eng, m, M * HEAD_N, &m->logits));
+    TRY(dal(eng, m, Bz * 5, &m->lens_dev));
+    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * Bz * 5, hipHostMallocDefault));
+    const char *tp = getenv("QVERSE_DEBUG_TAPS");
+    m->save_taps = tp && tp[0] == '1';
+    m->tap_x = nullptr;
+    if (m->save_taps) TRY(dal(eng, m, (size_t)(N_LAYERS + 1) * M * QV_D, &m->tap_x));
+    m->last_batch = m->last_tmax = m->last_tm_max = 0;
+    return QV_OK;
+}
+
+void qv_model_destroy(QvModel *m) {
+    if (!m) return;
+    for (void *p : m->allocs) (void)hipFree(p);
+    if (m->lens_host) (void)hipHostFree(m->lens_host);
+    delete m;
+}
+
+int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64_t *len_host, int batch, int64_t n_max,
+                     float *logprobs, int t_max_out, int32_t *t_out_host, hipStream_t s) {
+    if (batch < 1 || batch > m->max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
+    int B = batch, MB = m->max_batch;
+    int tm_max = 0, t1m = 0, t2m = 0, t3m = 0;
+    int32_t *lh = m->lens_host;
+    for (int b = 0; b < B; ++b) {
+        int64_t n = len_host[b];
+        if (n < 400 || n > n_max || n / 160 + 1 > m->tm_cap) {
+            qv_set_error(eng, "utterance length out of range (need 400 <= n <= capacity)");
+            return QV_ERR_CAPACITY;
+        }
+        int tm = (int)(n / 160 + 1), l1 = stage_len(tm), l2 = stage_len(l1), l3 = stage_len(l2);
+        lh[0 * MB + b] = (int32_t)n; lh[1 * MB + b] = tm; lh[2 * MB + b] = l1; lh[3 * MB + b] = l2; lh[4 * MB + b] = l3;
+        tm_max = std::max(tm_max, tm); t1m = std::max(t1m, l1); t2m = std::max(t2m, l2); t3m = std::max(t3m, l3);
+        t_out_host[b] = l3;
+    }
+    if (t_max_out < t3m) { qv_set_error(eng, "t_max smaller than the longest utterance's frame count"); return QV_ERR_ARG; }
+    const int T = t3m;   // dense row stride of every [M][*] activation
+    const int M = B * T;
+    const int t_pad = (T + 31) / 32 * 32;
+    QV_HIP(hipMemcpyAsync(m->lens_dev, lh, sizeof(int32_t) * MB * 5, hipMemcpyHostToDevice, s));
+    const int32_t *d_n = m->lens_dev, *d_tm = d_n + MB, *d_l1 = d_n + 2 * MB, *d_l2 = d_n + 3 * MB, *d_l3 = d_n + 4 * MB;
+    const half_t *posp = nullptr;
+    TRY(get_pos(eng, m, T, s, &posp));
+
+    launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, B, s);
+    launch_conv0(m->feats, tm_max, d_tm, m->c0_w, m->c0_b, m->c0, t1m, B, s);
+    launch_dwconv2d(m->c0, t1m, 40, d_l1, m->dw2_w, m->dw2_b, m->c1, t2m, 20, B, s);
+    GemmArgs g = {};
+    g.alpha = 1.f;
+    g.A = m->c1; g.W = m->pw3_w; g.bias = m->pw3_b; g.out = m->c1p;
+    g.M = B * t2m * 20; g.N = QV_SUBC; g.K = QV_SUBC; g.lda = QV_SUBC; g.ldw = QV_SUBC; g.ldo = QV_SUBC;
+    launch_gemm(EPI_F16_RELU, g, s);
+    launch_dwconv2d(m->c1p, t2m, 20, d_l2, m->dw5_w, m->dw5_b, m->c2, t3m, 10, B, s);
+    g.A = m->c2; g.W = m->pw6_w; g.bias = m->pw6_b; g.out = m->c2p; g.M = B * t3m * 10;
+    launch_gemm(EPI_F16_RELU, g, s);
+    launch_mask_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, B, s);
+    // Linear(2560 -> 512) and xscaling (x * sqrt(d_model)) in one epilogue
+    g.A = m->c2p; g.W = m->sub_out_w; g.bias = m->sub_out_b; g.out = m->x;
+    g.M = M; g.N = QV_D; g.K = 2560; g.lda = 2560; g.ldw = 2560; g.ldo = QV_D; g.alpha = sqrtf((float)QV_D);
+    launch_gemm(EPI_F32, g, s);
+    if (m->save_taps) QV_HIP(hipMemcpyAsync(m->tap_x, m->x, sizeof(float) * (size_t)M * QV_D, hipMemcpyDeviceToDevice, s));
+
+    launch_layernorm(m->x, m->L[0].ln_g[0], m->L[0].ln_b[0], m->ln, M, s);
+    for (int l = 0; l < N_LAYERS; ++l) {
+        const LayerW &L = m->L[l];
+        auto gemm = [&](int epi, const half_t *A, int K, const half_t *W, const float *bias, void *out, int N, int ldo,
+                        float alpha) {
+            GemmArgs a = {};
+            a.A = A; a.W = W; a.bias = bias; a.out = out; a.out2 = m->vt;
+            a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
+            launch_gemm(epi, a, s);
+        };
+        // 1/2 FFN
+        gemm(EPI_F16_SWISH, m->ln, QV_D, L.ff1_w1, L.ff1_b1, m->hbuf, QV_FF, QV_FF, 1.f);
+        gemm(EPI_RESID, m->hbuf, QV_FF, L.ff1_w2, L.ff1_b2, m->x, QV_D, QV_D, 0.5f);
+        // rel-pos MHSA
+        launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
+        gemm(EPI_QKV, m->ln, QV_D, L.qkv_w, L.qkv_b, m->qk, 3 * QV_D, 2 * QV_D, 1.f);
+        launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, m->att, T, t_pad, B, s);
+        gemm(EPI_RESID, m->att, QV_D, L.out_w, L.out_b, m->x, QV_D, QV_D, 1.f);
+        // conv module
+        launch_layernorm(m->x, L.ln_g[2], L.ln_b[2], m->ln, M, s);
+        gemm(EPI_GLU, m->ln, QV_D, L.pw1_w, L.pw1_b, m->glu, 2 * QV_D, QV_D, 1.f);
+        launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, m->dw, T, B, s);
+        gemm(EPI_RESID, m->dw, QV_D, L.pw2_w, L.pw2_b, m->x, QV_D, QV_D, 1.f);
+        // 1/2 FFN
+        launch_layernorm(m->x, L.ln_g[3], L.ln_b[3], m->ln, M, s);
+        gemm(EPI_F16_SWISH, m->ln, QV_D, L.ff2_w1, L.ff2_b1, m->hbuf, QV_FF, QV_FF, 1.f);
+        gemm(EPI_RESID, m->hbuf, QV_FF, L.ff2_w2, L.ff2_b2, m->x, QV_D, QV_D, 0.5f);
+        // norm_out (+ next layer's first LayerNorm)
+        if (l + 1 < N_LAYERS)
+            launch_layernorm2(m->x, L.ln_g[4], L.ln_b[4], m->L[l + 1].ln_g[0], m->L[l + 1].ln_b[0], m->ln, M, s);
+        else
+            launch_layernorm2(m->x, L.ln_g[4], L.ln_b[4], nullptr, nullptr, nullptr, M, s);
+        if (m->save_taps)
+            QV_HIP(hipMemcpyAsync(m->tap_x + (size_t)(l + 1) * M * QV_D, m->x, sizeof(float) * (size_t)M * QV_D,
+                                  hipMemcpyDeviceToDevice, s));
+    }
+    launch_to_half(m->x, m->xh, (size_t)M * QV_D, s);
+    {
+        GemmArgs a = {};
+        a.A = m->xh; a.W = m->head_w; a.bias = m->head_b; a.out = m->logits;
+        a.M = M; a.N = HEAD_N; a.K = QV_D; a.lda = QV_D; a.ldw = QV_D; a.ldo = HEAD_N; a.alpha = 1.f;
+        launch_gemm(EPI_F32, a, s);
+    }
+    if (t_max_out == T) launch_logsoftmax(m->logits, HEAD_N, logprobs, M, s);
+    else {
+        // caller's row stride differs from the dense one: one launch per utterance
+        for (int b = 0; b < B; ++b)
+            launch_logsoftmax(m->logits + (size_t)b * T * HEAD_N, HEAD_N, logprobs + (size_t)b * t_max_out * QV_VOCAB, T, s);
+    }
+    QV_HIP(hipGetLastError());
+    m->last_batch = B; m->last_tmax = T; m->last_tm_max = tm_max;
+    return QV_OK;
+}
+
+int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hipStream_t s) {
+    size_t M = (size_t)m->last_batch * m->last_tmax;
+    if (what == 0) {
+        QV_HIP(hipMemcpyAsync(out, m->feats, sizeof(float) * (size_t)m->last_batch * m->last_tm_max * QV_NMEL,
+                              hipMemcpyDeviceToDevice, s));
+    } else {
+        if (!m->save_taps) { qv_set_error(eng, "set QVERSE_DEBUG_TAPS=1 before creating the engine"); return QV_ERR_ARG; }
+        int idx = what == 1 ? 0 : layer + 1;
+        if (idx < 0 || idx > N_LAYERS) return QV_ERR_ARG;
+        QV_HIP(hipMemcpyAsync(out, m->tap_x + (size_t)idx * M * QV_D, sizeof(float) * M * QV_D, hipMemcpyDeviceToDevice, s));
+    }
+    QV_HIP(hipStreamSynchronize(s));
+    return QV_OK;
+}

@@ -1,0 +1,333 @@
+"""fp32 PyTorch-CPU restatement of the acoustic model (row a1 of SURVEY.md section 8).
+
+TEST INFRASTRUCTURE ONLY (see oracle/oracle.py header).
+
+PARITY UNPINNED for this stage: the reference runs an external ONNX file
+(data/onnx_export/fastconformer_full_mixed.onnx, listed in .MISSING_LARGE_BLOBS:11) through
+onnxruntime 1.24.2 (uv.lock:2858); neither the file nor onnxruntime/NeMo exists in the build
+container, and none of the reference's tests hold vectors at this boundary.
+This module therefore restates the PUBLIC NeMo definition of
+nvidia/stt_ar_fastconformer_hybrid_large_pcd_v1.0's CTC branch (nemo-toolkit 2.7.0,
+uv.lock:2313; model id at experiments/c2c-direct/run.py:50; call order preprocessor ->
+encoder -> ctc_decoder at experiments/c2c-direct/run.py:179-181):
+
+  AudioToMelSpectrogramPreprocessor / FilterbankFeatures (eval): pre-emphasis 0.97, STFT
+    n_fft 512 / hop 160 / win 400 symmetric Hann, center + reflect pad, power spectrum,
+    80 Slaney-normalised Slaney-scale mel filters 0-8000 Hz, log(x + 2^-24), per-feature
+    mean / unbiased-std normalisation over valid frames (+1e-5), padded frames zeroed.
+    In-repo anchors: docs/plans/2026-03-01-onnx-browser-migration-plan.md:174,586-594.
+  ConformerEncoder (FastConformer-Large): dw_striding x8 subsampling (256 ch), xscaling,
+    17 x [1/2 FFN, rel-pos MHSA (8 x 64, untied pos_bias_u/v, rel_shift), conv module
+    (pointwise, GLU, depthwise k=9, BatchNorm, Swish, pointwise), 1/2 FFN, LayerNorm].
+  ConvASRDecoder: 1x1 Conv1d 512 -> 1025, log_softmax.  blank = 1024
+    (web/frontend/public/export_metadata.json:13-14), output already log-softmaxed (PLAN.md:96).
+
+The HIP forward is checked against THIS module on seeded random weights (self-consistency);
+real-weights parity needs the weight file supplied out of band (tools/convert_weights.py).
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SR = 16000
+N_FFT = 512
+HOP = 160
+WIN = 400
+N_MELS = 80
+D_MODEL = 512
+N_HEADS = 8
+D_K = 64
+N_LAYERS = 17
+FF = 2048
+CONV_K = 9
+SUB_CH = 256
+VOCAB = 1025
+PREEMPH = 0.97
+LOG_GUARD = 2.0 ** -24
+
+
+# ------------------------------------------------------------------- weights ---------
+def weight_shapes(n_layers: int = N_LAYERS) -> dict[str, tuple]:
+    """NeMo state-dict names (CTC branch only) -> shapes."""
+    s = {
+        "encoder.pre_encode.conv.0.weight": (SUB_CH, 1, 3, 3), "encoder.pre_encode.conv.0.bias": (SUB_CH,),
+        "encoder.pre_encode.conv.2.weight": (SUB_CH, 1, 3, 3), "encoder.pre_encode.conv.2.bias": (SUB_CH,),
+        "encoder.pre_encode.conv.3.weight": (SUB_CH, SUB_CH, 1, 1), "encoder.pre_encode.conv.3.bias": (SUB_CH,),
+        "encoder.pre_encode.conv.5.weight": (SUB_CH, 1, 3, 3), "encoder.pre_encode.conv.5.bias": (SUB_CH,),
+        "encoder.pre_encode.conv.6.weight": (SUB_CH, SUB_CH, 1, 1), "encoder.pre_encode.conv.6.bias": (SUB_CH,),
+        "encoder.pre_encode.out.weight": (D_MODEL, SUB_CH * 10), "encoder.pre_encode.out.bias": (D_MODEL,),
+        "ctc_decoder.decoder_layers.0.weight": (VOCAB, D_MODEL, 1), "ctc_decoder.decoder_layers.0.bias": (VOCAB,),
+    }
+    for i in range(n_layers):
+        p = f"encoder.layers.{i}."
+        for ln in ("norm_feed_forward1", "norm_self_att", "norm_conv", "norm_feed_forward2", "norm_out"):
+            s[p + ln + ".weight"] = (D_MODEL,)
+            s[p + ln + ".bias"] = (D_MODEL,)
+        for ff in ("feed_forward1", "feed_forward2"):
+            s[p + ff + ".linear1.weight"] = (FF, D_MODEL)
+            s[p + ff + ".linear1.bias"] = (FF,)
+            s[p + ff + ".linear2.weight"] = (D_MODEL, FF)
+            s[p + ff + ".linear2.bias"] = (D_MODEL,)
+        for lin in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            s[p + "self_attn." + lin + ".weight"] = (D_MODEL, D_MODEL)
+            s[p + "self_attn." + lin + ".bias"] = (D_MODEL,)
+        s[p + "self_attn.linear_pos.weight"] = (D_MODEL, D_MODEL)
+        s[p + "self_attn.pos_bias_u"] = (N_HEADS, D_K)
+        s[p + "self_attn.pos_bias_v"] = (N_HEADS, D_K)
+        s[p + "conv.pointwise_conv1.weight"] = (2 * D_MODEL, D_MODEL, 1)
+        s[p + "conv.pointwise_conv1.bias"] = (2 * D_MODEL,)
+        s[p + "conv.depthwise_conv.weight"] = (D_MODEL, 1, CONV_K)
+        s[p + "conv.depthwise_conv.bias"] = (D_MODEL,)
+        s[p + "conv.batch_norm.weight"] = (D_MODEL,)
+        s[p + "conv.batch_norm.bias"] = (D_MODEL,)
+        s[p + "conv.batch_norm.running_mean"] = (D_MODEL,)
+        s[p + "conv.batch_norm.running_var"] = (D_MODEL,)
+        s[p + "conv.pointwise_conv2.weight"] = (D_MODEL, D_MODEL, 1)
+        s[p + "conv.pointwise_conv2.bias"] = (D_MODEL,)
+    return s
+
+
+def _fnv1a(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _noise(n: int, key: int) -> np.ndarray:
+    """zero-mean, unit-variance-ish (Irwin-Hall of 4 bytes), exact in float32; the HIP library's
+    own generator (csrc/qv_model.hip::init_random) is the same integer recipe."""
+    with np.errstate(over="ignore"):
+        h = _splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(key))
+    s = ((h & np.uint64(0xFF)) + ((h >> np.uint64(8)) & np.uint64(0xFF)) + ((h >> np.uint64(16)) & np.uint64(0xFF))
+         + ((h >> np.uint64(24)) & np.uint64(0xFF))).astype(np.int64) - 510
+    return s.astype(np.float32) * np.float32(1.0 / 147.8)
+
+
+def init_rule(name: str, shape) -> tuple[float, float, bool]:
+    """(offset, scale, abs) of the seeded init: value = offset + scale * (|noise| if abs else noise)."""
+    n = int(np.prod(shape))
+    if name.endswith("running_var"):
+        return 1.0, 0.1, True
+    if name.endswith("running_mean"):
+        return 0.0, 0.1, False
+    if ".norm_" in name or "batch_norm" in name:
+        return (1.0, 0.1, False) if name.endswith("weight") else (0.0, 0.1, False)
+    if name.endswith("bias") or "pos_bias" in name:
+        return 0.0, 0.1, False
+    fan_in = n // shape[0]
+    return 0.0, float(np.float32(1.0) / np.sqrt(np.float32(fan_in))), False
+
+
+def random_weights(seed: int = 20260630, n_layers: int = N_LAYERS) -> dict[str, torch.Tensor]:
+    out = {}
+    for name, shape in weight_shapes(n_layers).items():
+        n = int(np.prod(shape))
+        key = (_fnv1a(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        z = _noise(n, key)
+        off, sc, ab = init_rule(name, shape)
+        if ab:
+            z = np.abs(z)
+        v = np.float32(off) + np.float32(sc) * z
+        out[name] = torch.from_numpy(v.astype(np.float32).reshape(shape))
+    return out
+
+
+# ------------------------------------------------------------------- front-end --------
+def mel_filterbank() -> np.ndarray:
+    """librosa.filters.mel(sr=16000, n_fft=512, n_mels=80, fmin=0, fmax=8000, htk=False,
+    norm='slaney') restated (Slaney auditory-toolbox scale)."""
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        f_sp = 200.0 / 3
+        mels = f / f_sp
+        min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        f_sp = 200.0 / 3
+        min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, SR / 2, 1 + N_FFT // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(SR / 2), N_MELS + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((N_MELS, 1 + N_FFT // 2))
+    for i in range(N_MELS):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2: N_MELS + 2] - mel_f[:N_MELS])
+    return (w * enorm[:, None]).astype(np.float32)
+
+
+def hann_window() -> torch.Tensor:
+    return torch.hann_window(WIN, periodic=False, dtype=torch.float32)
+
+
+def mel_frames(n_samples: int) -> int:
+    return n_samples // HOP + 1
+
+
+def sub_len(t: int) -> int:
+    for _ in range(3):
+        t = (t + 2 - 3) // 2 + 1
+    return t
+
+
+def frontend(audio: torch.Tensor, lengths: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """audio [B,N] float32 (zero padded), lengths [B] -> features [B, 80, Tm] and Tm lengths."""
+    B, N = audio.shape
+    tm = torch.div(lengths, HOP, rounding_mode="floor") + 1
+    x = torch.cat([audio[:, :1], audio[:, 1:] - PREEMPH * audio[:, :-1]], dim=1)
+    # samples past each utterance's length must behave like the unpadded case: the reference feeds
+    # every file alone, and torch.stft's reflect padding mirrors around ITS end.  Process per item.
+    fb = torch.from_numpy(mel_filterbank())
+    win = hann_window()
+    Tm = int(tm.max())
+    out = torch.zeros(B, N_MELS, Tm)
+    for b in range(B):
+        n = int(lengths[b])
+        st = torch.stft(x[b, :n], N_FFT, hop_length=HOP, win_length=WIN, window=win, center=True,
+                        pad_mode="reflect", return_complex=True)
+        p = st.real ** 2 + st.imag ** 2
+        p = torch.sqrt(p) ** 2  # NeMo: magnitude then .pow(2)
+        m = torch.log(fb @ p + LOG_GUARD)
+        t = int(tm[b])
+        m = m[:, :t]
+        mean = m.mean(dim=1, keepdim=True)
+        std = torch.sqrt(((m - mean) ** 2).sum(dim=1, keepdim=True) / (t - 1)) + 1e-5
+        out[b, :, :t] = (m - mean) / std
+    return out, tm
+
+
+# ------------------------------------------------------------------- encoder ----------
+def rel_pos_emb(T: int) -> torch.Tensor:
+    """RelPositionalEncoding: positions T-1 .. -(T-1) -> [2T-1, d_model]."""
+    pos = torch.arange(T - 1, -T, -1, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, D_MODEL, 2, dtype=torch.float32) * -(math.log(10000.0) / D_MODEL))
+    pe = torch.zeros(2 * T - 1, D_MODEL)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def rel_shift(x: torch.Tensor) -> torch.Tensor:
+    b, h, qlen, pos_len = x.size()
+    x = F.pad(x, pad=(1, 0))
+    x = x.view(b, h, -1, qlen)
+    return x[:, :, 1:].view(b, h, qlen, pos_len)
+
+
+def subsampling(w, feats: torch.Tensor, tm: torch.Tensor):
+    """feats [B,80,Tm] -> [B,T,512]; activations past each stage's valid length are zeroed so a
+    padded batch equals the per-utterance (unpadded) result."""
+    x = feats.transpose(1, 2).unsqueeze(1)  # [B,1,Tm,80]
+    lens = tm.clone()
+
+    def mask_t(x, lens):
+        T = x.shape[2]
+        m = (torch.arange(T)[None, :] < lens[:, None]).to(x.dtype)
+        return x * m[:, None, :, None]
+
+    x = mask_t(x, lens)
+    x = F.relu(F.conv2d(x, w["encoder.pre_encode.conv.0.weight"], w["encoder.pre_encode.conv.0.bias"], stride=2, padding=1))
+    lens = (lens + 2 - 3) // 2 + 1
+    x = mask_t(x, lens)
+    for dw, pw in ((2, 3), (5, 6)):
+        x = F.conv2d(x, w[f"encoder.pre_encode.conv.{dw}.weight"], w[f"encoder.pre_encode.conv.{dw}.bias"], stride=2,
+                     padding=1, groups=SUB_CH)
+        x = F.relu(F.conv2d(x, w[f"encoder.pre_encode.conv.{pw}.weight"], w[f"encoder.pre_encode.conv.{pw}.bias"]))
+        lens = (lens + 2 - 3) // 2 + 1
+        x = mask_t(x, lens)
+    b, c, t, f = x.shape
+    x = x.transpose(1, 2).reshape(b, t, c * f)
+    x = F.linear(x, w["encoder.pre_encode.out.weight"], w["encoder.pre_encode.out.bias"])
+    return x, lens
+
+
+def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torch.Tensor):
+    """x [B,T,512]; pad [B,T] True where padded."""
+    B, T, _ = x.shape
+
+    def ln(name, t):
+        return F.layer_norm(t, (D_MODEL,), w[p + name + ".weight"], w[p + name + ".bias"], 1e-5)
+
+    def ffn(name, t):
+        t = F.linear(t, w[p + name + ".linear1.weight"], w[p + name + ".linear1.bias"])
+        t = t * torch.sigmoid(t)
+        return F.linear(t, w[p + name + ".linear2.weight"], w[p + name + ".linear2.bias"])
+
+    r = x
+    r = r + 0.5 * ffn("feed_forward1", ln("norm_feed_forward1", r))
+    # --- rel-pos MHSA
+    y = ln("norm_self_att", r)
+    a = p + "self_attn."
+    q = F.linear(y, w[a + "linear_q.weight"], w[a + "linear_q.bias"]).view(B, T, N_HEADS, D_K)
+    k = F.linear(y, w[a + "linear_k.weight"], w[a + "linear_k.bias"]).view(B, T, N_HEADS, D_K).transpose(1, 2)
+    v = F.linear(y, w[a + "linear_v.weight"], w[a + "linear_v.bias"]).view(B, T, N_HEADS, D_K).transpose(1, 2)
+    pp = F.linear(pos_emb, w[a + "linear_pos.weight"]).view(1, -1, N_HEADS, D_K).transpose(1, 2)
+    qu = (q + w[a + "pos_bias_u"]).transpose(1, 2)
+    qv = (q + w[a + "pos_bias_v"]).transpose(1, 2)
+    bd = rel_shift(torch.matmul(qv, pp.transpose(-2, -1)))
+    ac = torch.matmul(qu, k.transpose(-2, -1))
+    bd = bd[:, :, :, : ac.size(-1)]
+    scores = (ac + bd) / math.sqrt(D_K)
+    valid = ~pad
+    att_mask = ~(valid[:, None, :] & valid[:, :, None])  # [B,T,T] True = masked
+    scores = scores.masked_fill(att_mask[:, None], -10000.0)
+    attn = torch.softmax(scores, dim=-1).masked_fill(att_mask[:, None], 0.0)
+    ctx = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, D_MODEL)
+    r = r + F.linear(ctx, w[a + "linear_out.weight"], w[a + "linear_out.bias"])
+    # --- conv module
+    y = ln("norm_conv", r).transpose(1, 2)
+    c = p + "conv."
+    y = F.conv1d(y, w[c + "pointwise_conv1.weight"], w[c + "pointwise_conv1.bias"])
+    y = F.glu(y, dim=1)
+    y = y.masked_fill(pad[:, None, :], 0.0)
+    y = F.conv1d(y, w[c + "depthwise_conv.weight"], w[c + "depthwise_conv.bias"], padding=(CONV_K - 1) // 2, groups=D_MODEL)
+    y = F.batch_norm(y, w[c + "batch_norm.running_mean"], w[c + "batch_norm.running_var"], w[c + "batch_norm.weight"],
+                     w[c + "batch_norm.bias"], False, 0.0, 1e-5)
+    y = y * torch.sigmoid(y)
+    y = F.conv1d(y, w[c + "pointwise_conv2.weight"], w[c + "pointwise_conv2.bias"]).transpose(1, 2)
+    r = r + y
+    r = r + 0.5 * ffn("feed_forward2", ln("norm_feed_forward2", r))
+    return ln("norm_out", r)
+
+
+@torch.no_grad()
+def forward(w, audio: torch.Tensor, lengths, n_layers: int = N_LAYERS, taps: dict | None = None):
+    """audio [B,N] float32, lengths -> (log_probs [B,T,1025], T lengths).  taps (optional dict)
+    receives intermediate activations: 'mel' [B,Tm,80], 'sub' [B,T,512], 'layer{i}' [B,T,512]."""
+    lengths = torch.as_tensor(lengths, dtype=torch.int64)
+    feats, tm = frontend(audio, lengths)
+    if taps is not None:
+        taps["mel"] = feats.transpose(1, 2).contiguous()
+    x, lens = subsampling(w, feats, tm)
+    if taps is not None:
+        taps["sub"] = x.clone()
+    B, T, _ = x.shape
+    x = x * math.sqrt(D_MODEL)
+    pos_emb = rel_pos_emb(T).unsqueeze(0)
+    pad = torch.arange(T)[None, :] >= lens[:, None]
+    for i in range(n_layers):
+        x = conformer_layer(w, f"encoder.layers.{i}.", x, pos_emb, pad)
+        if taps is not None:
+            taps[f"layer{i}"] = x.clone()
+    logits = F.linear(x, w["ctc_decoder.decoder_layers.0.weight"].squeeze(-1), w["ctc_decoder.decoder_layers.0.bias"])
+    return torch.log_softmax(logits, dim=-1), lens
