@@ -162,6 +162,14 @@ int qv_debug_ctc_loss(qv_engine *e, const float *logprobs_dev, int32_t t_frames,
  * f32[B, t_max, 512]; 2 = encoder output after layer `layer` f32[B, t_max, 512]. */
 int qv_debug_forward_tap(qv_engine *e, int32_t what, int32_t layer, float *out_dev, void *stream);
 
+/* Measurement hooks for bench.py's roofline line: while enabled, every GEMM launch of the
+ * acoustic model is bracketed by HIP events on its own stream.  After synchronising the stream,
+ * qv_profile_gemm_read() returns, per kernel class c = epilogue*2 + (tile 128 ? 1 : 0) (14
+ * classes), the summed event time in ms, the summed algorithmic FLOPs (2*M*N*K) and the launch
+ * count, and clears the log. */
+int qv_profile_gemm(qv_engine *e, int32_t enable);
+int qv_profile_gemm_read(qv_engine *e, double *ms14, double *flops14, int32_t *launches14);
+
 /* Library build info: "gfx950;hip-x.y;..." */
 const char *qv_build_info(void);
 

@@ -1,6 +1,7 @@
 // qv_capi.hip -- C ABI entry points (include/qverse.h), engine lifetime, table upload.
 
 #include "qv_common.h"
+#include "qv_kernels.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -393,4 +394,19 @@ extern "C" int qv_debug_forward_tap(qv_engine *eng, int32_t what, int32_t layer,
     if (!eng) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
     return qv_model_tap(eng, eng->model, what, layer, out_dev, (hipStream_t)stream);
+}
+
+// ---- measurement hooks -------------------------------------------------------------------
+extern "C" int qv_profile_gemm(qv_engine *eng, int32_t enable) {
+    if (!eng) return QV_ERR_ARG;
+    qv_gemm_prof_enable(enable != 0);
+    return QV_OK;
+}
+
+extern "C" int qv_profile_gemm_read(qv_engine *eng, double *ms14, double *flops14, int32_t *launches14) {
+    if (!eng || !ms14 || !flops14 || !launches14) return QV_ERR_ARG;
+    int n[14];
+    qv_gemm_prof_collect(ms14, flops14, n);
+    for (int i = 0; i < 14; ++i) launches14[i] = n[i];
+    return QV_OK;
 }

@@ -4,6 +4,8 @@
 
 #include <stdio.h>
 
+#include <vector>
+
 namespace {
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -143,6 +145,41 @@ static void launch_one(const GemmArgs &g, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm<EPI, BN>), grid, dim3(256), lds, s, g);
 }
 
+// ---- measurement hook: HIP-event timing of every GEMM launch, per (epilogue, tile) class ----
+namespace {
+struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> cls;
+    std::vector<double> flops;
+    size_t used = 0;
+} g_prof;
+}  // namespace
+
+void qv_gemm_prof_enable(bool on) {
+    g_prof.on = on;
+    g_prof.used = 0;
+    g_prof.cls.clear();
+    g_prof.flops.clear();
+}
+
+// call after the stream has been synchronised; accumulates into ms[14], flops[14], n[14]
+void qv_gemm_prof_collect(double *ms, double *flops, int *n) {
+    for (int i = 0; i < 14; ++i) { ms[i] = 0; flops[i] = 0; n[i] = 0; }
+    for (size_t i = 0; i < g_prof.cls.size(); ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) continue;
+        ms[g_prof.cls[i]] += t;
+        flops[g_prof.cls[i]] += g_prof.flops[i];
+        n[g_prof.cls[i]] += 1;
+    }
+    g_prof.used = 0;
+    g_prof.cls.clear();
+    g_prof.flops.clear();
+}
+
+static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow);
+
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     if (g.K % 64 != 0 || g.N % 64 != 0) {
         fprintf(stderr, "launch_gemm: unsupported shape N=%d K=%d\n", g.N, g.K);
@@ -150,6 +187,21 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     }
     // narrow-N GEMMs on few row panels get 64-wide tiles so the grid still covers the chip
     bool narrow = (g.N % 128 != 0) || ((g.N / 128) * ((g.M + 127) / 128) < 512 && epi != EPI_GLU);
+    if (!g_prof.on) { launch_gemm_inner(epi, g, s, narrow); return; }
+    size_t i = g_prof.cls.size();
+    while (g_prof.ev.size() < 2 * (i + 1)) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { launch_gemm_inner(epi, g, s, narrow); return; }
+        g_prof.ev.push_back(e);
+    }
+    (void)hipEventRecord(g_prof.ev[2 * i], s);
+    launch_gemm_inner(epi, g, s, narrow);
+    (void)hipEventRecord(g_prof.ev[2 * i + 1], s);
+    g_prof.cls.push_back(epi * 2 + (narrow ? 0 : 1));
+    g_prof.flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
+}
+
+static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow) {
     switch (epi) {
 #define CASE(E)                                                   \
     case E:                                                       \

@@ -53,3 +53,7 @@ template <int EPI, int BN>
 __global__ void k_gemm(GemmArgs g);
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);
+
+// measurement hooks (bench.py roofline): per-launch HIP-event timing of the GEMMs
+void qv_gemm_prof_enable(bool on);
+void qv_gemm_prof_collect(double *ms, double *flops, int *n);

@@ -90,6 +90,8 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_debug_retrieve.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.qv_debug_ctc_loss.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     lib.qv_debug_forward_tap.argtypes = [vp, i32, i32, vp, vp]
+    lib.qv_profile_gemm.argtypes = [vp, i32]
+    lib.qv_profile_gemm_read.argtypes = [vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -275,6 +277,26 @@ class Engine:
         rc = hip.hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), batch * 16, 3, self._stream())
         if rc != 0:
             raise QvError(f"hipMemcpyAsync failed ({rc})")
+        return out
+
+    # ---------------------------------------------------------------- measurement
+    GEMM_EPILOGUES = ["f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"]
+
+    def profile_gemm(self, enable: bool):
+        self._check(self.lib.qv_profile_gemm(self.h, int(enable)), "qv_profile_gemm")
+
+    def profile_gemm_read(self) -> list[dict]:
+        """per GEMM kernel class: summed HIP-event ms, algorithmic FLOPs, launches."""
+        ms = np.zeros(14)
+        fl = np.zeros(14)
+        n = np.zeros(14, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._check(self.lib.qv_profile_gemm_read(self.h, p(ms), p(fl), p(n)), "qv_profile_gemm_read")
+        out = []
+        for c in range(14):
+            if n[c]:
+                out.append({"kernel": f"k_gemm<{self.GEMM_EPILOGUES[c // 2]},{128 if c % 2 else 64}>",
+                            "ms": float(ms[c]), "flops": float(fl[c]), "launches": int(n[c])})
         return out
 
     # ---------------------------------------------------------------- debug ------

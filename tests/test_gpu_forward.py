@@ -1,0 +1,119 @@
+"""HIP FastConformer-CTC forward vs the fp32 PyTorch restatement (oracle/fastconformer_ref.py)
+on seeded random weights, through the C ABI (GPU).
+
+Tolerance: north_star asks CTC log-probs within 1e-2; the fp16-operand / fp32-accumulate HIP
+path lands at ~4e-3 max abs on this workload.
+"""
+
+import os
+
+import pytest
+import torch
+
+from synth import synth_audio
+
+pytestmark = pytest.mark.gpu
+
+SEED = 7
+LENS = [48000, 30000, 17777]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    os.environ["QVERSE_DEBUG_TAPS"] = "1"
+    from offline_tarteel_amd.engine import Engine
+    from oracle import fastconformer_ref as R
+
+    audio = torch.from_numpy(synth_audio(3, 48000))
+    for b, n in enumerate(LENS):
+        audio[b, n:] = 0
+    w = R.random_weights(SEED)
+    taps = {}
+    lp_ref, t_ref = R.forward(w, audio, LENS, taps=taps)
+    eng = Engine(device=0, with_model=True, seed=SEED, max_batch=4, max_samples=80000)
+    lp, t = eng.forward(audio.cuda().contiguous(), LENS)
+    torch.cuda.synchronize()
+    yield dict(eng=eng, audio=audio, lp=lp, t=t, lp_ref=lp_ref, t_ref=t_ref.tolist(), taps=taps, w=w, R=R)
+    eng.close()
+    os.environ.pop("QVERSE_DEBUG_TAPS", None)
+
+
+def _maxdiff(a, b, lens):
+    return max(float((a[i, :n].float().cpu() - b[i, :n].float()).abs().max()) for i, n in enumerate(lens))
+
+
+def test_frame_counts(setup):
+    assert setup["t"] == setup["t_ref"]
+    for n, t in zip(LENS, setup["t"]):
+        assert setup["eng"].frames_for(n) == t
+
+
+def test_logmel_frontend(setup):
+    tm = [n // 160 + 1 for n in LENS]
+    mel = setup["eng"].forward_tap(0, 0, (3, max(tm), 80))
+    assert _maxdiff(mel, setup["taps"]["mel"], tm) <= 5e-4
+    # padded frames are zeroed (NeMo masks features past the valid length)
+    assert float(mel[2, tm[2]:].abs().max()) == 0.0
+
+
+def test_subsampling_and_layers(setup):
+    T = setup["t"]
+    eng, taps = setup["eng"], setup["taps"]
+    sub = eng.forward_tap(1, 0, (3, max(T), 512))
+    assert _maxdiff(sub, taps["sub"] * (512 ** 0.5), T) <= 5e-2   # values ~ +-30, fp16 operands
+    for l in (0, 3, 8, 16):
+        x = eng.forward_tap(2, l, (3, max(T), 512))
+        assert _maxdiff(x, taps[f"layer{l}"], T) <= 1.5e-2, l
+
+
+def test_logprobs_within_tolerance(setup):
+    T = setup["t"]
+    d = _maxdiff(setup["lp"], setup["lp_ref"], T)
+    assert d <= 1e-2, d
+    for i, n in enumerate(T):
+        got = setup["lp"][i, :n].cpu()
+        assert torch.allclose(got.exp().sum(-1), torch.ones(n), atol=1e-4)
+        assert (got.argmax(-1) == setup["lp_ref"][i, :n].argmax(-1)).all()
+
+
+def test_batch_invariance(setup):
+    """an utterance alone == the same utterance inside a padded batch."""
+    eng, audio = setup["eng"], setup["audio"]
+    lp1, t1 = eng.forward(audio[1:2, :30000].cuda().contiguous(), [30000])
+    assert t1[0] == setup["t"][1]
+    assert float((lp1[0, :t1[0]] - setup["lp"][1, :t1[0]]).abs().max()) <= 1e-5
+    lp2, t2 = eng.forward(audio[2:3, :17777].cuda().contiguous(), [17777])
+    assert float((lp2[0, :t2[0]] - setup["lp"][2, :t2[0]]).abs().max()) <= 1e-5
+
+
+def test_predict_batch_equals_forward_then_postlogits(setup):
+    eng, audio = setup["eng"], setup["audio"]
+    res = eng.predict_batch(audio.cuda().contiguous(), LENS)
+    res2 = eng.decode_retrieve_rerank(setup["lp"].contiguous(), setup["t"])
+    for a, b in zip(res, res2):
+        assert (a["surah"], a["ayah"], a["ayah_end"], a["source"], a["greedy_ids"]) == (
+            b["surah"], b["ayah"], b["ayah_end"], b["source"], b["greedy_ids"])
+        assert a["score"] == b["score"]
+
+
+def test_predict_matches_oracle_on_hip_logprobs(setup, oracle):
+    """whole path: HIP post-logits == oracle post-logits on the HIP forward's log-probs."""
+    eng = setup["eng"]
+    res = eng.decode_retrieve_rerank(setup["lp"].contiguous(), setup["t"])
+    for i, n in enumerate(setup["t"]):
+        want = oracle.predict_logprobs(setup["lp"][i, :n].cpu().numpy())
+        got = res[i]
+        assert got["greedy_ids"] == want["greedy_ids"]
+        assert (got["surah"], got["ayah"], got["ayah_end"], got["source"]) == (
+            want["surah"], want["ayah"], want["ayah_end"], want["source"])
+        assert abs(got["score"] - want.get("score_raw", 0.0)) <= 1e-3 * max(want.get("score_raw", 0.0), 1e-3)
+
+
+def test_rejects_out_of_capacity(setup):
+    from offline_tarteel_amd.engine import QvError
+
+    eng = setup["eng"]
+    with pytest.raises(QvError):
+        eng.forward(torch.zeros(1, 90000, device="cuda"), [90000])
+    with pytest.raises(QvError):
+        eng.forward(torch.zeros(5, 16000, device="cuda"), [16000] * 5)
