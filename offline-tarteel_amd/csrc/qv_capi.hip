@@ -215,6 +215,7 @@ static int alloc_work(qv_engine *eng) {
     QV_TRY(dalloc(eng, Bz * QV_MAXQ, &w.qs));
     QV_TRY(dalloc(eng, Bz * 2 * QV_NSYM * QV_MAXW, &w.pm));
     QV_TRY(dalloc(eng, Bz * N, &w.cand1));
+    QV_TRY(dalloc(eng, Bz * N * 3, &w.lcsf));
     QV_TRY(dalloc(eng, Bz * N * 3, &w.fs));
     QV_TRY(dalloc(eng, Bz * N, &w.p3));
     w.search_sc = nullptr;

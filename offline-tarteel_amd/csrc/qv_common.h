@@ -104,6 +104,7 @@ struct QvWork {
     uint8_t *qs;             // [B][QV_MAXQ] spaceless
     uint64_t *pm;            // [B][2][QV_NSYM][QV_MAXW]  (0: q, 1: spaceless q)
     int32_t *cand1;          // [B][N]
+    int16_t *lcsf;           // [B][N][3] full-string LCS(transcript, text) (clean, alt, nobsm)
     double *fs;              // [B][N][3] fragment scores (clean, alt, nobsm)
     double *p3;              // [B][N]   pass-3 score
     double *search_sc;       // [B][N]   search score (max over clean/alt)

@@ -93,45 +93,78 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    // operands swapped (D^T = W A^T): a lane then holds 4 CONSECUTIVE output
+                    // columns per register quad, so the epilogue stores 8/16 bytes at a time
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
     // ------------------------------------------------------------------ epilogue ----------
-    const int colb = n0 + wn * WN + (lane & 31);
+    // accumulator (i, j), register r: row m = m0 + wm*64 + i*32 + (lane & 31),
+    //   column n = n0 + wn*WN + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+    const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 64 + i * 32 + l31;
+        if (row >= g.M) continue;
+        if (EPI == EPI_GLU) {
+            // W rows interleaved in 32-channel groups: [value(32) | gate(32)] per 64 columns
+            const int nb = n0 + wn * WN;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= g.M) continue;
-            if (EPI == EPI_GLU) {
-                // W rows interleaved in 32-channel groups: [a(32) | gate(32)] per 64 columns
-                float av = acc[i][0][r] + g.bias[colb];
-                float gv = acc[i][NF - 1][r] + g.bias[colb + 32];
-                int oc = ((n0 + wn * WN) >> 1) + (lane & 31);
-                ((half_t *)g.out)[(size_t)row * g.ldo + oc] = (half_t)(av * sigmoidf_(gv));
-                continue;
+            for (int q = 0; q < 4; ++q) {
+                int nl = 8 * q + 4 * hi;
+                f32x4 ba = *(const f32x4 *)(g.bias + nb + nl), bg = *(const f32x4 *)(g.bias + nb + 32 + nl);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float av = acc[i][0][q * 4 + e] + ba[e], gv = acc[i][NF - 1][q * 4 + e] + bg[e];
+                    o[e] = (half_t)(av * sigmoidf_(gv));
+                }
+                *(half4 *)((half_t *)g.out + (size_t)row * g.ldo + (nb >> 1) + nl) = o;
             }
+            continue;
+        }
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                int col = colb + j * 32;
-                float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
-                if (EPI == EPI_F16) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)v;
-                else if (EPI == EPI_F16_SWISH) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)(v * sigmoidf_(v));
-                else if (EPI == EPI_F16_RELU) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)(v > 0.f ? v : 0.f);
-                else if (EPI == EPI_RESID) {
-                    float *o = (float *)g.out + (size_t)row * g.ldo + col;
-                    *o = *o + g.alpha * v;
-                } else if (EPI == EPI_F32) ((float *)g.out)[(size_t)row * g.ldo + col] = g.alpha * v;
-                else if (EPI == EPI_QKV) {
-                    if (col < 2 * QV_D) ((half_t *)g.out)[(size_t)row * g.ldo + col] = (half_t)v;
-                    else {
-                        int hd = col - 2 * QV_D;  // h*64 + d
-                        int b = row / g.t_max, t = row - b * g.t_max;
-                        ((half_t *)g.out2)[((size_t)b * QV_D + hd) * g.t_pad + t] = (half_t)v;
+        for (int j = 0; j < NF; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn * WN + j * 32 + 8 * q + 4 * hi;
+                f32x4 v;
+                if (g.bias) {
+                    f32x4 bb = *(const f32x4 *)(g.bias + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] + bb[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                }
+                if (EPI == EPI_RESID) {
+                    f32x4 *o = (f32x4 *)((float *)g.out + (size_t)row * g.ldo + col);
+                    f32x4 old = *o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) old[e] += g.alpha * v[e];
+                    *o = old;
+                } else if (EPI == EPI_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= g.alpha;
+                    *(f32x4 *)((float *)g.out + (size_t)row * g.ldo + col) = v;
+                } else if (EPI == EPI_QKV && col >= 2 * QV_D) {
+                    // V: transposed store Vt[b][h*64+d][t]; 32 lanes = 32 consecutive t
+                    int b = row / g.t_max, t = row - b * g.t_max;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ((half_t *)g.out2)[((size_t)b * QV_D + (col - 2 * QV_D + e)) * g.t_pad + t] = (half_t)v[e];
+                } else {
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        if (EPI == EPI_F16_SWISH) x = x * sigmoidf_(x);
+                        if (EPI == EPI_F16_RELU) x = x > 0.f ? x : 0.f;
+                        o[e] = (half_t)x;
                     }
+                    *(half4 *)((half_t *)g.out + (size_t)row * g.ldo + col) = o;
                 }
             }
         }

@@ -110,57 +110,90 @@ __global__ __launch_bounds__(320) void k_melnorm(float *__restrict__ feats, cons
 
 // ------------------------------------------------------------------ subsampling --------
 // conv0: Conv2d(1->256, 3x3, s2, p1) + ReLU on [B][Tm][80] -> channels-last f16 [B][T1][40][256].
-// One thread = one (t1, f1) position x 8 channels.
+// Block = one output row t1; a thread owns 8 channels (weights [9][256] tap-major, held in
+// registers) and walks the 40 frequency positions with stride 8; the 3 input rows sit in LDS.
 __global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_in,
-                                               const float *__restrict__ w, const float *__restrict__ bias,
+                                               const float *__restrict__ wt /*[9][256]*/, const float *__restrict__ bias,
                                                half_t *__restrict__ out, int t1_max) {
+    __shared__ float rows[3][QV_NMEL + 2];
     const int b = blockIdx.z, t1 = blockIdx.y, tid = threadIdx.x;
     const int tin = len_in[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
-    for (int idx = tid; idx < 40 * 32; idx += 256) {
-        int f1 = idx >> 5, c0 = (idx & 31) * 8;
-        float in[9];
+    for (int i = tid; i < 3 * (QV_NMEL + 2); i += 256) {
+        int dt = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = 2 * t1 - 1 + dt;
+        rows[dt][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? x[t * QV_NMEL + f] : 0.f;
+    }
+    const int c0 = (tid & 31) * 8, fl = tid >> 5;
+    float w[9][8], bs[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        f32x4 w0 = *(const f32x4 *)(wt + k * QV_SUBC + c0), w1 = *(const f32x4 *)(wt + k * QV_SUBC + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = w0[c]; w[k][4 + c] = w1[c]; }
+    }
+    {
+        f32x4 b0 = *(const f32x4 *)(bias + c0), b1 = *(const f32x4 *)(bias + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
+    }
+    __syncthreads();
+    for (int f1 = fl; f1 < 40; f1 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = bs[c];
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
             for (int df = 0; df < 3; ++df) {
-                int t = 2 * t1 - 1 + dt, f = 2 * f1 - 1 + df;
-                in[dt * 3 + df] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? x[t * QV_NMEL + f] : 0.f;
+                float v = rows[dt][2 * f1 + df];  // input f = 2*f1 - 1 + df, stored at +1
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * v;
             }
         half8 o;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float acc = bias[c0 + c];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc += w[(c0 + c) * 9 + k] * in[k];
-            o[c] = (half_t)(acc > 0.f ? acc : 0.f);
-        }
+        for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] > 0.f ? acc[c] : 0.f);
         *(half8 *)(out + (((size_t)b * t1_max + t1) * 40 + f1) * QV_SUBC + c0) = o;
     }
 }
 
 // depthwise Conv2d(256, 3x3, s2, p1, groups=256) on channels-last f16; rows t >= len_in[b] read as 0.
+// Same ownership as conv0: 8 channels per thread, weights [9][256] in registers.
 __global__ __launch_bounds__(256) void k_dwconv2d(const half_t *__restrict__ in, int tin_max, int fin,
-                                                  const int32_t *__restrict__ len_in, const float *__restrict__ w,
+                                                  const int32_t *__restrict__ len_in, const float *__restrict__ wt,
                                                   const float *__restrict__ bias, half_t *__restrict__ out, int tout_max,
                                                   int fout) {
     const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
     const int tin = len_in[b];
-    for (int idx = tid; idx < fout * 32; idx += 256) {
-        int fo = idx >> 5, c0 = (idx & 31) * 8;
+    const int c0 = (tid & 31) * 8, fl = tid >> 5;
+    float w[9][8], bs[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        f32x4 w0 = *(const f32x4 *)(wt + k * QV_SUBC + c0), w1 = *(const f32x4 *)(wt + k * QV_SUBC + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = w0[c]; w[k][4 + c] = w1[c]; }
+    }
+    {
+        f32x4 b0 = *(const f32x4 *)(bias + c0), b1 = *(const f32x4 *)(bias + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
+    }
+    for (int fo = fl; fo < fout; fo += 8) {
         float acc[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = bias[c0 + c];
+        for (int c = 0; c < 8; ++c) acc[c] = bs[c];
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+        for (int dt = 0; dt < 3; ++dt) {
+            int t = 2 * to - 1 + dt;
+            if (t < 0 || t >= tin) continue;
 #pragma unroll
             for (int df = 0; df < 3; ++df) {
-                int t = 2 * to - 1 + dt, f = 2 * fo - 1 + df;
-                if (t < 0 || t >= tin || f < 0 || f >= fin) continue;
+                int f = 2 * fo - 1 + df;
+                if (f < 0 || f >= fin) continue;
                 half8 v = *(const half8 *)(in + (((size_t)b * tin_max + t) * fin + f) * QV_SUBC + c0);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += w[(c0 + c) * 9 + dt * 3 + df] * (float)v[c];
+                for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * (float)v[c];
             }
+        }
         half8 o;
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
@@ -378,28 +411,57 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 
 // ------------------------------------------------------------------ conv module --------
 // depthwise Conv1d(512, k=9, pad 4) + folded BatchNorm + Swish on f16 [M][512]; input frames
-// t >= len[b] read as zero (the reference zeroes padded frames after GLU).
-__global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, const float *__restrict__ w /*[512][9]*/,
+// t >= len[b] read as zero (the reference zeroes padded frames after GLU).  A lane owns 8
+// channels (weights [9][512] tap-major in registers) and slides over DW_TT consecutive frames,
+// so each input row is loaded once per DW_TT outputs instead of 9 times.
+#define DW_TT 8
+__global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, const float *__restrict__ wt /*[9][512]*/,
                                                   const float *__restrict__ bias, const int32_t *__restrict__ len,
                                                   half_t *__restrict__ y, int t_max) {
-    const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= t_max) return;
+    const int b = blockIdx.y, t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DW_TT, lane = threadIdx.x & 63;
+    if (t0 >= t_max) return;
     const int T = len[b], c0 = lane * 8;
-    float acc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = bias[c0 + c];
+    float w[9][8], bs[8];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        int tt = t + k - 4;
+        f32x4 w0 = *(const f32x4 *)(wt + k * QV_D + c0), w1 = *(const f32x4 *)(wt + k * QV_D + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = w0[c]; w[k][4 + c] = w1[c]; }
+    }
+    {
+        f32x4 b0 = *(const f32x4 *)(bias + c0), b1 = *(const f32x4 *)(bias + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
+    }
+    float acc[DW_TT][8];
+#pragma unroll
+    for (int j = 0; j < DW_TT; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = bs[c];
+#pragma unroll
+    for (int i = 0; i < DW_TT + 8; ++i) {
+        int tt = t0 - 4 + i;
         if (tt < 0 || tt >= T) continue;
         half8 v = *(const half8 *)(x + ((size_t)b * t_max + tt) * QV_D + c0);
+        float vf[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] += w[(c0 + c) * 9 + k] * (float)v[c];
+        for (int c = 0; c < 8; ++c) vf[c] = (float)v[c];
+#pragma unroll
+        for (int j = 0; j < DW_TT; ++j) {
+            int k = i - j;  // tap index: tt = (t0 + j) + k - 4
+            if (k < 0 || k > 8) continue;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[j][c] += w[k][c] * vf[c];
+        }
     }
-    half8 o;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] * sigmoidf_(acc[c]));
-    *(half8 *)(y + ((size_t)b * t_max + t) * QV_D + c0) = o;
+    for (int j = 0; j < DW_TT; ++j) {
+        if (t0 + j >= t_max) break;
+        half8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[j][c] * sigmoidf_(acc[j][c]));
+        *(half8 *)(y + ((size_t)b * t_max + t0 + j) * QV_D + c0) = o;
+    }
 }
 
 // ------------------------------------------------------------------ log-softmax --------
@@ -475,7 +537,7 @@ void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int
 
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, half_t *y, int t_max, int batch,
                      hipStream_t s) {
-    hipLaunchKernelGGL(k_dwconv1d, dim3((t_max + 3) / 4, batch), dim3(256), 0, s, x, w, bias, len, y, t_max);
+    hipLaunchKernelGGL(k_dwconv1d, dim3((t_max + 4 * DW_TT - 1) / (4 * DW_TT), batch), dim3(256), 0, s, x, w, bias, len, y, t_max);
 }
 
 void launch_logsoftmax(const float *logits, int ld, float *out, int M, hipStream_t s) {

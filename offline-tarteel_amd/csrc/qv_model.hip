@@ -196,6 +196,14 @@ int dal(qv_engine *eng, QvModel *m, size_t count, T **dev) {
     return QV_OK;
 }
 
+// [C][9] -> [9][C] (tap-major) so a thread's 8 channels of one tap are one 32-byte load
+std::vector<float> tap_major(const std::vector<float> &w, int C) {
+    std::vector<float> t((size_t)C * 9);
+    for (int c = 0; c < C; ++c)
+        for (int k = 0; k < 9; ++k) t[(size_t)k * C + c] = w[(size_t)c * 9 + k];
+    return t;
+}
+
 std::vector<half_t> to_half(const std::vector<float> &v) {
     std::vector<half_t> h(v.size());
     for (size_t i = 0; i < v.size(); ++i) h[i] = (half_t)v[i];
@@ -251,13 +259,13 @@ int build_frontend(qv_engine *eng, QvModel *m) {
 
 int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
     const std::string pe = "encoder.pre_encode.";
-    TRY(up(eng, m, hw.get(pe + "conv.0.weight"), &m->c0_w));
+    TRY(up(eng, m, tap_major(hw.get(pe + "conv.0.weight"), QV_SUBC), &m->c0_w));
     TRY(up(eng, m, hw.get(pe + "conv.0.bias"), &m->c0_b));
-    TRY(up(eng, m, hw.get(pe + "conv.2.weight"), &m->dw2_w));
+    TRY(up(eng, m, tap_major(hw.get(pe + "conv.2.weight"), QV_SUBC), &m->dw2_w));
     TRY(up(eng, m, hw.get(pe + "conv.2.bias"), &m->dw2_b));
     TRY(up(eng, m, to_half(hw.get(pe + "conv.3.weight")), &m->pw3_w));
     TRY(up(eng, m, hw.get(pe + "conv.3.bias"), &m->pw3_b));
-    TRY(up(eng, m, hw.get(pe + "conv.5.weight"), &m->dw5_w));
+    TRY(up(eng, m, tap_major(hw.get(pe + "conv.5.weight"), QV_SUBC), &m->dw5_w));
     TRY(up(eng, m, hw.get(pe + "conv.5.bias"), &m->dw5_b));
     TRY(up(eng, m, to_half(hw.get(pe + "conv.6.weight")), &m->pw6_w));
     TRY(up(eng, m, hw.get(pe + "conv.6.bias"), &m->pw6_b));
@@ -352,7 +360,7 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
                 for (int k = 0; k < 9; ++k) fw[(size_t)c * 9 + k] = w[(size_t)c * 9 + k] * s;
                 fb[c] = (b[c] - mu[c]) * s + be[c];
             }
-            TRY(up(eng, m, fw, &L.dw_w));
+            TRY(up(eng, m, tap_major(fw, QV_D), &L.dw_w));
             TRY(up(eng, m, fb, &L.dw_b));
         }
         TRY(up(eng, m, to_half(hw.get(p + "conv.pointwise_conv2.weight")), &L.pw2_w));

@@ -338,23 +338,19 @@ __device__ int pyset_order(const int32_t *vals, int n, int32_t *out, int32_t *ta
 
 #define TRI_WORDS 352  // >= ceil(10243/32), multiple of 32
 
-__global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *score = (double *)smem;                            // [N]
-    uint32_t *bits = (uint32_t *)(score + tab.n_verses);       // [TRI_WORDS]
-    double *sh_s = (double *)(bits + TRI_WORDS);               // [8]
-    unsigned long long *sh_k = (unsigned long long *)(sh_s + 8);  // [8]
-    int32_t *top = (int32_t *)(sh_k + 8);                      // [64]
-    int32_t *tabA = top + 64;                                  // [256]
-    int32_t *tabB = tabA + 256;                                // [256]
-    int *cnt = (int *)(tabB + 256);
-    int b = blockIdx.x, tid = threadIdx.x;
+#define TRI_CHUNKS 16
+
+// IDF-weighted trigram overlap per verse (forward index: the trigram ids of each verse are
+// tested against the transcript's trigram bitmap; sums run in ascending trigram id = the
+// canonical order).  grid (TRI_CHUNKS, B): each block scores one slice of the verses.
+__global__ __launch_bounds__(256) void k_tri_score(QvTables tab, QvWork wk) {
+    __shared__ uint32_t bits[TRI_WORDS];
+    int b = blockIdx.y, tid = threadIdx.x;
     QvUtt &u = wk.utt[b];
     int m = u.q_len;
-    if (m == 0) return;
+    if (m < 3) return;  // no trigrams: nothing touched (n_cand1 stays 0 -> full scan)
     const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
     for (int i = tid; i < TRI_WORDS; i += 256) bits[i] = 0;
-    if (tid == 0) *cnt = 0;
     __syncthreads();
     for (int i = tid; i + 2 < m; i += 256) {
         uint32_t key = ((uint32_t)q[i] << 12) | ((uint32_t)q[i + 1] << 6) | q[i + 2];
@@ -368,8 +364,10 @@ __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
         if (id >= 0) atomicOr(&bits[id >> 5], 1u << (id & 31));
     }
     __syncthreads();
-    int N = tab.n_verses, local = 0;
-    for (int v = tid; v < N; v += 256) {
+    int N = tab.n_verses, per = (N + TRI_CHUNKS - 1) / TRI_CHUNKS;
+    int v0 = blockIdx.x * per, v1 = min(N, v0 + per), local = 0;
+    double *score = wk.p3 + (size_t)b * N;  // pass 3 runs later and overwrites this buffer
+    for (int v = v0 + tid; v < v1; v += 256) {
         double s = 0.0;
         bool touched = false;
         for (uint32_t p = tab.vtri_off[v]; p < tab.vtri_off[v + 1]; ++p) {
@@ -379,9 +377,30 @@ __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
         score[v] = touched ? s : -1.0;
         local += touched;
     }
-    atomicAdd(cnt, local);
+    local = wave_sum_i(local);
+    if ((tid & 63) == 0 && local) atomicAdd(&u.n_cand1, local);  // temporary: touched count
+}
+
+__global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *score = (double *)smem;                            // [N]
+    double *sh_s = (double *)(score + tab.n_verses);           // [8]
+    unsigned long long *sh_k = (unsigned long long *)(sh_s + 8);  // [8]
+    int32_t *top = (int32_t *)(sh_k + 8);                      // [64]
+    int32_t *tabA = top + 64;                                  // [256]
+    int32_t *tabB = tabA + 256;                                // [256]
+    int b = blockIdx.x, tid = threadIdx.x;
+    QvUtt &u = wk.utt[b];
+    int m = u.q_len;
+    if (m == 0) return;
+    int N = tab.n_verses;
+    int touched_total = u.n_cand1;
     __syncthreads();
-    int touched_total = *cnt;
+    if (touched_total >= 20) {
+        const double *gs = wk.p3 + (size_t)b * N;
+        for (int v = tid; v < N; v += 256) score[v] = gs[v];
+    }
+    __syncthreads();
     int32_t *cand1 = wk.cand1 + (size_t)b * N;
     if (touched_total < 20) {  // quran_db.py:285-286
         for (int v = tid; v < N; v += 256) cand1[v] = v;
@@ -454,14 +473,13 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
     else { pm = tab.pmv + tab.pmv_off[t.tid]; stride = qv_tmpl_w((n + 63) >> 6); s = n; lt = q; L = m; }
     int W = (s + 63) >> 6;
     int nwin = windows ? (L - s + 1) : 0;
-    int full = 0, best = 0;
-    // lane 0 of round 0 carries the full-string LCS, the other lanes windows
-    int total = nwin + 1;
-    for (int base = 0; base < total; base += 64) {
+    // full-string LCS comes from k_lcs_full (one text per lane); lanes here = sliding windows
+    int full = wk.lcsf[((size_t)b * tab.n_verses + v) * 3 + variant], best = 0;
+    for (int base = 0; base < nwin; base += 64) {
         int job = base + lane;
-        if (job >= total) continue;
-        if (job == 0) full = lcs_dispatch(W, pm, stride, lt, L, s);
-        else { int r = lcs_dispatch(W, pm, stride, lt + (job - 1), s, s); best = max(best, r); }
+        if (job >= nwin) continue;
+        int r = lcs_dispatch(W, pm, stride, lt + job, s, s);
+        best = max(best, r);
     }
     best = wave_max_i(best);
     if (lane == 0) {
@@ -481,6 +499,29 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
     }
 }
 
+// full-string LCS(transcript, text), one text per lane, pattern = the transcript's match masks.
+// mode 0: the texts of the pass-1 iteration list; mode 1: clean + alt of every verse for the
+// slow-list utterances (skipped when pass 1 already scanned everything).
+__global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int mode) {
+    int b;
+    if (mode == 0) b = blockIdx.y;
+    else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
+    const QvUtt &u = wk.utt[b];
+    if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
+    const int m = u.q_len, W = (m + 63) >> 6, N = tab.n_verses;
+    const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
+    const int32_t *cand1 = wk.cand1 + (size_t)b * N;
+    int16_t *out = wk.lcsf + (size_t)b * N * 3;
+    const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 2;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < jobs; j += gridDim.x * 256) {
+        int v, variant;
+        if (mode == 0) { v = cand1[j / 3]; variant = j % 3; } else { v = j >> 1; variant = j & 1; }
+        if (variant == 2 && tab.nobsm_len[v] == 0) continue;
+        TextRef t = text_of(tab, v, variant);
+        out[v * 3 + variant] = (int16_t)lcs_dispatch(W, pm, QV_MAXW, t.p, t.n, m);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode) {
     int lane = threadIdx.x & 63;
     int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
@@ -488,7 +529,7 @@ __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode)
     if (mode == 0) b = blockIdx.y;
     else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
     const QvUtt &u = wk.utt[b];
-    if (u.q_len == 0) return;
+    if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
     if (mode == 0) {
         const int32_t *cand1 = wk.cand1 + (size_t)b * tab.n_verses;
         int jobs = u.n_cand1 * 3;
@@ -651,7 +692,7 @@ __global__ __launch_bounds__(256) void k_pass3(QvTables tab, QvWork wk) {
     const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
     const uint8_t *t = tab.clean + tab.clean_off[v];
     int n = tab.clean_len[v], ns = n - (tab.nw[0][v] - 1);
-    int l1 = lcs_dispatch((m + 63) >> 6, pm, QV_MAXW, t, n, m);
+    int l1 = wk.lcsf[((size_t)b * tab.n_verses + v) * 3];  // LCS(t, clean) from k_lcs_full
     int l2 = lcs_dispatch((ms + 63) >> 6, pm + QV_NSYM * QV_MAXW, QV_MAXW, t, n, ms);
     double a = ratio_from(l1, m, n), c = ratio_from(l2, ms, ns);
     wk.p3[(size_t)b * tab.n_verses + v] = a > c ? a : c;
@@ -783,37 +824,42 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
         if (s == 0) a[k] = lp[QV_BLANK];
         if (s == 1) a[k] = lp[tok[k]];
     }
-    float cur[NS], nxt[NS];
-    if (T > 1) {
+    // the gathers lp[t][tok] do not depend on the recurrence: fetch TCH frames ahead so their
+    // L2 latency overlaps the exp/log chain instead of serialising with it
+    constexpr int TCH = NS <= 2 ? 8 : (NS <= 6 ? 4 : 2);
+    for (int t0 = 1; t0 < T; t0 += TCH) {
+        float lpv[TCH][NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) cur[k] = lp[(size_t)QV_VOCAB + tok[k]];
-    }
-    for (int t = 1; t < T; ++t) {
-        if (t + 1 < T) {
-            const float *row = lp + (size_t)(t + 1) * QV_VOCAB;
+        for (int j = 0; j < TCH; ++j) {
+            int t = t0 + j < T ? t0 + j : T - 1;
+            const float *row = lp + (size_t)t * QV_VOCAB;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) nxt[k] = row[tok[k]];
-        }
-        // previous lane's last two states
-        float p1 = __shfl_up(a[NS - 1], 1), p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1) : __shfl_up(a[NS - 1], 2);
-        if (lane == 0) { p1 = NEG; p2 = NEG; }
-        if (NS == 1 && lane == 1) p2 = NEG;
-        float na[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            int s = lane * NS + k;
-            float la1 = a[k];
-            float la2 = k >= 1 ? a[k - 1] : p1;
-            float la3 = k >= 2 ? a[k - 2] : (k == 1 ? p1 : p2);
-            if (NS == 1) la3 = p2;
-            if (!skip_ok[k]) la3 = NEG;
-            float lamax = fmaxf(la1, fmaxf(la2, la3));
-            if (lamax == NEG) lamax = 0.f;
-            float v = logf(expf(la1 - lamax) + expf(la2 - lamax) + expf(la3 - lamax)) + lamax + cur[k];
-            na[k] = s < S ? v : NEG;
+            for (int k = 0; k < NS; ++k) lpv[j][k] = row[tok[k]];
         }
 #pragma unroll
-        for (int k = 0; k < NS; ++k) { a[k] = na[k]; cur[k] = nxt[k]; }
+        for (int j = 0; j < TCH; ++j) {
+            if (t0 + j >= T) break;
+            // previous lane's last two states
+            float p1 = __shfl_up(a[NS - 1], 1), p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1) : __shfl_up(a[NS - 1], 2);
+            if (lane == 0) { p1 = NEG; p2 = NEG; }
+            if (NS == 1 && lane == 1) p2 = NEG;
+            float na[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                int s = lane * NS + k;
+                float la1 = a[k];
+                float la2 = k >= 1 ? a[k - 1] : p1;
+                float la3 = k >= 2 ? a[k - 2] : (k == 1 ? p1 : p2);
+                if (NS == 1) la3 = p2;
+                if (!skip_ok[k]) la3 = NEG;
+                float lamax = fmaxf(la1, fmaxf(la2, la3));
+                if (lamax == NEG) lamax = 0.f;
+                float v = logf(expf(la1 - lamax) + expf(la2 - lamax) + expf(la3 - lamax)) + lamax + lpv[j][k];
+                na[k] = s < S ? v : NEG;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) a[k] = na[k];
+        }
     }
     // l1 = a[S-1], l2 = a[S-2]
     float l1 = NEG, l2 = NEG;
@@ -831,17 +877,21 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
     return -ll;
 }
 
+// LONG = engine capacity above 30 s (more than 384 states per target): only then are the wide
+// instantiations compiled into the kernel, keeping the common kernel's register footprint small
+template <bool LONG>
 __device__ float ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L, int lane) {
     int S = 2 * L + 1;
     if (S <= 64) return ctc_wave<1>(lp, T, tgt, L, lane);
     if (S <= 128) return ctc_wave<2>(lp, T, tgt, L, lane);
     if (S <= 192) return ctc_wave<3>(lp, T, tgt, L, lane);
     if (S <= 256) return ctc_wave<4>(lp, T, tgt, L, lane);
-    if (S <= 384) return ctc_wave<6>(lp, T, tgt, L, lane);
+    if (S <= 384 || !LONG) return ctc_wave<6>(lp, T, tgt, L, lane);
     if (S <= 512) return ctc_wave<8>(lp, T, tgt, L, lane);
     return ctc_wave<12>(lp, T, tgt, L, lane);
 }
 
+template <bool LONG>
 __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn, const float *__restrict__ lp, int t_max) {
     if ((int)blockIdx.y >= *wk.n_fail) return;
     int b = wk.fail_list[blockIdx.y];
@@ -856,8 +906,8 @@ __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn
         int L = (int)(tab.tok_off[key + 1] - tab.tok_off[key]);
         float loss = INFINITY;
         double fin = -INFINITY;
-        if (L > 0 && 2 * L + 1 <= T && 2 * L + 1 <= 768) {  // gate of c2c-direct/run.py:332
-            loss = ctc_dispatch(lpb, T, tab.tok + tab.tok_off[key], L, lane);
+        if (L > 0 && 2 * L + 1 <= T && 2 * L + 1 <= (LONG ? 768 : 384)) {  // gate of c2c-direct/run.py:332
+            loss = ctc_dispatch<LONG>(lpb, T, tab.tok + tab.tok_off[key], L, lane);
             if (isinf(loss)) loss = 0.f;  // zero_infinity=True
             float norm = __fdiv_rn(loss, (float)L);
             // -norm + TEXT_WEIGHT*text_score - SPAN_PENALTY*(span_len-1), in Python doubles
@@ -876,7 +926,7 @@ __global__ __launch_bounds__(64) void k_ctc_debug(const float *__restrict__ lp, 
     int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n) return;
     int L = off[c + 1] - off[c];
-    float l = ctc_dispatch(lp, T, tg + off[c], L, lane);
+    float l = ctc_dispatch<true>(lp, T, tg + off[c], L, lane);
     if (lane == 0) loss[c] = l;
 }
 
@@ -953,14 +1003,17 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
     QvWork &wk = eng->work;
     QvKnobs kn = eng->knobs;
     int N = tab.n_verses;
-    size_t sm_tri = (size_t)N * 8 + TRI_WORDS * 4 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 16;
+    size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 16;
+    hipLaunchKernelGGL(k_tri_score, dim3(TRI_CHUNKS, batch), dim3(256), 0, stream, tab, wk);
     hipLaunchKernelGGL(k_trigram, dim3(batch), dim3(256), sm_tri, stream, tab, wk);
+    hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 0);
     hipLaunchKernelGGL(k_frag, dim3(64, batch), dim3(256), 0, stream, tab, wk, 0);
     size_t sm_p1 = (size_t)N * 8 + 8 * 8 + 8 * 8;
     hipLaunchKernelGGL(k_pass1_final, dim3(batch), dim3(256), sm_p1, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_base_final, dim3((batch + 63) / 64), dim3(64), 0, stream, tab, wk, kn, batch, force_ctc);
     // gate-failed utterances only (device-side list; blocks past n_fail exit at once)
+    hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 1);
     hipLaunchKernelGGL(k_frag, dim3(128, batch), dim3(256), 0, stream, tab, wk, 1);
     hipLaunchKernelGGL(k_pass3, dim3((N + 255) / 256, batch), dim3(256), 0, stream, tab, wk);
     hipLaunchKernelGGL(k_topk, dim3(batch, 2), dim3(256), sm_p1, stream, tab, wk, kn);
@@ -985,7 +1038,8 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
     hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);
     int rc = launch_retrieval(eng, batch, 0, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ctc, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+    if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+    else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
     hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
     QV_HIP(hipGetLastError());
     eng->last_batch = batch;
