@@ -1,0 +1,86 @@
+"""Audio ingest on the host side of the boundary (reference: shared/audio.py:8-18 ``load_audio``
+and experiments/c2c-direct-mixed-tta/run.py:60-71 ``_speed_perturb``).
+
+``load_audio(path, sr=16000)`` -> float32 mono at 16 kHz.  The reference leans on
+librosa/soundfile; this image has neither (and no ffmpeg), so WAV containers are parsed with the
+standard library (PCM 8/16/24/32-bit and IEEE float) and resampled with
+``scipy.signal.resample_poly``.  librosa's default resampler is soxr_hq, a different FIR design:
+for non-16 kHz sources the samples agree to resampler-design tolerance, not bit-for-bit
+(documented in DESIGN.md); 16 kHz sources (the 29 RetaSy files of the v1 corpus) are exact.
+Compressed formats (mp3/m4a) raise: there is no decoder in this environment.
+"""
+
+from __future__ import annotations
+
+import struct
+from fractions import Fraction
+from pathlib import Path
+
+import numpy as np
+
+TARGET_SR = 16000
+
+
+def _read_wav(path: Path):
+    data = path.read_bytes()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file (no decoder for compressed audio in this environment)")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8: pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:  # WAVE_FORMAT_EXTENSIBLE -> sub-format
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError(f"{path}: malformed WAV")
+    tag, ch, sr, bits = fmt
+    if tag == 3 and bits == 32:
+        x = np.frombuffer(pcm, dtype="<f4").astype(np.float32)
+    elif tag == 3 and bits == 64:
+        x = np.frombuffer(pcm, dtype="<f8").astype(np.float32)
+    elif tag == 1 and bits == 16:
+        x = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 8:
+        x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif tag == 1 and bits == 32:
+        x = np.frombuffer(pcm, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        x = v.astype(np.float32) / 8388608.0
+    else:
+        raise ValueError(f"{path}: unsupported WAV encoding tag={tag} bits={bits}")
+    if ch > 1:
+        x = x[: len(x) // ch * ch].reshape(-1, ch).mean(axis=1)
+    return x.astype(np.float32), sr
+
+
+def resample(audio: np.ndarray, orig_sr: int, target_sr: int) -> np.ndarray:
+    if orig_sr == target_sr:
+        return audio.astype(np.float32)
+    from scipy.signal import resample_poly
+
+    fr = Fraction(target_sr, orig_sr)
+    return resample_poly(audio, fr.numerator, fr.denominator).astype(np.float32)
+
+
+def load_audio(path: str, sr: int = TARGET_SR) -> np.ndarray:
+    audio, native = _read_wav(Path(path))
+    return resample(audio, native, sr)
+
+
+def speed_perturb(audio_16k: np.ndarray, factor: float) -> np.ndarray:
+    """0.9 = 10 % slower, 1.1 = 10 % faster: resample_poly(x, int(factor*10), 10), default Kaiser
+    FIR -- the same scipy call the reference's TTA wrapper makes."""
+    if factor == 1.0:
+        return audio_16k
+    from scipy.signal import resample_poly
+
+    return resample_poly(audio_16k, int(factor * 10), 10).astype("float32")

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's plugin surface for this path
+(experiments/c2c-direct-mixed/run.py and experiments/c2c-direct-mixed-tta/run.py):
+``predict(audio_path) -> dict``, ``transcribe(audio_path) -> str``, ``model_size() -> int``,
+plus the batched entry the throughput metric needs (``predict_batch``).
+
+Same dict keys (surah, ayah, ayah_end, score, transcript, source; _empty on no match), same env
+knobs (CTC_DIRECT_*, C2C_DIRECT_MIXED_PROFILE), same error behaviour (missing model ->
+FileNotFoundError; any exception propagates to the runner, which records an empty prediction).
+
+Model weights: ``QVERSE_WEIGHTS`` names the flat weight file produced by
+tools/convert_weights.py from the reference's checkpoint.  Without it ``predict`` raises
+FileNotFoundError like the reference does for a missing ONNX -- unless
+``QVERSE_RANDOM_WEIGHTS=1`` explicitly asks for the seeded synthetic weights (throughput runs).
+"""
+
+from __future__ import annotations
+
+import os
+import time
+from collections import Counter
+from pathlib import Path
+
+import numpy as np
+
+from .audio import load_audio, speed_perturb
+
+_PROFILE = os.getenv("C2C_DIRECT_MIXED_PROFILE", "") not in ("", "0", "false", "False")
+CONFIDENCE_SKIP_THRESHOLD = 0.5  # c2c-direct-mixed-tta/run.py:57
+MAX_SAMPLES = int(os.getenv("QVERSE_MAX_SAMPLES", str(16000 * 60)))
+MAX_BATCH = int(os.getenv("QVERSE_MAX_BATCH", "16"))
+
+_engine = None
+
+
+def weights_path() -> Path | None:
+    p = os.getenv("QVERSE_WEIGHTS")
+    return Path(p) if p else None
+
+
+def _ensure_engine():
+    global _engine
+    if _engine is not None:
+        return _engine
+    from .engine import Engine
+
+    wp = weights_path()
+    if wp is None and os.getenv("QVERSE_RANDOM_WEIGHTS", "") not in ("1", "true", "True"):
+        raise FileNotFoundError(
+            "No model weights: set QVERSE_WEIGHTS to the flat file written by tools/convert_weights.py "
+            "(from fastconformer_full_mixed.onnx / the .nemo checkpoint), or QVERSE_RANDOM_WEIGHTS=1 for "
+            "seeded synthetic weights.")
+    if wp is not None and not wp.exists():
+        raise FileNotFoundError(f"No weight file at {wp}. Run `python tools/convert_weights.py` first.")
+    device = int(os.getenv("LOCAL_RANK", "0"))
+    print(f"[c2c-direct-mixed/qverse] loading {'synthetic weights' if wp is None else wp.name} on cuda:{device}...")
+    _engine = Engine(device=device, with_model=True, weights_path=str(wp) if wp else None,
+                     max_batch=MAX_BATCH, max_samples=MAX_SAMPLES)
+    return _engine
+
+
+def _empty(transcript: str = "") -> dict:
+    return {"surah": 0, "ayah": 0, "ayah_end": None, "score": 0.0, "transcript": transcript, "candidates": []}
+
+
+def _to_dict(r: dict, round_score: bool) -> dict:
+    if not r["surah"]:
+        return _empty(r.get("transcript", ""))
+    score = r["score"]
+    return {
+        "surah": r["surah"], "ayah": r["ayah"], "ayah_end": r["ayah_end"] or r["ayah"],
+        "score": round(score, 4) if round_score else score,
+        "transcript": r.get("transcript", ""), "source": r["source"],
+    }
+
+
+def predict_arrays(arrays, round_score: bool = True) -> list[dict]:
+    """audio arrays (float32, 16 kHz) -> predict()-shaped dicts, one engine call per <= MAX_BATCH."""
+    import torch
+
+    eng = _ensure_engine()
+    out = []
+    for s in range(0, len(arrays), eng.max_batch):
+        chunk = arrays[s: s + eng.max_batch]
+        lens = [len(a) for a in chunk]
+        buf = np.zeros((len(chunk), max(lens)), dtype=np.float32)
+        for i, a in enumerate(chunk):
+            buf[i, : len(a)] = a
+        dev = torch.from_numpy(buf).cuda(eng.device)
+        out.extend(_to_dict(r, round_score) for r in eng.predict_batch(dev, lens))
+    return out
+
+
+def predict_batch(audio_paths) -> list[dict]:
+    return predict_arrays([load_audio(p) for p in audio_paths])
+
+
+def predict(audio_path: str) -> dict:
+    t0 = time.perf_counter()
+    audio = load_audio(audio_path)
+    t1 = time.perf_counter()
+    res = predict_arrays([audio])[0]
+    if _PROFILE:
+        t2 = time.perf_counter()
+        print(f"[c2c-direct-mixed profile] audio={Path(audio_path).name} load={t1 - t0:.3f}s "
+              f"device={t2 - t1:.3f}s total={t2 - t0:.3f}s source={res.get('source')}")
+    return res
+
+
+def transcribe(audio_path: str) -> str:
+    import torch
+
+    eng = _ensure_engine()
+    audio = load_audio(audio_path)
+    dev = torch.from_numpy(audio[None, :]).cuda(eng.device)
+    lp, T = eng.forward(dev, [len(audio)])
+    ids = lp[0, : T[0]].argmax(-1).cpu().numpy().tolist()
+    dedup, prev = [], -1
+    for i in ids:
+        if i != prev and i != 1024:
+            dedup.append(i)
+        prev = i
+    return eng.transcript_of(dedup)
+
+
+def model_size() -> int:
+    wp = weights_path()
+    return wp.stat().st_size if wp is not None and wp.exists() else 0
+
+
+# ------------------------------------------------------------------ TTA variant --------
+def predict_tta(audio_path: str) -> dict:
+    """c2c-direct-mixed-tta/run.py:117-149: anchor pass, gate 0.5, 0.9x / 1.1x passes (batched
+    into ONE engine call instead of two threads on one session), majority else score pick."""
+    audio = load_audio(audio_path)
+    anchor = predict_arrays([audio], round_score=False)[0]
+    if anchor["score"] >= CONFIDENCE_SKIP_THRESHOLD:
+        return anchor
+    p09, p11 = predict_arrays([speed_perturb(audio, 0.9), speed_perturb(audio, 1.1)], round_score=False)
+    preds = [p09, anchor, p11]
+    keys = [(p["surah"], p["ayah"]) for p in preds]
+    top, n = Counter(keys).most_common(1)[0]
+    if n >= 2:
+        for p in preds:
+            if (p["surah"], p["ayah"]) == top:
+                p["tta"] = "majority"
+                p["tta_preds"] = keys
+                return p
+    best = max(preds, key=lambda p: p["score"])
+    best["tta"] = "score_pick"
+    best["tta_preds"] = keys
+    best["tta_scores"] = [p["score"] for p in preds]
+    return best

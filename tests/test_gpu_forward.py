@@ -117,3 +117,71 @@ def test_rejects_out_of_capacity(setup):
         eng.forward(torch.zeros(1, 90000, device="cuda"), [90000])
     with pytest.raises(QvError):
         eng.forward(torch.zeros(5, 16000, device="cuda"), [16000] * 5)
+
+
+def test_weight_file_path_equals_seeded_init(setup, tmp_path):
+    """tools/convert_weights.py --random S writes the same tensors the engine's seeded init
+    generates: loading the file must give bit-identical log-probs."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    from offline_tarteel_amd.engine import Engine
+
+    root = Path(__file__).resolve().parent.parent
+    out = tmp_path / "w.qvw"
+    subprocess.run([sys.executable, str(root / "tools" / "convert_weights.py"), "--random", str(SEED), "--out", str(out)],
+                   check=True)
+    eng2 = Engine(device=0, with_model=True, weights_path=str(out), max_batch=4, max_samples=80000)
+    lp2, t2 = eng2.forward(setup["audio"].cuda().contiguous(), LENS)
+    torch.cuda.synchronize()
+    assert t2 == setup["t"]
+    for i, n in enumerate(t2):
+        assert torch.equal(lp2[i, :n], setup["lp"][i, :n])
+    eng2.close()
+    with pytest.raises(FileNotFoundError):
+        Engine(device=0, with_model=True, weights_path=str(tmp_path / "missing.qvw"))
+
+
+def test_plugin_and_runner_on_synthetic_corpus(tmp_path, monkeypatch):
+    """the drop-in surface end to end: runner CLI -> experiments/c2c-direct-mixed/run.py ->
+    C ABI, on a tiny WAV corpus with seeded synthetic weights."""
+    import json
+    import struct
+
+    import numpy as np
+
+    from offline_tarteel_amd import plugin
+    from offline_tarteel_amd.benchmark import runner
+
+    corpus = tmp_path / "corpus"
+    corpus.mkdir()
+    samples = []
+    for i, n in enumerate((24000, 36000, 30000)):
+        pcm = (synth_audio(1, n, seed=50 + i)[0] * 20000).astype("<i2")
+        data = pcm.tobytes()
+        hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack(
+            "<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" + struct.pack("<I", len(data))
+        (corpus / f"s{i}.wav").write_bytes(hdr + data)
+        samples.append({"id": f"s{i}", "file": f"s{i}.wav", "surah": 1, "ayah": 1, "category": "short"})
+    (corpus / "manifest.json").write_text(json.dumps({"samples": samples}))
+    monkeypatch.setenv("QVERSE_RANDOM_WEIGHTS", "1")
+    monkeypatch.setenv("QVERSE_MAX_SAMPLES", "64000")
+    monkeypatch.setenv("QVERSE_MAX_BATCH", "4")
+    monkeypatch.setattr(plugin, "_engine", None)
+    monkeypatch.setattr(plugin, "MAX_SAMPLES", 64000)
+    monkeypatch.setattr(plugin, "MAX_BATCH", 4)
+    exp = runner.discover_experiments("c2c-direct-mixed")[0]
+    one = runner.run_experiment(exp, samples, corpus, batch=1)
+    many = runner.run_experiment(exp, samples, corpus, batch=3)
+    assert one["total"] == many["total"] == 3
+    for a, b in zip(one["per_sample"], many["per_sample"]):
+        assert a["predicted"] == b["predicted"]   # batch composition does not change answers
+        assert a["latency"] > 0
+    r = plugin.predict(str(corpus / "s0.wav"))
+    assert set(r) >= {"surah", "ayah", "ayah_end", "score", "transcript"}
+    assert isinstance(plugin.transcribe(str(corpus / "s0.wav")), str)
+    tta = runner.run_experiment(runner.discover_experiments("c2c-direct-mixed-tta")[0], samples, corpus)
+    assert tta["total"] == 3
+    plugin._engine.close()
+    monkeypatch.setattr(plugin, "_engine", None)

@@ -1,0 +1,139 @@
+"""CPU tests of the host-side mirror: runner scoring, emissions, plugin surface, audio ingest,
+data-parallel sharding + all-gather over gloo (world size 2)."""
+
+import json
+import os
+import struct
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_runner_scoring_matches_reference_known_answers(golden_dir):
+    from offline_tarteel_amd.benchmark.runner import predict_to_emissions, score_sequence
+
+    sc = json.loads((golden_dir / "scoring_cases.json").read_text(encoding="utf-8"))
+    for c in sc["score_sequence"]:
+        assert score_sequence(c["expected"], c["predicted"]) == c["out"]
+    for c in sc["emissions"]:
+        assert predict_to_emissions(c["in"]) == c["out"]
+
+
+def test_plugins_load_by_path_and_expose_contract():
+    from offline_tarteel_amd.benchmark.runner import EXPERIMENT_REGISTRY, load_module
+
+    for name, path in EXPERIMENT_REGISTRY.items():
+        mod = load_module(name.replace("-", "_"), path)
+        for fn in ("predict", "transcribe", "model_size"):
+            assert callable(getattr(mod, fn)), (name, fn)
+        assert mod.model_size() == 0  # no weight file configured
+
+
+def test_missing_model_is_file_not_found(monkeypatch, tmp_path):
+    from offline_tarteel_amd import plugin
+
+    monkeypatch.delenv("QVERSE_WEIGHTS", raising=False)
+    monkeypatch.delenv("QVERSE_RANDOM_WEIGHTS", raising=False)
+    monkeypatch.setattr(plugin, "_engine", None)
+    wav = tmp_path / "a.wav"
+    _write_wav(wav, np.zeros(1600, np.int16), 16000)
+    with pytest.raises(FileNotFoundError):
+        plugin.predict(str(wav))
+
+
+def test_runner_records_empty_prediction_on_plugin_error(tmp_path, monkeypatch):
+    """missing audio -> skipped; exception in predict -> empty emissions, latency 0.0."""
+    from offline_tarteel_amd.benchmark import runner
+
+    corpus = tmp_path / "corpus"
+    corpus.mkdir()
+    _write_wav(corpus / "x.wav", np.zeros(3200, np.int16), 16000)
+    (corpus / "manifest.json").write_text(json.dumps({"samples": [
+        {"id": "present", "file": "x.wav", "surah": 1, "ayah": 1, "category": "short"},
+        {"id": "absent", "file": "nope.wav", "surah": 1, "ayah": 2, "category": "short"}]}))
+    monkeypatch.delenv("QVERSE_WEIGHTS", raising=False)
+    monkeypatch.delenv("QVERSE_RANDOM_WEIGHTS", raising=False)
+    exp = runner.discover_experiments("c2c-direct-mixed")[0]
+    res = runner.run_experiment(exp, runner.load_manifest(corpus), corpus)
+    assert res["total"] == 1 and res["per_sample"][0]["id"] == "present"
+    assert res["per_sample"][0]["predicted"] == [] and res["per_sample"][0]["latency"] == 0.0
+    assert res["recall"] == 0.0
+    p = runner.save_results([res], results_dir=tmp_path / "results")
+    latest = json.loads((tmp_path / "results" / "latest.json").read_text())
+    assert latest[0]["name"] == "c2c-direct-mixed" and latest[0]["source_file"] == p.name
+
+
+def _write_wav(path, pcm16, sr, channels=1):
+    data = pcm16.astype("<i2").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack(
+        "<IHHIIHH", 16, 1, channels, sr, sr * 2 * channels, 2 * channels, 16) + b"data" + struct.pack("<I", len(data))
+    Path(path).write_bytes(hdr + data)
+
+
+def test_load_audio_wav_mono_and_resample(tmp_path):
+    from offline_tarteel_amd.audio import load_audio, speed_perturb
+
+    t = np.arange(16000) / 16000.0
+    x = (np.sin(2 * np.pi * 440 * t) * 12000).astype(np.int16)
+    _write_wav(tmp_path / "m.wav", x, 16000)
+    a = load_audio(str(tmp_path / "m.wav"))
+    assert a.dtype == np.float32 and len(a) == 16000 and np.allclose(a, x / 32768.0)
+    st = np.stack([x, -x], axis=1).reshape(-1)
+    _write_wav(tmp_path / "s.wav", st, 44100, channels=2)
+    b = load_audio(str(tmp_path / "s.wav"))
+    assert abs(len(b) - round(16000 * 16000 / 44100)) <= 1 and np.abs(b).max() < 1e-3  # L/R cancel
+    from scipy.signal import resample_poly
+
+    assert np.array_equal(speed_perturb(a, 0.9), resample_poly(a, 9, 10).astype("float32"))
+    assert speed_perturb(a, 1.0) is a
+    with pytest.raises(ValueError):
+        (tmp_path / "c.mp3").write_bytes(b"ID3\x00" * 8)
+        load_audio(str(tmp_path / "c.mp3"))
+
+
+def test_shard_plan_covers_batch_once():
+    from offline_tarteel_amd.dist import shard_plan
+
+    lens = [5, 30, 12, 7, 22, 9, 18]
+    order, slices = shard_plan(lens, 4)
+    assert sorted(i for i in order if i >= 0) == list(range(7)) and len(order) == 8
+    assert [order[s].tolist() for s in slices][0][0] == 1  # longest first
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import offline_tarteel_amd
+from offline_tarteel_amd.dist import shard_plan, pack_results, all_gather_results, unpack_results
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lens = [100, 400, 250, 50, 320]
+order, slices = shard_plan(lens, world)
+mine = order[slices[rank]]
+# stand-in for the engine: every utterance "predicts" (surah=idx+1, ayah=len%7+1)
+res = [{"surah": (int(i) + 1 if i >= 0 else 0), "ayah": (lens[i] % 7 + 1 if i >= 0 else 0), "ayah_end": None,
+        "score": (lens[i] / 1000.0 if i >= 0 else 0.0)} for i in mine]
+full = all_gather_results(torch.from_numpy(pack_results(res)), order, len(lens))
+got = unpack_results(full)
+assert [g["surah"] for g in got] == [1, 2, 3, 4, 5], got
+assert all(abs(g["score"] - l / 1000.0) < 1e-6 for g, l in zip(got, lens))
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_all_gather_results_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script), str(ROOT)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
