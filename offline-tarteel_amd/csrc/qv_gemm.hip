@@ -1,4 +1,10 @@
 // qv_gemm.hip -- fused-epilogue f16 GEMM on v_mfma_f32_32x32x16_f16 (see qv_kernels.h).
+//
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias).  128 x BN x 64 tiles, 4 waves (2 x 2), two LDS
+// stages filled by direct global->LDS loads.  The epilogue goes back through LDS so that every
+// global store is a full 16-byte lane-contiguous row segment (a wave writes 4 whole tile rows per
+// instruction); storing straight from the MFMA accumulator layout (one row per lane) cost more
+// time than the whole K loop.
 
 #include "qv_kernels.h"
 
@@ -16,7 +22,9 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+constexpr bool epi_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; }
 
 }  // namespace
 
@@ -26,9 +34,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     constexpr int WN = BN / 2;   // columns per wave
     constexpr int NF = WN / 32;  // 32-wide B fragments per wave
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int NST = 2;                       // LDS stages (64 KB: two blocks fit a CU; deeper prefetch at one block/CU measured slower)
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int G = 4 + BN / 32;               // direct loads per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half_t *sA0 = (half_t *)smem, *sA1 = (half_t *)(smem + A_BYTES);
-    half_t *sB0 = (half_t *)(smem + 2 * A_BYTES), *sB1 = (half_t *)(smem + 2 * A_BYTES + B_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -50,13 +59,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // LDS tile rows are 128 B (64 halves); the 16-B chunk index is XORed with (row >> 1) & 7 --
+    // on the global SOURCE address (the direct load writes LDS lane-linearly) and on the fragment
+    // read -- which spreads each ds_read_b128 lane group over all 16 slots of the 256-B bank row.
     const int nk = g.K / BK;
-    auto stage = [&](int kt, half_t *sA, half_t *sB) {
+    auto stage = [&](int kt) {
+        half_t *sA = (half_t *)(smem + (kt % NST) * STAGE_BYTES), *sB = (half_t *)((unsigned char *)sA + A_BYTES);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int chunk = wave * 4 + q;
             int row = chunk * 8 + (lane >> 3);
-            int c = (lane & 7) ^ (row & 7);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
             int grow = m0 + row;
             grow = grow < g.M ? grow : g.M - 1;
             glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
@@ -65,16 +78,27 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int q = 0; q < BN / 32; ++q) {
             int chunk = wave * (BN / 32) + q;
             int row = chunk * 8 + (lane >> 3);
-            int c = (lane & 7) ^ (row & 7);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
             glds16(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8, sB + chunk * 512);
         }
     };
 
-    stage(0, sA0, sB0);
-    __syncthreads();
+    // Software pipeline with counted waits: a wave waits only for ITS OWN loads of tile kt
+    // (vmcnt = loads issued after them), then one raw s_barrier makes every wave's part of the
+    // tile visible and retires the buffer that the next prefetch overwrites.  __syncthreads()
+    // would drain the whole queue (vmcnt(0)) and serialise load latency with the MFMAs.
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s);
     for (int kt = 0; kt < nk; ++kt) {
-        half_t *sA = (kt & 1) ? sA1 : sA0, *sB = (kt & 1) ? sB1 : sB0;
-        if (kt + 1 < nk) stage(kt + 1, (kt & 1) ? sA0 : sA1, (kt & 1) ? sB0 : sB1);
+        const int ahead = min(nk - 1 - kt, NST - 2);  // tiles issued after tile kt
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nk) stage(kt + NST - 1);
+        const half_t *sA = (const half_t *)(smem + (kt % NST) * STAGE_BYTES);
+        const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             half8 a[2], b[NF];
@@ -82,91 +106,141 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int row = wm * 64 + i * 32 + (lane & 31);
-                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ (row & 7)) << 3));
+                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
             }
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 int row = wn * WN + j * 32 + (lane & 31);
-                b[j] = *(const half8 *)(sB + row * 64 + ((c ^ (row & 7)) << 3));
+                b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
-                    // operands swapped (D^T = W A^T): a lane then holds 4 CONSECUTIVE output
-                    // columns per register quad, so the epilogue stores 8/16 bytes at a time
+                    // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per
+                    // register quad -> 8/16-byte LDS writes in the epilogue
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();  // every wave is done with the operand stages before the epilogue reuses them
 
     // ------------------------------------------------------------------ epilogue ----------
-    // accumulator (i, j), register r: row m = m0 + wm*64 + i*32 + (lane & 31),
-    //   column n = n0 + wn*WN + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+    // accumulator (i, j), register r: tile row  = wm*64 + i*32 + (lane & 31),
+    //   tile column = wn*WN + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
     const int l31 = lane & 31, hi = lane >> 5;
+
+    if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
+        // V tile: transposed store Vt[b][h*64+d][t] straight from registers (32 lanes = 32
+        // consecutive frames = 64 contiguous bytes)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m0 + wm * 64 + i * 32 + l31;
-        if (row >= g.M) continue;
-        if (EPI == EPI_GLU) {
-            // W rows interleaved in 32-channel groups: [value(32) | gate(32)] per 64 columns
-            const int nb = n0 + wn * WN;
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wm * 64 + i * 32 + l31;
+            if (row >= g.M) continue;
+            int b = row / g.t_max, t = row - b * g.t_max;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int nl = 8 * q + 4 * hi;
-                f32x4 ba = *(const f32x4 *)(g.bias + nb + nl), bg = *(const f32x4 *)(g.bias + nb + 32 + nl);
-                half4 o;
+            for (int j = 0; j < NF; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float av = acc[i][0][q * 4 + e] + ba[e], gv = acc[i][NF - 1][q * 4 + e] + bg[e];
-                    o[e] = (half_t)(av * sigmoidf_(gv));
-                }
-                *(half4 *)((half_t *)g.out + (size_t)row * g.ldo + (nb >> 1) + nl) = o;
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = n0 + wn * WN + j * 32 + 8 * q + 4 * hi;
-                f32x4 v;
-                if (g.bias) {
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + wn * WN + j * 32 + 8 * q + 4 * hi;
                     f32x4 bb = *(const f32x4 *)(g.bias + col);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] + bb[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-                }
-                if (EPI == EPI_RESID) {
-                    f32x4 *o = (f32x4 *)((float *)g.out + (size_t)row * g.ldo + col);
-                    f32x4 old = *o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) old[e] += g.alpha * v[e];
-                    *o = old;
-                } else if (EPI == EPI_F32) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= g.alpha;
-                    *(f32x4 *)((float *)g.out + (size_t)row * g.ldo + col) = v;
-                } else if (EPI == EPI_QKV && col >= 2 * QV_D) {
-                    // V: transposed store Vt[b][h*64+d][t]; 32 lanes = 32 consecutive t
-                    int b = row / g.t_max, t = row - b * g.t_max;
-#pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        ((half_t *)g.out2)[((size_t)b * QV_D + (col - 2 * QV_D + e)) * g.t_pad + t] = (half_t)v[e];
-                } else {
+                        ((half_t *)g.out2)[((size_t)b * QV_D + (col - 2 * QV_D + e)) * g.t_pad + t] =
+                            (half_t)(acc[i][j][q * 4 + e] + bb[e]);
+                }
+        }
+        return;
+    }
+
+    if (epi_is_f32(EPI)) {
+        constexpr int LDT = BN + 4;  // floats per staged row (pad keeps 16-B alignment)
+        float *sO = (float *)smem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = wm * 64 + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
+                    f32x4 v;
+                    if (g.bias) {
+                        f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = g.alpha * (acc[i][j][q * 4 + e] + bb[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = g.alpha * acc[i][j][q * 4 + e];
+                    }
+                    *(f32x4 *)(sO + rl * LDT + cl) = v;
+                }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 4;  // 16-byte chunks per row
+        for (int idx = tid; idx < BM * CPR; idx += 256) {
+            int r = idx / CPR, c = (idx % CPR) * 4;
+            if (m0 + r >= g.M) continue;
+            f32x4 v = *(const f32x4 *)(sO + r * LDT + c);
+            f32x4 *o = (f32x4 *)((float *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c);
+            if (EPI == EPI_RESID) {
+                f32x4 old = *o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            *o = v;
+        }
+        return;
+    }
+
+    {
+        constexpr int BNO = EPI == EPI_GLU ? BN / 2 : BN;  // output tile width
+        constexpr int LDT = BNO + 8;                        // halves per staged row
+        half_t *sO = (half_t *)smem;
+        const int n0o = EPI == EPI_GLU ? n0 / 2 : n0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = wm * 64 + i * 32 + l31;
+            if (EPI == EPI_GLU) {
+                // W rows interleaved in 32-channel groups: [value(32) | gate(32)] per 64 columns
+                const int nb = n0 + wn * WN;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int nl = 8 * q + 4 * hi;
+                    f32x4 ba = *(const f32x4 *)(g.bias + nb + nl), bg = *(const f32x4 *)(g.bias + nb + 32 + nl);
                     half4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = v[e];
+                        float av = acc[i][0][q * 4 + e] + ba[e], gv = acc[i][NF - 1][q * 4 + e] + bg[e];
+                        o[e] = (half_t)(av * sigmoidf_(gv));
+                    }
+                    *(half4 *)(sO + rl * LDT + wn * (WN / 2) + nl) = o;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
+                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                    if (g.bias) bb = *(const f32x4 *)(g.bias + n0 + cl);
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][q * 4 + e] + bb[e];
                         if (EPI == EPI_F16_SWISH) x = x * sigmoidf_(x);
                         if (EPI == EPI_F16_RELU) x = x > 0.f ? x : 0.f;
                         o[e] = (half_t)x;
                     }
-                    *(half4 *)((half_t *)g.out + (size_t)row * g.ldo + col) = o;
+                    *(half4 *)(sO + rl * LDT + cl) = o;
                 }
-            }
+        }
+        __syncthreads();
+        constexpr int CPR = BNO / 8;  // 16-byte chunks per row
+        for (int idx = tid; idx < BM * CPR; idx += 256) {
+            int r = idx / CPR, c = (idx % CPR) * 8;
+            if (m0 + r >= g.M) continue;
+            *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0o + c) = *(const half8 *)(sO + r * LDT + c);
         }
     }
 }
@@ -174,7 +248,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 template <int EPI, int BN>
 static void launch_one(const GemmArgs &g, hipStream_t s) {
     dim3 grid(g.N / BN, (g.M + 127) / 128);
-    size_t lds = 2 * (128 * 64 * 2) + 2 * (BN * 64 * 2);
+    size_t lds = 2 * ((128 * 64 * 2) + (BN * 64 * 2));
+    size_t epi = epi_is_f32(EPI) ? (size_t)128 * (BN + 4) * 4 : (size_t)128 * (BN + 8) * 2;
+    if (epi > lds) lds = epi;
     hipLaunchKernelGGL((k_gemm<EPI, BN>), grid, dim3(256), lds, s, g);
 }
 
@@ -185,13 +261,11 @@ struct GemmProf {
     std::vector<hipEvent_t> ev;   // pairs
     std::vector<int> cls;
     std::vector<double> flops;
-    size_t used = 0;
 } g_prof;
 }  // namespace
 
 void qv_gemm_prof_enable(bool on) {
     g_prof.on = on;
-    g_prof.used = 0;
     g_prof.cls.clear();
     g_prof.flops.clear();
 }
@@ -206,12 +280,28 @@ void qv_gemm_prof_collect(double *ms, double *flops, int *n) {
         flops[g_prof.cls[i]] += g_prof.flops[i];
         n[g_prof.cls[i]] += 1;
     }
-    g_prof.used = 0;
     g_prof.cls.clear();
     g_prof.flops.clear();
 }
 
-static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow);
+static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow) {
+    switch (epi) {
+#define CASE(E)                                                   \
+    case E:                                                       \
+        if (narrow) launch_one<E, 64>(g, s);                      \
+        else launch_one<E, 128>(g, s);                            \
+        break;
+        CASE(EPI_F16)
+        CASE(EPI_F16_SWISH)
+        CASE(EPI_F16_RELU)
+        CASE(EPI_RESID)
+        CASE(EPI_F32)
+        CASE(EPI_QKV)
+#undef CASE
+        case EPI_GLU: launch_one<EPI_GLU, 128>(g, s); break;
+        default: abort();
+    }
+}
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     if (g.K % 64 != 0 || g.N % 64 != 0) {
@@ -232,23 +322,4 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     (void)hipEventRecord(g_prof.ev[2 * i + 1], s);
     g_prof.cls.push_back(epi * 2 + (narrow ? 0 : 1));
     g_prof.flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
-}
-
-static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow) {
-    switch (epi) {
-#define CASE(E)                                                   \
-    case E:                                                       \
-        if (narrow) launch_one<E, 64>(g, s);                      \
-        else launch_one<E, 128>(g, s);                            \
-        break;
-        CASE(EPI_F16)
-        CASE(EPI_F16_SWISH)
-        CASE(EPI_F16_RELU)
-        CASE(EPI_RESID)
-        CASE(EPI_F32)
-        CASE(EPI_QKV)
-#undef CASE
-        case EPI_GLU: launch_one<EPI_GLU, 128>(g, s); break;
-        default: abort();
-    }
 }
