@@ -74,6 +74,18 @@ __device__ __forceinline__ void block_best(double &s, unsigned long long &k, dou
         if (better(sh_s[i], sh_k[i], s, k)) { s = sh_s[i]; k = sh_k[i]; }
 }
 
+// best non-negative entry among the positions p = tid, tid + 256, ... that this thread owns.
+// Top-k selection keeps each thread's best cached: after a round only the owner of the winner
+// rescans its ~25 entries, so a round costs one block reduction instead of a full scan.
+__device__ __forceinline__ void local_best(const double *sc, int n, int tid, double &s, unsigned long long &k) {
+    s = -1.0;
+    k = ~0ull;
+    for (int p = tid; p < n; p += 256) {
+        double x = sc[p];
+        if (x >= 0.0 && better(x, (unsigned long long)p, s, k)) { s = x; k = p; }
+    }
+}
+
 // ------------------------------------------------------------------ bit-parallel LCS ---
 // Hyyro/Crochemore: V all ones; per text char U = V & M; V = (V + U) | (V & ~M).
 // pm: match masks [sym][stride] (u64), W words used; text codes >= QV_NSYM match nothing.
@@ -408,15 +420,16 @@ __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
         return;
     }
     int K = touched_total < 50 ? touched_total : 50;
-    for (int r = 0; r < K; ++r) {
-        double s = -1.0;
-        unsigned long long k = ~0ull;
-        for (int v = tid; v < N; v += 256) {
-            double x = score[v];
-            if (x >= 0.0 && better(x, (unsigned long long)v, s, k)) { s = x; k = v; }
+    {
+        double ls; unsigned long long lk;
+        local_best(score, N, tid, ls, lk);
+        for (int r = 0; r < K; ++r) {
+            double s = ls;
+            unsigned long long k = lk;
+            block_best(s, k, sh_s, sh_k);
+            if (tid == 0) top[r] = (int32_t)k;
+            if ((int)(k & 255) == tid) { score[k] = -2.0; local_best(score, N, tid, ls, lk); }
         }
-        block_best(s, k, sh_s, sh_k);
-        if (tid == 0) { top[r] = (int32_t)k; score[k] = -2.0; }
         __syncthreads();
     }
     if (tid == 0) {
@@ -569,17 +582,14 @@ __global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, Qv
     int rounds = K > K20 ? K : K20;
     int32_t *ridx = wk.runner_idx + (size_t)b * QV_RUNNER_CAP;
     double *rsc = wk.runner_score + (size_t)b * QV_RUNNER_CAP;
+    double ls; unsigned long long lk;
+    local_best(sc, n, tid, ls, lk);
     for (int r = 0; r < rounds; ++r) {
-        double s = -1.0;
-        unsigned long long k = ~0ull;
-        for (int p = tid; p < n; p += 256) {
-            double x = sc[p];
-            if (x >= 0.0 && better(x, (unsigned long long)p, s, k)) { s = x; k = p; }
-        }
+        double s = ls;
+        unsigned long long k = lk;
         block_best(s, k, sh_s, sh_k);
         if (tid == 0) {
             int v = cand1[k];
-            sc[k] = -2.0;
             if (r < QV_RUNNER_CAP) { ridx[r] = v; rsc[r] = s; }
             if (r == 0) { u.best1_idx = v; u.best1_score = s; }
             if (r < K20) {
@@ -589,7 +599,7 @@ __global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, Qv
                 if (!seen) u.surah20[u.n_surah20++] = su;
             }
         }
-        __syncthreads();
+        if ((int)(k & 255) == tid) { sc[k] = -2.0; local_best(sc, n, tid, ls, lk); }
     }
     if (tid == 0) u.n_runners = K < kn.top_text ? K : kn.top_text;
 }
@@ -720,23 +730,20 @@ __global__ __launch_bounds__(256) void k_topk(QvTables tab, QvWork wk, QvKnobs k
     if (K > N) K = N;
     int32_t *oi = (which == 0 ? wk.top_search : wk.top_p3) + (size_t)b * QV_RUNNER_CAP;
     double *os = (which == 0 ? wk.top_search_sc : wk.top_p3_sc) + (size_t)b * QV_RUNNER_CAP;
+    double ls; unsigned long long lk;
+    local_best(sc, N, tid, ls, lk);
     for (int r = 0; r < K; ++r) {
-        double s = -1.0;
-        unsigned long long k = ~0ull;
-        for (int v = tid; v < N; v += 256) {
-            double x = sc[v];
-            if (x >= 0.0 && better(x, (unsigned long long)v, s, k)) { s = x; k = v; }
-        }
+        double s = ls;
+        unsigned long long k = lk;
         block_best(s, k, sh_s, sh_k);
-        if (tid == 0) { oi[r] = (int32_t)k; os[r] = s; sc[k] = -2.0; }
-        __syncthreads();
+        if (tid == 0) { oi[r] = (int32_t)k; os[r] = s; }
+        if ((int)(k & 255) == tid) { sc[k] = -2.0; local_best(sc, N, tid, ls, lk); }
     }
 }
 
 // ------------------------------------------------------------------ 8. candidates ------
 // c2c-direct/run.py:251-311: ordered, de-duplicated union + span expansion of the first
-// top_span_refs single refs.  Sequential by construction (order defines CTC tie-breaks);
-// one lane per gate-failed utterance does ~2k bitmap inserts.
+// top_span_refs single refs.  The order defines CTC tie-breaks and must be reproduced.
 __device__ __forceinline__ double py_round3(double x) {
     // round(x, 3) for x in [0, 1]: nearest k/1000 (ties cannot occur for non-representable
     // thousandths; exact halves x = (2k+1)/2000 are not binary fractions), then k/1000.0
@@ -748,57 +755,131 @@ __device__ __forceinline__ double py_round3(double x) {
     return __ddiv_rn(k, 1000.0);
 }
 
-__global__ __launch_bounds__(64) void k_candidates(QvTables tab, QvWork wk, QvKnobs kn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char seen[];  // [N] bit per span
+#define CAND_PCAP 3072   // proposals before de-duplication: 1 + 3*127 + 128*20 worst case
+#define CAND_HT 4096     // open-addressing table (key -> first proposal index)
+
+// Parallel form of the ordered, de-duplicated union: (1) lay out every proposal in reference
+// order, (2) a hash table keeps the FIRST proposal index of each (start, span) key, (3) an
+// ordered compaction of the proposals that are their key's first occurrence.
+__global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvKnobs kn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *pscore = (double *)smem;                       // [CAND_PCAP]
+    uint32_t *pkey = (uint32_t *)(pscore + CAND_PCAP);     // [CAND_PCAP]
+    uint32_t *htk = pkey + CAND_PCAP;                      // [CAND_HT]
+    uint32_t *hti = htk + CAND_HT;                         // [CAND_HT]
+    int32_t *refs = (int32_t *)(hti + CAND_HT);            // [128]
+    int32_t *roff = refs + 128;                            // [129]
+    int32_t *wsum = roff + 132;                            // [8]
     if ((int)blockIdx.x >= *wk.n_fail) return;
-    int b = wk.fail_list[blockIdx.x], lane = threadIdx.x;
+    const int b = wk.fail_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QvUtt &u = wk.utt[b];
-    int N = tab.n_verses;
-    for (int i = lane; i < N; i += 64) seen[i] = 0;
-    __syncthreads();
-    if (lane != 0 || u.q_len == 0) return;
-    int32_t *cs = wk.cand_start + (size_t)b * QV_CAND_CAP;
-    int32_t *cp = wk.cand_span + (size_t)b * QV_CAND_CAP;
-    double *csc = wk.cand_score + (size_t)b * QV_CAND_CAP;
-    int n = 0, nrefs = 0;
-    int32_t refs[128];
-    bool overflow = false;
-    auto add = [&](int st, int sp, double scv) {
-        unsigned char bit = (unsigned char)(1u << (sp - 1));
-        if (seen[st] & bit) return;
-        seen[st] |= bit;
-        if (n >= QV_CAND_CAP) { overflow = true; return; }
-        cs[n] = st; cp[n] = sp; csc[n] = scv; ++n;
-    };
-    auto ref = [&](int v) { if (nrefs < kn.top_span_refs && nrefs < 128) refs[nrefs++] = v; };
-    if (u.base_start >= 0) {
-        add(u.base_start, u.base_span, u.base_score);
-        ref(u.base_start);
-        const int32_t *ri = wk.runner_idx + (size_t)b * QV_RUNNER_CAP;
-        const double *rs = wk.runner_score + (size_t)b * QV_RUNNER_CAP;
-        for (int i = 0; i < u.n_runners; ++i) { add(ri[i], 1, py_round3(rs[i])); ref(ri[i]); }
-    }
+    if (u.q_len == 0) return;
+    const int N = tab.n_verses;
     int K = kn.top_text < QV_RUNNER_CAP ? kn.top_text : QV_RUNNER_CAP;
     if (K > N) K = N;
-    const int32_t *ti = wk.top_search + (size_t)b * QV_RUNNER_CAP;
-    const double *ts = wk.top_search_sc + (size_t)b * QV_RUNNER_CAP;
-    for (int i = 0; i < K; ++i) { add(ti[i], 1, ts[i]); ref(ti[i]); }
-    ti = wk.top_p3 + (size_t)b * QV_RUNNER_CAP;
-    ts = wk.top_p3_sc + (size_t)b * QV_RUNNER_CAP;
-    for (int i = 0; i < K; ++i) { add(ti[i], 1, ts[i]); ref(ti[i]); }
-    for (int r = 0; r < nrefs; ++r) {
-        int v = refs[r], s = tab.surah[v], a = tab.ayah[v];
-        int s0 = tab.surah_start[s - 1], max_ayah = tab.surah_len[s - 1];
+    const bool has_base = u.base_start >= 0;
+    const int nrun = has_base ? u.n_runners : 0;
+    const int nA = (has_base ? 1 : 0) + nrun + 2 * K;      // singles + base, in order
+    const int32_t *ri = wk.runner_idx + (size_t)b * QV_RUNNER_CAP;
+    const double *rs = wk.runner_score + (size_t)b * QV_RUNNER_CAP;
+    const int32_t *si = wk.top_search + (size_t)b * QV_RUNNER_CAP;
+    const double *ss = wk.top_search_sc + (size_t)b * QV_RUNNER_CAP;
+    const int32_t *pi = wk.top_p3 + (size_t)b * QV_RUNNER_CAP;
+    const double *ps = wk.top_p3_sc + (size_t)b * QV_RUNNER_CAP;
+    for (int i = tid; i < CAND_HT; i += 256) { htk[i] = 0xFFFFFFFFu; hti[i] = 0xFFFFFFFFu; }
+    // segment A + the ref list (first top_span_refs entries of the same sequence)
+    const int nrefs = min(min(nA, kn.top_span_refs), 128);
+    for (int i = tid; i < nA; i += 256) {
+        int j = i, st, sp = 1;
+        double sc;
+        if (has_base && j == 0) { st = u.base_start; sp = u.base_span; sc = u.base_score; }
+        else {
+            j -= has_base ? 1 : 0;
+            if (j < nrun) { st = ri[j]; sc = py_round3(rs[j]); }
+            else if (j < nrun + K) { st = si[j - nrun]; sc = ss[j - nrun]; }
+            else { st = pi[j - nrun - K]; sc = ps[j - nrun - K]; }
+        }
+        pkey[i] = (uint32_t)st * 8u + (uint32_t)sp;
+        pscore[i] = sc;
+        if (i < nrefs) refs[i] = st;
+    }
+    __syncthreads();
+    // span expansion sizes per ref (c2c-direct/run.py:300-309)
+    for (int r = tid; r < nrefs; r += 256) {
+        int v = refs[r], s = tab.surah[v], a = tab.ayah[v], max_ayah = tab.surah_len[s - 1];
         int lo = a - kn.max_span + 1; if (lo < 1) lo = 1;
-        int hi = a < max_ayah ? a : max_ayah;
+        int hi = a < max_ayah ? a : max_ayah, cnt = 0;
         for (int st = lo; st <= hi; ++st) {
             int e0 = a > st + 1 ? a : st + 1;
             int e1 = st + kn.max_span - 1; if (e1 > max_ayah) e1 = max_ayah;
-            for (int en = e0; en <= e1; ++en) add(s0 + st - 1, en - st + 1, 0.0);
+            if (e1 >= e0) cnt += e1 - e0 + 1;
+        }
+        roff[r + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        roff[0] = nA;
+        for (int r = 0; r < nrefs; ++r) roff[r + 1] += roff[r];
+    }
+    __syncthreads();
+    int nP = roff[nrefs];
+    bool overflow = nP > CAND_PCAP;
+    if (overflow) nP = CAND_PCAP;
+    for (int r = tid; r < nrefs; r += 256) {
+        int v = refs[r], s = tab.surah[v], a = tab.ayah[v];
+        int s0 = tab.surah_start[s - 1], max_ayah = tab.surah_len[s - 1];
+        int lo = a - kn.max_span + 1; if (lo < 1) lo = 1;
+        int hi = a < max_ayah ? a : max_ayah, o = roff[r];
+        for (int st = lo; st <= hi; ++st) {
+            int e0 = a > st + 1 ? a : st + 1;
+            int e1 = st + kn.max_span - 1; if (e1 > max_ayah) e1 = max_ayah;
+            for (int en = e0; en <= e1; ++en, ++o)
+                if (o < CAND_PCAP) { pkey[o] = (uint32_t)(s0 + st - 1) * 8u + (uint32_t)(en - st + 1); pscore[o] = 0.0; }
         }
     }
-    u.n_cand = n;
-    if (overflow) u.flags |= QV_FLAG_CAND_OVERFLOW;
+    __syncthreads();
+    // first occurrence per key
+    for (int i = tid; i < nP; i += 256) {
+        uint32_t key = pkey[i], slot = (key * 2654435761u) >> 20;  // 12 bits
+        for (;;) {
+            uint32_t old = atomicCAS(&htk[slot], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { atomicMin(&hti[slot], (uint32_t)i); break; }
+            slot = (slot + 1) & (CAND_HT - 1);
+        }
+    }
+    __syncthreads();
+    // ordered compaction: thread t owns proposals [t*per, (t+1)*per)
+    const int per = (nP + 255) / 256;
+    int i0 = tid * per, i1 = min(nP, i0 + per), cnt = 0;
+    unsigned keepmask = 0;  // per <= 12
+    for (int i = i0; i < i1; ++i) {
+        uint32_t key = pkey[i], slot = (key * 2654435761u) >> 20;
+        while (htk[slot] != key) slot = (slot + 1) & (CAND_HT - 1);
+        if (hti[slot] == (uint32_t)i) { keepmask |= 1u << (i - i0); ++cnt; }
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int x = __shfl_up(incl, o);
+        if (lane >= o) incl += x;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - cnt;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int32_t *cs = wk.cand_start + (size_t)b * QV_CAND_CAP;
+    int32_t *cp = wk.cand_span + (size_t)b * QV_CAND_CAP;
+    double *csc = wk.cand_score + (size_t)b * QV_CAND_CAP;
+    for (int i = i0; i < i1; ++i) {
+        if (!(keepmask >> (i - i0) & 1u)) continue;
+        if (base < QV_CAND_CAP) { cs[base] = (int32_t)(pkey[i] >> 3); cp[base] = (int32_t)(pkey[i] & 7u); csc[base] = pscore[i]; }
+        ++base;
+    }
+    if (tid == 0) {
+        u.n_cand = total < QV_CAND_CAP ? total : QV_CAND_CAP;
+        if (overflow || total > QV_CAND_CAP) u.flags |= QV_FLAG_CAND_OVERFLOW;
+    }
 }
 
 // ------------------------------------------------------------------ 9. CTC -------------
@@ -854,7 +935,9 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
                 if (!skip_ok[k]) la3 = NEG;
                 float lamax = fmaxf(la1, fmaxf(la2, la3));
                 if (lamax == NEG) lamax = 0.f;
-                float v = logf(expf(la1 - lamax) + expf(la2 - lamax) + expf(la3 - lamax)) + lamax + lpv[j][k];
+                // hardware exp2/log2 paths: arguments are <= 0 and the sum is in [1, 3], so their
+                // ~1 ulp error is far below the float32 rounding of the ~1e2..1e3 accumulator
+                float v = __logf(__expf(la1 - lamax) + __expf(la2 - lamax) + __expf(la3 - lamax)) + lamax + lpv[j][k];
                 na[k] = s < S ? v : NEG;
             }
 #pragma unroll
@@ -1017,7 +1100,7 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
     hipLaunchKernelGGL(k_frag, dim3(128, batch), dim3(256), 0, stream, tab, wk, 1);
     hipLaunchKernelGGL(k_pass3, dim3((N + 255) / 256, batch), dim3(256), 0, stream, tab, wk);
     hipLaunchKernelGGL(k_topk, dim3(batch, 2), dim3(256), sm_p1, stream, tab, wk, kn);
-    hipLaunchKernelGGL(k_candidates, dim3(batch), dim3(64), (size_t)N, stream, tab, wk, kn);
+    hipLaunchKernelGGL(k_candidates, dim3(batch), dim3(256), (size_t)CAND_PCAP * 12 + CAND_HT * 8 + 1200, stream, tab, wk, kn);
     return QV_OK;
 }
 
