@@ -327,11 +327,12 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
         float mrow[16], lrow[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
-        for (int kt = 0; kt < n_kt; ++kt) {
+        // operand fragments of key tile kt are fetched one tile ahead (straight from HBM/L2 in
+        // fragment order), so their latency overlaps the previous tile's softmax instead of
+        // serialising with the MFMAs
+        half8 kf[4], p0[4], p1[4], v0[2], v1[2];
+        auto fetch = [&](int kt) {
             const int j0 = kt * 32;
-            f32x16 s, r0acc, r1acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; r0acc[r] = 0.f; r1acc[r] = 0.f; }
             int kj = j0 + l31;
             kj = kj < t_max ? kj : t_max - 1;
             // relative-position rows for this tile: rr0 + c, c in [0,64)
@@ -342,13 +343,33 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 int d = ks * 16 + hi * 8;
-                half8 kf = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
-                half8 p0 = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
-                half8 p1 = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(au[ks], kf, s, 0, 0, 0);
-                r0acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p0, r0acc, 0, 0, 0);
-                r1acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p1, r1acc, 0, 0, 0);
+                kf[ks] = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
+                p0[ks] = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
+                p1[ks] = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
             }
+        };
+        auto fetch_v = [&](int kt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                int jj = kt * 32 + ks * 16 + hi * 8;  // < t_pad (t_pad is a multiple of 32)
+                v0[ks] = *(const half8 *)(vb + (size_t)l31 * t_pad + jj);
+                v1[ks] = *(const half8 *)(vb + (size_t)(32 + l31) * t_pad + jj);
+            }
+        };
+        fetch(0);
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const int j0 = kt * 32;
+            f32x16 s, r0acc, r1acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; r0acc[r] = 0.f; r1acc[r] = 0.f; }
+            fetch_v(kt);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(au[ks], kf[ks], s, 0, 0, 0);
+                r0acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p0[ks], r0acc, 0, 0, 0);
+                r1acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p1[ks], r1acc, 0, 0, 0);
+            }
+            if (kt + 1 < n_kt) fetch(kt + 1);
             // skew: S[ii][jj] += raw[ii][31 - ii + jj]
             float p[16];
 #pragma unroll
@@ -390,11 +411,8 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 half8 pa = *(const half8 *)(pw_ + l31 * 40 + ks * 16 + hi * 8);
-                int jj = j0 + ks * 16 + hi * 8;  // < t_pad (t_pad is a multiple of 32)
-                half8 v0 = *(const half8 *)(vb + (size_t)l31 * t_pad + jj);
-                half8 v1 = *(const half8 *)(vb + (size_t)(32 + l31) * t_pad + jj);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v0, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v1, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v0[ks], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v1[ks], o1, 0, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -109,6 +109,33 @@ def test_predict_matches_oracle_on_hip_logprobs(setup, oracle):
         assert abs(got["score"] - want.get("score_raw", 0.0)) <= 1e-3 * max(want.get("score_raw", 0.0), 1e-3)
 
 
+def test_max_length_ragged_batch_30s(oracle):
+    """BASELINE's longest clip (30 s, T = 376) next to a 5 s one: forward vs the fp32 reference,
+    then the whole post-logits path vs the oracle on the HIP log-probs (exercises the 12-tile
+    attention loop, the 6-states-per-lane CTC instantiation and ~1k-char transcripts)."""
+    from offline_tarteel_amd.engine import Engine
+    from oracle import fastconformer_ref as R
+
+    lens = [480000, 80000]
+    audio = torch.from_numpy(synth_audio(2, 480000, seed=99))
+    audio[1, 80000:] = 0
+    w = R.random_weights(11)
+    lp_ref, t_ref = R.forward(w, audio, lens)
+    eng = Engine(device=0, with_model=True, seed=11, max_batch=2, max_samples=480000)
+    lp, t = eng.forward(audio.cuda().contiguous(), lens)
+    assert t == t_ref.tolist() == [376, 63]
+    assert _maxdiff(lp, lp_ref, t) <= 1e-2
+    res = eng.predict_batch(audio.cuda().contiguous(), lens)
+    for i, n in enumerate(t):
+        want = oracle.predict_logprobs(lp[i, :n].cpu().numpy())
+        got = res[i]
+        assert got["greedy_ids"] == want["greedy_ids"]
+        assert (got["surah"], got["ayah"], got["ayah_end"], got["source"]) == (
+            want["surah"], want["ayah"], want["ayah_end"], want["source"])
+        assert abs(got["score"] - want.get("score_raw", 0.0)) <= 1e-3 * max(want.get("score_raw", 0.0), 1e-3)
+    eng.close()
+
+
 def test_rejects_out_of_capacity(setup):
     from offline_tarteel_amd.engine import QvError
 

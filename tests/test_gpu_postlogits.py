@@ -116,6 +116,36 @@ def test_end_to_end_fixtures_batched(engine, oracle, e2e_cases):
                 assert r["n_candidates"] == c["n_candidates"], c["name"]
 
 
+def test_long_transcripts_T376_vs_oracle(oracle):
+    """30 s worth of frames: long verse prefixes (transcripts of several hundred characters ->
+    multi-word bit-vectors, windows on both sides, CTC targets with > 256 states)."""
+    import random
+
+    from offline_tarteel_amd.engine import Engine
+
+    eng = Engine(device=0, with_model=False, max_batch=4, max_samples=480000)
+    rnd = random.Random(5)
+    lps, want = [], []
+    for (s, a), keep, rate in (((2, 282), 170, 0.0), ((2, 282), 150, 0.25), ((4, 12), 120, 0.1), ((2, 255), 80, 0.4)):
+        ids = oracle.token_ids(oracle.verse_index(s, a), 1).tolist()[:keep]
+        ids = [(rnd.randrange(1, 1024) if rnd.random() < rate else i) for i in ids]
+        lg = synth_logits(ids, 376, seed=s * 1000 + a, noise=1.0, boost=7.0, rep=2)
+        lp = torch.log_softmax(torch.from_numpy(lg), -1)
+        lps.append(lp)
+        want.append(oracle.predict_logprobs(lp.numpy()))
+    res = eng.decode_retrieve_rerank(torch.stack(lps).cuda().contiguous(), [376] * len(lps))
+    for got, w in zip(res, want):
+        assert got["greedy_ids"] == w["greedy_ids"]
+        assert got["transcript"] == w["transcript"] and len(w["transcript"]) > 150
+        assert (got["surah"], got["ayah"], got["ayah_end"], got["source"]) == (
+            w["surah"], w["ayah"], w["ayah_end"], w["source"])
+        assert got["use_ctc"] == w.get("use_ctc", got["use_ctc"])
+        if got["use_ctc"]:
+            assert got["n_candidates"] == w["n_candidates"]
+        assert abs(got["score"] - w.get("score_raw", 0.0)) <= 1e-3 * max(w.get("score_raw", 0.0), 1e-3)
+    eng.close()
+
+
 def test_random_transcripts_vs_oracle(engine, oracle):
     """seeded perturbed verses / spans: device == oracle for base + full candidate list."""
     import random
