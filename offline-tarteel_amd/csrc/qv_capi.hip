@@ -160,7 +160,11 @@ static int load_tables(qv_engine *eng, const char *path) {
     QV_TRY(upload(eng, cpo.data(), (size_t)N, &t.clean_off));
     QV_TRY(upload(eng, clen.data(), (size_t)N, &t.clean_len));
     QV_TRY(upload(eng, nlen.data(), (size_t)N, &t.nobsm_len));
-    QV_TRY(upload(eng, atxt, (size_t)aoff[N], &t.alt));
+    {
+        std::vector<uint8_t> apad(atxt, atxt + aoff[N]);
+        apad.resize(apad.size() + 64, 0);  // texts are read 8 bytes at a time
+        QV_TRY(upload(eng, apad.data(), apad.size(), &t.alt));
+    }
     QV_TRY(upload(eng, apo.data(), (size_t)N, &t.alt_off));
     QV_TRY(upload(eng, alen.data(), (size_t)N, &t.alt_len));
     QV_TRY(upload(eng, (const uint16_t *)blob.get("clean_nw"), (size_t)N, &t.nw[0]));
@@ -211,8 +215,8 @@ static int alloc_work(qv_engine *eng) {
     QV_TRY(dalloc(eng, Bz, &w.utt));
     QV_TRY(dalloc(eng, Bz * w.t_cap, &w.frame_ids));
     QV_TRY(dalloc(eng, Bz * w.t_cap, &w.greedy));
-    QV_TRY(dalloc(eng, Bz * QV_MAXQ, &w.q));
-    QV_TRY(dalloc(eng, Bz * QV_MAXQ, &w.qs));
+    QV_TRY(dalloc(eng, Bz * QV_MAXQ + 64, &w.q));
+    QV_TRY(dalloc(eng, Bz * QV_MAXQ + 64, &w.qs));
     QV_TRY(dalloc(eng, Bz * 2 * QV_NSYM * QV_MAXW, &w.pm));
     QV_TRY(dalloc(eng, Bz * N, &w.cand1));
     QV_TRY(dalloc(eng, Bz * N * 3, &w.lcsf));

@@ -95,21 +95,30 @@ __device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int str
     uint64_t V[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
-    for (int j = 0; j < n; ++j) {
-        int c = text[j];
-        const uint64_t *M = pm + (size_t)(c < QV_NSYM ? c : 0) * stride;
-        uint64_t zero_if_other = c < QV_NSYM ? ~0ull : 0ull;
-        uint64_t carry = 0;
+    // the text is fetched 8 codes per (possibly unaligned) load: one memory access per 8 steps
+    // of the recurrence instead of one per step; every text buffer is padded by >= 8 bytes
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        uint64_t chunk = *(const u64_unaligned *)(text + j0);
+        const int cnt = n - j0 < 8 ? n - j0 : 8;
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            uint64_t v = V[w], mm = M[w] & zero_if_other;
-            uint64_t u = v & mm;
-            uint64_t s = v + u;
-            uint64_t c1 = s < v;
-            uint64_t s2 = s + carry;
-            uint64_t c2 = s2 < s;
-            carry = c1 | c2;
-            V[w] = s2 | (v & ~mm);
+        for (int e = 0; e < 8; ++e) {
+            if (e >= cnt) break;
+            int c = (int)((chunk >> (8 * e)) & 0xFF);
+            const uint64_t *M = pm + (size_t)(c < QV_NSYM ? c : 0) * stride;
+            uint64_t zero_if_other = c < QV_NSYM ? ~0ull : 0ull;
+            uint64_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                uint64_t v = V[w], mm = M[w] & zero_if_other;
+                uint64_t u = v & mm;
+                uint64_t s = v + u;
+                uint64_t c1 = s < v;
+                uint64_t s2 = s + carry;
+                uint64_t c2 = s2 < s;
+                carry = c1 | c2;
+                V[w] = s2 | (v & ~mm);
+            }
         }
     }
     int zeros = 0;
@@ -133,6 +142,12 @@ __device__ __forceinline__ int lcs_dispatch(int W, const uint64_t *pm, int strid
     if (W <= 8) return lcs_core<8>(pm, stride, text, n, m);
     if (W <= 11) return lcs_core<11>(pm, stride, text, n, m);
     return lcs_core<16>(pm, stride, text, n, m);
+}
+
+// stage the transcript's match masks (both the spaced and the spaceless pattern, 10 KB) in LDS
+__device__ __forceinline__ void load_pm_lds(uint64_t *spm, const uint64_t *gpm) {
+    for (int i = threadIdx.x; i < 2 * QV_NSYM * QV_MAXW; i += blockDim.x) spm[i] = gpm[i];
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------ 1. argmax ----------
@@ -522,7 +537,9 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
     const QvUtt &u = wk.utt[b];
     if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
     const int m = u.q_len, W = (m + 63) >> 6, N = tab.n_verses;
-    const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_MAXW];
+    load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
+    const uint64_t *pm = spm;
     const int32_t *cand1 = wk.cand1 + (size_t)b * N;
     int16_t *out = wk.lcsf + (size_t)b * N * 3;
     const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 2;
@@ -615,9 +632,11 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_MAXW];
+    load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     if (u.q_len > 0) {
         int m = u.q_len, W = (m + 63) >> 6;
-        const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
+        const uint64_t *pm = spm;
         int per = kn.max_span - 1;
         unsigned long long jbase = 0;
         for (int si = 0; si < u.n_surah20; ++si) {
@@ -696,14 +715,16 @@ __global__ __launch_bounds__(256) void k_pass3(QvTables tab, QvWork wk) {
     if ((int)blockIdx.y >= *wk.n_fail) return;
     int b = wk.fail_list[blockIdx.y];
     const QvUtt &u = wk.utt[b];
+    if (u.q_len == 0) return;
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_MAXW];
+    load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= tab.n_verses || u.q_len == 0) return;
+    if (v >= tab.n_verses) return;
     int m = u.q_len, ms = u.qs_len;
-    const uint64_t *pm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
     const uint8_t *t = tab.clean + tab.clean_off[v];
     int n = tab.clean_len[v], ns = n - (tab.nw[0][v] - 1);
     int l1 = wk.lcsf[((size_t)b * tab.n_verses + v) * 3];  // LCS(t, clean) from k_lcs_full
-    int l2 = lcs_dispatch((ms + 63) >> 6, pm + QV_NSYM * QV_MAXW, QV_MAXW, t, n, ms);
+    int l2 = lcs_dispatch((ms + 63) >> 6, spm + QV_NSYM * QV_MAXW, QV_MAXW, t, n, ms);
     double a = ratio_from(l1, m, n), c = ratio_from(l2, ms, ns);
     wk.p3[(size_t)b * tab.n_verses + v] = a > c ? a : c;
 }
