@@ -86,6 +86,101 @@ __device__ __forceinline__ void local_best(const double *sc, int n, int tid, dou
     }
 }
 
+// Top-K of sc[0..n) (entries < 0 excluded) in the order of a stable descending sort, i.e.
+// (score desc, position asc), for a 256-thread block.  MSB-first radix select on the
+// order-preserving bit pattern of the non-negative doubles finds the K-th largest value in 8
+// histogram passes; ties at that value are taken in position order; the <= K survivors are
+// ordered by rank counting.  scratch: u32[256 + 8], sel_p: i32[K], sel_s: f64[K] (LDS).
+// out_p / out_s may be global.  Returns the number selected (same in every thread).
+__device__ int block_topk_select(const double *sc, int n, int K, uint32_t *scratch, int32_t *sel_p, double *sel_s,
+                                 int32_t *out_p, double *out_s) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *hist = scratch, *misc = scratch + 256;  // misc: [0] digit, [1] need, [2] count, [3..6] wave sums
+    auto key_of = [&](int p) -> unsigned long long {
+        double x = sc[p];
+        return x >= 0.0 ? (unsigned long long)__double_as_longlong(x) + 1ull : 0ull;
+    };
+    // number of valid entries
+    int cnt = 0;
+    for (int p = tid; p < n; p += 256) cnt += sc[p] >= 0.0;
+    cnt = wave_sum_i(cnt);
+    if (lane == 0) misc[3 + wave] = cnt;
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+    const int nvalid = misc[3] + misc[4] + misc[5] + misc[6];
+    if (K > nvalid) K = nvalid;
+    if (K <= 0) return 0;
+    unsigned long long prefix = 0, mask = 0;
+    int need = K;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        __syncthreads();
+        hist[tid] = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += 256) {
+            unsigned long long k = key_of(p);
+            if (k != 0 && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // bins 255..0: lane l owns bins 4l..4l+3; suffix sums from the top
+            uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            uint32_t tot = h0 + h1 + h2 + h3, suf = tot;  // inclusive suffix over lanes >= l
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t x = __shfl_down(suf, o);
+                if (lane + o < 64) suf += x;
+            }
+            uint32_t above = suf - tot;  // elements in bins of higher lanes
+            bool here = above < (uint32_t)need && suf >= (uint32_t)need;
+            if (here) {
+                uint32_t c = above;
+                int d;
+                if (c + h3 >= (uint32_t)need) d = 3;
+                else { c += h3; if (c + h2 >= (uint32_t)need) d = 2; else { c += h2; if (c + h1 >= (uint32_t)need) d = 1; else { c += h1; d = 0; } } }
+                misc[0] = 4 * lane + d;
+                misc[1] = need - (int)c;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)misc[0] << shift;
+        mask |= 0xFFull << shift;
+        need = (int)misc[1];
+    }
+    const unsigned long long T = prefix;  // key of the K-th largest; `need` of the == T entries are taken
+    // entries above T (unordered) ...
+    for (int p = tid; p < n; p += 256) {
+        unsigned long long k = key_of(p);
+        if (k > T) { int slot = atomicAdd(&misc[2], 1u); sel_p[slot] = p; sel_s[slot] = sc[p]; }
+    }
+    // ... and the first `need` entries equal to T, in position order
+    int taken = 0;
+    for (int base = 0; base < n && taken < need; base += 256) {
+        int p = base + tid;
+        bool eq = p < n && key_of(p) == T;
+        unsigned long long bal = __ballot(eq);
+        int r = __popcll(bal & ((1ull << lane) - 1ull)), tot = __popcll(bal);
+        __syncthreads();
+        if (lane == 0) misc[3 + wave] = tot;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += misc[3 + w];
+        int all = misc[3] + misc[4] + misc[5] + misc[6];
+        if (eq && taken + before + r < need) { int slot = atomicAdd(&misc[2], 1u); sel_p[slot] = p; sel_s[slot] = sc[p]; }
+        taken += all;
+    }
+    __syncthreads();
+    // order the K survivors
+    for (int i = tid; i < K; i += 256) {
+        double si = sel_s[i];
+        int pi = sel_p[i], rank = 0;
+        for (int j = 0; j < K; ++j) rank += better(sel_s[j], (unsigned long long)sel_p[j], si, (unsigned long long)pi);
+        out_p[rank] = pi;
+        out_s[rank] = si;
+    }
+    __syncthreads();
+    return K;
+}
+
 // ------------------------------------------------------------------ bit-parallel LCS ---
 // Hyyro/Crochemore: V all ones; per text char U = V & M; V = (V + U) | (V & ~M).
 // pm: match masks [sym][stride] (u64), W words used; text codes >= QV_NSYM match nothing.
@@ -436,16 +531,11 @@ __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
     }
     int K = touched_total < 50 ? touched_total : 50;
     {
-        double ls; unsigned long long lk;
-        local_best(score, N, tid, ls, lk);
-        for (int r = 0; r < K; ++r) {
-            double s = ls;
-            unsigned long long k = lk;
-            block_best(s, k, sh_s, sh_k);
-            if (tid == 0) top[r] = (int32_t)k;
-            if ((int)(k & 255) == tid) { score[k] = -2.0; local_best(score, N, tid, ls, lk); }
-        }
-        __syncthreads();
+        uint32_t *tri_scratch = (uint32_t *)(tabB + 256);     // [272]
+        double *sel_s = (double *)(tri_scratch + 272);        // [64]
+        double *ord_s = sel_s + 64;                           // [64]
+        int32_t *sel_p = (int32_t *)(ord_s + 64);             // [64]
+        block_topk_select(score, N, K, tri_scratch, sel_p, sel_s, top, ord_s);
     }
     if (tid == 0) {
         int n = pyset_order(top, K, cand1, tabA, tabB);
@@ -599,24 +689,24 @@ __global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, Qv
     int rounds = K > K20 ? K : K20;
     int32_t *ridx = wk.runner_idx + (size_t)b * QV_RUNNER_CAP;
     double *rsc = wk.runner_score + (size_t)b * QV_RUNNER_CAP;
-    double ls; unsigned long long lk;
-    local_best(sc, n, tid, ls, lk);
-    for (int r = 0; r < rounds; ++r) {
-        double s = ls;
-        unsigned long long k = lk;
-        block_best(s, k, sh_s, sh_k);
-        if (tid == 0) {
-            int v = cand1[k];
-            if (r < QV_RUNNER_CAP) { ridx[r] = v; rsc[r] = s; }
-            if (r == 0) { u.best1_idx = v; u.best1_score = s; }
-            if (r < K20) {
-                int su = tab.surah[v];
-                bool seen = false;
-                for (int i = 0; i < u.n_surah20; ++i) seen |= (u.surah20[i] == su);
-                if (!seen) u.surah20[u.n_surah20++] = su;
-            }
+    double *sel_s = sh_s;                                 // [128]
+    int32_t *sel_p = (int32_t *)(sel_s + QV_RUNNER_CAP);  // [128]
+    uint32_t *scratch = (uint32_t *)(sel_p + QV_RUNNER_CAP);  // [272]
+    int32_t *ord_p = (int32_t *)(scratch + 272);          // [128]
+    double *ord_s = (double *)(ord_p + QV_RUNNER_CAP);    // [128]
+    int nsel = block_topk_select(sc, n, rounds, scratch, sel_p, sel_s, ord_p, ord_s);
+    for (int r = tid; r < nsel; r += 256) { ridx[r] = cand1[ord_p[r]]; rsc[r] = ord_s[r]; }
+    if (tid == 0) {
+        u.best1_idx = cand1[ord_p[0]];
+        u.best1_score = ord_s[0];
+        int ns = 0;
+        for (int r = 0; r < K20; ++r) {
+            int su = tab.surah[cand1[ord_p[r]]];
+            bool seen = false;
+            for (int i = 0; i < ns; ++i) seen |= (u.surah20[i] == su);
+            if (!seen) u.surah20[ns++] = su;
         }
-        if ((int)(k & 255) == tid) { sc[k] = -2.0; local_best(sc, n, tid, ls, lk); }
+        u.n_surah20 = ns;
     }
     if (tid == 0) u.n_runners = K < kn.top_text ? K : kn.top_text;
 }
@@ -751,15 +841,10 @@ __global__ __launch_bounds__(256) void k_topk(QvTables tab, QvWork wk, QvKnobs k
     if (K > N) K = N;
     int32_t *oi = (which == 0 ? wk.top_search : wk.top_p3) + (size_t)b * QV_RUNNER_CAP;
     double *os = (which == 0 ? wk.top_search_sc : wk.top_p3_sc) + (size_t)b * QV_RUNNER_CAP;
-    double ls; unsigned long long lk;
-    local_best(sc, N, tid, ls, lk);
-    for (int r = 0; r < K; ++r) {
-        double s = ls;
-        unsigned long long k = lk;
-        block_best(s, k, sh_s, sh_k);
-        if (tid == 0) { oi[r] = (int32_t)k; os[r] = s; }
-        if ((int)(k & 255) == tid) { sc[k] = -2.0; local_best(sc, N, tid, ls, lk); }
-    }
+    double *sel_s = sh_s;                                 // [128]
+    int32_t *sel_p = (int32_t *)(sel_s + QV_RUNNER_CAP);  // [128]
+    uint32_t *scratch = (uint32_t *)(sel_p + QV_RUNNER_CAP);
+    block_topk_select(sc, N, K, scratch, sel_p, sel_s, oi, os);
 }
 
 // ------------------------------------------------------------------ 8. candidates ------
@@ -1107,12 +1192,12 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
     QvWork &wk = eng->work;
     QvKnobs kn = eng->knobs;
     int N = tab.n_verses;
-    size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 16;
+    size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + 64;
     hipLaunchKernelGGL(k_tri_score, dim3(TRI_CHUNKS, batch), dim3(256), 0, stream, tab, wk);
     hipLaunchKernelGGL(k_trigram, dim3(batch), dim3(256), sm_tri, stream, tab, wk);
     hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 0);
     hipLaunchKernelGGL(k_frag, dim3(64, batch), dim3(256), 0, stream, tab, wk, 0);
-    size_t sm_p1 = (size_t)N * 8 + 8 * 8 + 8 * 8;
+    size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
     hipLaunchKernelGGL(k_pass1_final, dim3(batch), dim3(256), sm_p1, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_base_final, dim3((batch + 63) / 64), dim3(64), 0, stream, tab, wk, kn, batch, force_ctc);
