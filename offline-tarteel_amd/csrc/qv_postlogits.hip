@@ -632,13 +632,35 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
     const uint64_t *pm = spm;
     const int32_t *cand1 = wk.cand1 + (size_t)b * N;
     int16_t *out = wk.lcsf + (size_t)b * N * 3;
+    const bool short_q = u.q_words < 4;
+    const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
     const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 2;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < jobs; j += gridDim.x * 256) {
         int v, variant;
         if (mode == 0) { v = cand1[j / 3]; variant = j % 3; } else { v = j >> 1; variant = j & 1; }
-        if (variant == 2 && tab.nobsm_len[v] == 0) continue;
+        double *fs = wk.fs + ((size_t)b * N + v) * 3 + variant;
+        if (variant == 2 && tab.nobsm_len[v] == 0) { if (short_q) *fs = -1.0; continue; }
         TextRef t = text_of(tab, v, variant);
-        out[v * 3 + variant] = (int16_t)lcs_dispatch(W, pm, QV_MAXW, t.p, t.n, m);
+        int l = lcs_dispatch(W, pm, QV_MAXW, t.p, t.n, m);
+        out[v * 3 + variant] = (int16_t)l;
+        if (short_q) {
+            // fewer than 4 query words: _fragment_score never looks at windows
+            // (quran_db.py:225-226), so the score is final here and k_frag is skipped
+            double fr = ratio_from(l, m, t.n);
+            if (u.q_words >= 3 && m <= t.n) {
+                bool sub = false;
+                for (int i = 0; i + m <= t.n && !sub; ++i) {
+                    if (i > 0 && t.p[i - 1] != 0) continue;
+                    if (i + m < t.n && t.p[i + m] != 0) continue;
+                    bool ok = true;
+                    for (int k = 0; k < m; ++k)
+                        if (q[k] != t.p[i + k] || q[k] >= QV_NSYM) { ok = false; break; }
+                    sub = ok;
+                }
+                if (sub && fr < 0.98) fr = 0.98;
+            }
+            *fs = fr;
+        }
     }
 }
 
@@ -650,6 +672,7 @@ __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode)
     else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
     const QvUtt &u = wk.utt[b];
     if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
+    if (u.q_words < 4) return;  // scores already final (k_lcs_full): no windows below 4 query words
     if (mode == 0) {
         const int32_t *cand1 = wk.cand1 + (size_t)b * tab.n_verses;
         int jobs = u.n_cand1 * 3;
@@ -993,7 +1016,10 @@ __global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvK
 // c2c-direct/run.py:354-362).  One wave per target; state s = lane*NS + k.
 template <int NS>
 __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tgt, int L, int lane) {
-    const float NEG = -INFINITY;
+    // The recursion runs in log2 units (alpha2 = alpha * log2 e): v_exp_f32 / v_log_f32 are
+    // base-2, so this drops four multiplies per state update; "-inf" is a large finite sentinel,
+    // which removes the all-(-inf) special case (exp2(0) = 1, and the sentinel absorbs the rest).
+    const float NEG = -1e30f, LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
     int S = 2 * L + 1;
     int tok[NS];
     bool skip_ok[NS];
@@ -1008,8 +1034,8 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
             skip_ok[k] = s > 1 && tgt[s >> 1] != tgt[(s >> 1) - 1];
         }
         a[k] = NEG;
-        if (s == 0) a[k] = lp[QV_BLANK];
-        if (s == 1) a[k] = lp[tok[k]];
+        if (s == 0) a[k] = lp[QV_BLANK] * LOG2E;
+        if (s == 1) a[k] = lp[tok[k]] * LOG2E;
     }
     // the gathers lp[t][tok] do not depend on the recurrence: fetch TCH frames ahead so their
     // L2 latency overlaps the exp/log chain instead of serialising with it
@@ -1021,7 +1047,7 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
             int t = t0 + j < T ? t0 + j : T - 1;
             const float *row = lp + (size_t)t * QV_VOCAB;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) lpv[j][k] = row[tok[k]];
+            for (int k = 0; k < NS; ++k) lpv[j][k] = row[tok[k]] * LOG2E;
         }
 #pragma unroll
         for (int j = 0; j < TCH; ++j) {
@@ -1033,18 +1059,15 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
             float na[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                int s = lane * NS + k;
                 float la1 = a[k];
                 float la2 = k >= 1 ? a[k - 1] : p1;
                 float la3 = k >= 2 ? a[k - 2] : (k == 1 ? p1 : p2);
                 if (NS == 1) la3 = p2;
                 if (!skip_ok[k]) la3 = NEG;
                 float lamax = fmaxf(la1, fmaxf(la2, la3));
-                if (lamax == NEG) lamax = 0.f;
-                // hardware exp2/log2 paths: arguments are <= 0 and the sum is in [1, 3], so their
-                // ~1 ulp error is far below the float32 rounding of the ~1e2..1e3 accumulator
-                float v = __logf(__expf(la1 - lamax) + __expf(la2 - lamax) + __expf(la3 - lamax)) + lamax + lpv[j][k];
-                na[k] = s < S ? v : NEG;
+                // states beyond 2L never feed a lower state, so they are left unmasked
+                na[k] = __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(la1 - lamax) + __builtin_amdgcn_exp2f(la2 - lamax) +
+                                              __builtin_amdgcn_exp2f(la3 - lamax)) + lamax + lpv[j][k];
             }
 #pragma unroll
             for (int k = 0; k < NS; ++k) a[k] = na[k];
@@ -1061,9 +1084,9 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l1 = fmaxf(l1, __shfl_xor(l1, o)); l2 = fmaxf(l2, __shfl_xor(l2, o)); }
     float m = fmaxf(l1, l2);
-    if (m == NEG) m = 0.f;
-    float ll = logf(expf(l1 - m) + expf(l2 - m)) + m;
-    return -ll;
+    float ll2 = __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(l1 - m) + __builtin_amdgcn_exp2f(l2 - m)) + m;
+    if (ll2 < -1e29f) return INFINITY;  // no alignment (the caller applies zero_infinity)
+    return -ll2 * LN2;
 }
 
 // LONG = engine capacity above 30 s (more than 384 states per target): only then are the wide
