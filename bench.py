@@ -165,9 +165,17 @@ def main():
         gemm_ms = sum(c["ms"] for c in classes)
         dom = max(classes, key=lambda c: c["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # separate rocprofv3 runs of this same script; summary committed under profiles/)
+        traffic = None
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())["kernels"]
+            traffic = pmc.get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         roof = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
             "flops_per_launch": dom["flops"] / dom["launches"],
             "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "launches": dom["launches"],

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 // t >= len[b] read as zero (the reference zeroes padded frames after GLU).  A lane owns 8
 // channels (weights [9][512] tap-major in registers) and slides over DW_TT consecutive frames,
 // so each input row is loaded once per DW_TT outputs instead of 9 times.
-#define DW_TT 8
+#define DW_TT 4
 __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, const float *__restrict__ wt /*[9][512]*/,
                                                   const float *__restrict__ bias, const int32_t *__restrict__ len,
                                                   half_t *__restrict__ y, int t_max) {

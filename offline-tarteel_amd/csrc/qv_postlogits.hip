@@ -460,7 +460,7 @@ __device__ int pyset_order(const int32_t *vals, int n, int32_t *out, int32_t *ta
 
 #define TRI_WORDS 352  // >= ceil(10243/32), multiple of 32
 
-#define TRI_CHUNKS 16
+#define TRI_CHUNKS 48
 
 // IDF-weighted trigram overlap per verse (forward index: the trigram ids of each verse are
 // tested against the transcript's trigram bitmap; sums run in ascending trigram id = the
