@@ -12,9 +12,11 @@ struct FrontendTab {
 };
 
 void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
-                   int tm_max, int batch, hipStream_t s);
-void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const float *w, const float *bias, half_t *out,
-                  int t1_max, int batch, hipStream_t s);
+                   int tm_max, double *stats, int batch, hipStream_t s);
+void launch_melapply(const float *feats, const int32_t *n_samples, int tm_max, const double *stats, float *out, int batch,
+                     hipStream_t s);
+void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const double *stats, const float *w,
+                  const float *bias, half_t *out, int t1_max, int batch, hipStream_t s);
 void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,
                      half_t *out, int tout_max, int fout, int batch, hipStream_t s);
 void launch_mask_rows(half_t *x, int t_max, int row_elems, const int32_t *len, int batch, hipStream_t s);

@@ -81,30 +81,45 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
     }
 }
 
-// per-feature mean / unbiased std over the valid frames, normalise in place, zero the padding.
-__global__ __launch_bounds__(320) void k_melnorm(float *__restrict__ feats, const int32_t *__restrict__ n_samples,
-                                                 int tm_max) {
-    __shared__ float part[4][QV_NMEL], mean_s[QV_NMEL], rstd_s[QV_NMEL];
-    const int b = blockIdx.x, f = threadIdx.x % QV_NMEL, g = threadIdx.x / QV_NMEL;  // 4 time groups
+// per-feature sum / sum of squares over the valid frames (f64 accumulation, one atomic per
+// feature per block); the normalisation itself is applied by conv0 while it loads its input rows,
+// so the features make no extra round trip through HBM.
+#define MS_CHUNKS 16
+__global__ __launch_bounds__(320) void k_melstats(const float *__restrict__ feats, const int32_t *__restrict__ n_samples,
+                                                  int tm_max, double *__restrict__ acc /*[B][80][2]*/) {
+    __shared__ double p1[4][QV_NMEL], p2[4][QV_NMEL];
+    const int b = blockIdx.y, f = threadIdx.x % QV_NMEL, g = threadIdx.x / QV_NMEL;  // 4 time groups
     const int tm = n_samples[b] / 160 + 1;
-    float *x = feats + (size_t)b * tm_max * QV_NMEL;
-    float s = 0.f;
-    for (int t = g; t < tm; t += 4) s += x[t * QV_NMEL + f];
-    part[g][f] = s;
+    const int per = (tm + MS_CHUNKS - 1) / MS_CHUNKS, t0 = blockIdx.x * per, t1 = min(tm, t0 + per);
+    const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = t0 + g; t < t1; t += 4) { double v = x[t * QV_NMEL + f]; s1 += v; s2 += v * v; }
+    p1[g][f] = s1;
+    p2[g][f] = s2;
     __syncthreads();
-    if (g == 0) mean_s[f] = (part[0][f] + part[1][f] + part[2][f] + part[3][f]) / (float)tm;
-    __syncthreads();
-    float mu = mean_s[f];
-    s = 0.f;
-    for (int t = g; t < tm; t += 4) { float d = x[t * QV_NMEL + f] - mu; s += d * d; }
-    part[g][f] = s;
-    __syncthreads();
-    if (g == 0) rstd_s[f] = 1.f / (sqrtf((part[0][f] + part[1][f] + part[2][f] + part[3][f]) / (float)(tm - 1)) + 1e-5f);
-    __syncthreads();
-    float rs = rstd_s[f];
-    for (int t = g; t < tm_max; t += 4) {
-        float v = x[t * QV_NMEL + f];
-        x[t * QV_NMEL + f] = t < tm ? (v - mu) * rs : 0.f;
+    if (g == 0 && t0 < t1) {
+        atomicAdd(&acc[((size_t)b * QV_NMEL + f) * 2], p1[0][f] + p1[1][f] + p1[2][f] + p1[3][f]);
+        atomicAdd(&acc[((size_t)b * QV_NMEL + f) * 2 + 1], p2[0][f] + p2[1][f] + p2[2][f] + p2[3][f]);
+    }
+}
+
+__device__ __forceinline__ void mel_mean_rstd(const double *acc, int b, int f, int tm, float &mean, float &rstd) {
+    double s1 = acc[((size_t)b * QV_NMEL + f) * 2], s2 = acc[((size_t)b * QV_NMEL + f) * 2 + 1];
+    double mu = s1 / tm, var = (s2 - s1 * mu) / (tm - 1);
+    mean = (float)mu;
+    rstd = 1.f / (sqrtf((float)(var > 0.0 ? var : 0.0)) + 1e-5f);
+}
+
+// materialise the normalised features (only for the debug tap / parity tests)
+__global__ __launch_bounds__(320) void k_melapply(const float *__restrict__ feats, const int32_t *__restrict__ n_samples,
+                                                  int tm_max, const double *__restrict__ acc, float *__restrict__ out) {
+    const int b = blockIdx.y, f = threadIdx.x % QV_NMEL, g = threadIdx.x / QV_NMEL;
+    const int tm = n_samples[b] / 160 + 1;
+    float mean, rstd;
+    mel_mean_rstd(acc, b, f, tm, mean, rstd);
+    for (int t = blockIdx.x * 4 + g; t < tm_max; t += gridDim.x * 4) {
+        size_t i = ((size_t)b * tm_max + t) * QV_NMEL + f;
+        out[i] = t < tm ? (feats[i] - mean) * rstd : 0.f;
     }
 }
 
@@ -113,15 +128,20 @@ __global__ __launch_bounds__(320) void k_melnorm(float *__restrict__ feats, cons
 // Block = one output row t1; a thread owns 8 channels (weights [9][256] tap-major, held in
 // registers) and walks the 40 frequency positions with stride 8; the 3 input rows sit in LDS.
 __global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_in,
-                                               const float *__restrict__ wt /*[9][256]*/, const float *__restrict__ bias,
-                                               half_t *__restrict__ out, int t1_max) {
+                                               const double *__restrict__ stats, const float *__restrict__ wt /*[9][256]*/,
+                                               const float *__restrict__ bias, half_t *__restrict__ out, int t1_max) {
     __shared__ float rows[3][QV_NMEL + 2];
+    __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
     const int b = blockIdx.z, t1 = blockIdx.y, tid = threadIdx.x;
     const int tin = len_in[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
+    __syncthreads();
+    // per-feature normalisation (NeMo normalize_batch "per_feature") applied on load; frames past
+    // the utterance and the conv padding read as 0
     for (int i = tid; i < 3 * (QV_NMEL + 2); i += 256) {
         int dt = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = 2 * t1 - 1 + dt;
-        rows[dt][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? x[t * QV_NMEL + f] : 0.f;
+        rows[dt][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? (x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f] : 0.f;
     }
     const int c0 = (tid & 31) * 8, fl = tid >> 5;
     float w[9][8], bs[8];
@@ -514,14 +534,20 @@ __global__ __launch_bounds__(256) void k_logsoftmax(const float *__restrict__ lo
 // ====================================================================== launchers ======
 
 void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
-                   int tm_max, int batch, hipStream_t s) {
+                   int tm_max, double *stats, int batch, hipStream_t s) {
+    (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * QV_NMEL * batch, s);
     hipLaunchKernelGGL(k_logmel, dim3((tm_max + 3) / 4, batch), dim3(256), 0, s, audio, n_max, n_samples, ft, feats, tm_max);
-    hipLaunchKernelGGL(k_melnorm, dim3(batch), dim3(320), 0, s, feats, n_samples, tm_max);
+    hipLaunchKernelGGL(k_melstats, dim3(MS_CHUNKS, batch), dim3(320), 0, s, feats, n_samples, tm_max, stats);
 }
 
-void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const float *w, const float *bias, half_t *out,
-                  int t1_max, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_conv0, dim3(1, t1_max, batch), dim3(256), 0, s, feats, tm_max, len_in, w, bias, out, t1_max);
+void launch_melapply(const float *feats, const int32_t *n_samples, int tm_max, const double *stats, float *out, int batch,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_melapply, dim3(64, batch), dim3(320), 0, s, feats, n_samples, tm_max, stats, out);
+}
+
+void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const double *stats, const float *w,
+                  const float *bias, half_t *out, int t1_max, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv0, dim3(1, t1_max, batch), dim3(256), 0, s, feats, tm_max, len_in, stats, w, bias, out, t1_max);
 }
 
 void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,

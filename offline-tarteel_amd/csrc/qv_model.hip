@@ -165,6 +165,7 @@ struct QvModel {
     int max_batch, tm_cap, t1_cap, t2_cap, t3_cap;
     // activations
     float *feats, *x, *logits;
+    double *mel_stats;   // [max_batch][80][2] per-feature sum / sum of squares
     half_t *c0, *c1, *c1p, *c2, *c2p, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
     int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3
     int32_t *lens_host;  // pinned
@@ -425,6 +426,7 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     size_t Bz = (size_t)B, M = Bz * m->t3_cap;
     int t_pad_cap = (m->t3_cap + 31) / 32 * 32;
     TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
+    TRY(dal(eng, m, Bz * QV_NMEL * 2, &m->mel_stats));
     TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
     TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1));
     TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1p));
@@ -483,8 +485,8 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     const half_t *posp = nullptr;
     TRY(get_pos(eng, m, T, s, &posp));
 
-    launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, B, s);
-    launch_conv0(m->feats, tm_max, d_tm, m->c0_w, m->c0_b, m->c0, t1m, B, s);
+    launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, m->mel_stats, B, s);
+    launch_conv0(m->feats, tm_max, d_tm, m->mel_stats, m->c0_w, m->c0_b, m->c0, t1m, B, s);
     launch_dwconv2d(m->c0, t1m, 40, d_l1, m->dw2_w, m->dw2_b, m->c1, t2m, 20, B, s);
     GemmArgs g = {};
     g.alpha = 1.f;
@@ -558,8 +560,8 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
 int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hipStream_t s) {
     size_t M = (size_t)m->last_batch * m->last_tmax;
     if (what == 0) {
-        QV_HIP(hipMemcpyAsync(out, m->feats, sizeof(float) * (size_t)m->last_batch * m->last_tm_max * QV_NMEL,
-                              hipMemcpyDeviceToDevice, s));
+        // normalised features are never materialised on the fast path (conv0 normalises on load)
+        launch_melapply(m->feats, m->lens_dev, m->last_tm_max, m->mel_stats, out, m->last_batch, s);
     } else {
         if (!m->save_taps) { qv_set_error(eng, "set QVERSE_DEBUG_TAPS=1 before creating the engine"); return QV_ERR_ARG; }
         int idx = what == 1 ? 0 : layer + 1;
