@@ -295,18 +295,23 @@ __global__ void k_to_half(const float *__restrict__ x, half_t *__restrict__ y, s
 
 // ------------------------------------------------------------------ attention ----------
 // RelPositionMultiHeadAttention core for one (utterance, head): flash-style online softmax over
-// 32-key tiles, one wave per 32-query tile.
+// 32-key tiles, one wave per 32-query tile, everything on v_mfma_f32_32x32x16_f16.
 //   AC[i,j]  = (q_i + u) . k_j
 //   BD[i,j]  = (q_i + v) . p_{T-1-i+j}          (rel_shift of the [T, 2T-1] product)
 //   out      = softmax((AC + BD) / 8, keys < len) V
-// The BD tile is produced as two 32-wide MFMA tiles over the 63 relative positions the tile
-// touches and skewed into place with ds_bpermute (row ii of the accumulator lives in a fixed
-// register, so the skew is a per-register lane rotation).
+// All products are computed TRANSPOSED (keys / positions / head-dim on the MFMA row axis, queries
+// on the column axis), so a lane owns ONE query: its 16 accumulator registers are 16 keys of that
+// query, the softmax reductions are in-register plus one cross-half shuffle, the running max / sum
+// are per-lane scalars, and exp(S^T) is already in the B-operand layout of the P.V product (the
+// contraction index is permuted identically on the V side, which only changes which 8-byte pieces
+// of V^T a lane loads).  The rel-pos term needs raw[c = 31 - i + j]: the two raw tiles go through
+// a per-wave LDS slab (row = query, odd stride) and come back skewed.
+#define ATT_LDS_LD 67  // floats per query row of the skew slab (odd: conflict-free skewed reads)
 __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
                                                    const half_t *__restrict__ pos, int pos_ld, const float *__restrict__ bias_u,
                                                    const float *__restrict__ bias_v, const int32_t *__restrict__ len,
                                                    half_t *__restrict__ out, int t_max, int t_pad) {
-    __shared__ __attribute__((aligned(16))) half_t pbuf[4][32 * 40];  // P tile relayout, row stride 40 halves
+    __shared__ float slab[4][32 * ATT_LDS_LD];
     const int b = blockIdx.y, h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int T = len[b];
     const int l31 = lane & 31, hi = lane >> 5;
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
     const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;                  // [64][t_pad]
     const half_t *pb = pos + h * QV_DK;                                             // [2*t_max-1][pos_ld]
     const int n_qt = (T + 31) >> 5, n_kt = (T + 31) >> 5;
+    float *sl = slab[wave];
     for (int qt = wave; qt < (t_max + 31) / 32; qt += 4) {
         const int i0 = qt * 32;
         half_t *orow = out + ((size_t)b * t_max + i0) * QV_D + h * QV_DK;
@@ -324,34 +330,28 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
                 if (lane < 8) *(half8 *)(orow + (size_t)r * QV_D + lane * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
             continue;
         }
-        // A fragments of (q+u) and (q+v): row = i0 + l31 (clamped), d = ks*16 + hi*8 .. +7
-        half8 au[4], av[4];
+        // B fragments (queries on the column axis): (q+u) and (q+v), row i0 + l31, d = ks*16 + hi*8..
+        half8 qu[4], qv[4];
         {
             int qi = i0 + l31;
             qi = qi < t_max ? qi : t_max - 1;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 int d = ks * 16 + hi * 8;
-                half8 qv8 = *(const half8 *)(qb + (size_t)qi * (2 * QV_D) + d);
+                half8 q8 = *(const half8 *)(qb + (size_t)qi * (2 * QV_D) + d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float qf = (float)qv8[e];
-                    au[ks][e] = (half_t)(qf + bias_u[h * QV_DK + d + e]);
-                    av[ks][e] = (half_t)(qf + bias_v[h * QV_DK + d + e]);
+                    float qf = (float)q8[e];
+                    qu[ks][e] = (half_t)(qf + bias_u[h * QV_DK + d + e]);
+                    qv[ks][e] = (half_t)(qf + bias_v[h * QV_DK + d + e]);
                 }
             }
         }
-        f32x16 o0, o1;
+        f32x16 o0, o1;  // O^T: rows d (0..31 / 32..63), column = this lane's query
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-        float mrow[16], lrow[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
-        // operand fragments of key tile kt are fetched one tile ahead (straight from HBM/L2 in
-        // fragment order), so their latency overlaps the previous tile's softmax instead of
-        // serialising with the MFMAs
-        half8 kf[4], p0[4], p1[4], v0[2], v1[2];
-        auto fetch = [&](int kt) {
+        float m_run = -1e30f, l_run = 0.f;
+        for (int kt = 0; kt < n_kt; ++kt) {
             const int j0 = kt * 32;
             int kj = j0 + l31;
             kj = kj < t_max ? kj : t_max - 1;
@@ -360,89 +360,84 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
             int pr0 = rr0 + l31, pr1 = rr0 + 32 + l31;
             pr0 = pr0 < 0 ? 0 : (pr0 > 2 * t_max - 2 ? 2 * t_max - 2 : pr0);
             pr1 = pr1 < 0 ? 0 : (pr1 > 2 * t_max - 2 ? 2 * t_max - 2 : pr1);
+            f32x16 st, r0, r1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; r0[r] = 0.f; r1[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 int d = ks * 16 + hi * 8;
-                kf[ks] = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
-                p0[ks] = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
-                p1[ks] = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
+                half8 kf = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
+                half8 p0 = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
+                half8 p1 = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);   // S^T[jj][ii]
+                r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);   // raw^T[c][ii], c < 32
+                r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);   // raw^T[32 + c][ii]
             }
-        };
-        auto fetch_v = [&](int kt) {
+            // skew through LDS: slab[ii][c] <- raw^T[c][ii]; BD^T[jj][ii] = slab[ii][31 - ii + jj]
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                int jj = kt * 32 + ks * 16 + hi * 8;  // < t_pad (t_pad is a multiple of 32)
-                v0[ks] = *(const half8 *)(vb + (size_t)l31 * t_pad + jj);
-                v1[ks] = *(const half8 *)(vb + (size_t)(32 + l31) * t_pad + jj);
+            for (int r = 0; r < 16; ++r) {
+                int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sl[l31 * ATT_LDS_LD + c] = r0[r];
+                sl[l31 * ATT_LDS_LD + 32 + c] = r1[r];
             }
-        };
-        fetch(0);
-        for (int kt = 0; kt < n_kt; ++kt) {
-            const int j0 = kt * 32;
-            f32x16 s, r0acc, r1acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; r0acc[r] = 0.f; r1acc[r] = 0.f; }
-            fetch_v(kt);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(au[ks], kf[ks], s, 0, 0, 0);
-                r0acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p0[ks], r0acc, 0, 0, 0);
-                r1acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks], p1[ks], r1acc, 0, 0, 0);
-            }
-            if (kt + 1 < n_kt) fetch(kt + 1);
-            // skew: S[ii][jj] += raw[ii][31 - ii + jj]
+            __builtin_amdgcn_wave_barrier();
             float p[16];
+            float mx = -1e30f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int ii = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                int cc = 31 - ii + l31;               // 0..62
-                int srcl = (cc & 31) + 32 * hi;
-                float a0 = __shfl(r0acc[r], srcl), a1 = __shfl(r1acc[r], srcl);
-                float bd = cc < 32 ? a0 : a1;
-                float sc = (s[r] + bd) * 0.125f;
-                p[r] = (j0 + l31 < T) ? sc : -1e30f;
+                int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float bd = sl[l31 * ATT_LDS_LD + 31 - l31 + jj];
+                float sc = (st[r] + bd) * 0.125f;
+                p[r] = (j0 + jj < T) ? sc : -1e30f;
+                mx = fmaxf(mx, p[r]);
             }
-            // online softmax: row ii lives in register r of the 32 lanes sharing `hi`
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float m_new = fmaxf(m_run, mx);
+            float corr = __expf(m_run - m_new);
+            float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float mx = p[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                float mnew = fmaxf(mrow[r], mx);
-                float corr = __expf(mrow[r] - mnew);
-                float e = (j0 + l31 < T) ? __expf(p[r] - mnew) : 0.f;
-                float sum = e;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                lrow[r] = lrow[r] * corr + sum;
-                mrow[r] = mnew;
-                o0[r] *= corr;
-                o1[r] *= corr;
+                int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float e = (j0 + jj < T) ? __expf(p[r] - m_new) : 0.f;
                 p[r] = e;
+                sum += e;
             }
-            // P (C layout) -> LDS [ii][jj] -> A fragments
-            half_t *pw_ = pbuf[wave];
+            sum += __shfl_xor(sum, 32);
+            l_run = l_run * corr + sum;
+            m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int ii = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                pw_[ii * 40 + l31] = (half_t)p[r];
-            }
-            __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+            // P.V: B operand = exp(S^T) registers 8ks..8ks+7 (keys 16ks + 4hi + {0..3, 8..11});
+            // A operand = V^T rows d with the same key order
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                half8 pa = *(const half8 *)(pw_ + l31 * 40 + ks * 16 + hi * 8);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v0[ks], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, v1[ks], o1, 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+                half8 pbf;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int ii = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (i0 + ii >= t_max) continue;
-            float inv = (i0 + ii < T) ? 1.f / lrow[r] : 0.f;
-            orow[(size_t)ii * QV_D + l31] = (half_t)(o0[r] * inv);
-            orow[(size_t)ii * QV_D + 32 + l31] = (half_t)(o1[r] * inv);
+                for (int e = 0; e < 8; ++e) pbf[e] = (half_t)p[8 * ks + e];
+                int jb = j0 + 16 * ks + 4 * hi;  // < t_pad
+                half4 a0 = *(const half4 *)(vb + (size_t)l31 * t_pad + jb), a1 = *(const half4 *)(vb + (size_t)l31 * t_pad + jb + 8);
+                half4 c0 = *(const half4 *)(vb + (size_t)(32 + l31) * t_pad + jb),
+                      c1 = *(const half4 *)(vb + (size_t)(32 + l31) * t_pad + jb + 8);
+                half8 va = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                half8 vc = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pbf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vc, pbf, o1, 0, 0, 0);
+            }
+        }
+        // O^T column (query i0 + l31): d = (r&3) + 8*(r>>2) + 4*hi (+32)
+        if (i0 + l31 < t_max) {
+            float inv = (i0 + l31 < T) ? 1.f / l_run : 0.f;
+            half_t *o = orow + (size_t)l31 * QV_D;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int d = 8 * q + 4 * hi;
+                half4 h0, h1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h0[e] = (half_t)(o0[4 * q + e] * inv); h1[e] = (half_t)(o1[4 * q + e] * inv); }
+                *(half4 *)(o + d) = h0;
+                *(half4 *)(o + 32 + d) = h1;
+            }
         }
     }
 }
