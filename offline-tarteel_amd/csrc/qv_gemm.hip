@@ -9,6 +9,7 @@
 #include "qv_kernels.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -309,7 +310,8 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
         abort();
     }
     // narrow-N GEMMs on few row panels get 64-wide tiles so the grid still covers the chip
-    bool narrow = (g.N % 128 != 0) || ((g.N / 128) * ((g.M + 127) / 128) < 512 && epi != EPI_GLU);
+    static const int min_tiles = [] { const char *e = getenv("QVERSE_GEMM_MIN_TILES"); return e ? atoi(e) : 512; }();
+    bool narrow = (g.N % 128 != 0) || ((g.N / 128) * ((g.M + 127) / 128) < min_tiles && epi != EPI_GLU);
     if (!g_prof.on) { launch_gemm_inner(epi, g, s, narrow); return; }
     size_t i = g_prof.cls.size();
     while (g_prof.ev.size() < 2 * (i + 1)) {
