@@ -169,6 +169,12 @@ int qv_debug_forward_tap(qv_engine *e, int32_t what, int32_t layer, float *out_d
  * count, and clears the log. */
 int qv_profile_gemm(qv_engine *e, int32_t enable);
 int qv_profile_gemm_read(qv_engine *e, double *ms14, double *flops14, int32_t *launches14);
+/* Replays ONE GEMM of layer 0 with the shapes of the last forward `iters` times back to back
+ * between two HIP events on `stream` (SYNCHRONOUS).  which: 0 FFN-up [M,512]x[512,2048]+Swish,
+ * 1 FFN-down [M,2048]x[2048,512]+residual, 2 QKV, 3 attention out-projection, 4 pointwise-conv+GLU.
+ * Returns the average launch duration in microseconds and the algorithmic FLOPs (2*M*N*K). */
+int qv_profile_replay_gemm(qv_engine *e, int32_t which, int32_t iters, double *avg_us, double *flops_per_launch,
+                           void *stream);
 
 /* Library build info: "gfx950;hip-x.y;..." */
 const char *qv_build_info(void);

@@ -415,3 +415,10 @@ extern "C" int qv_profile_gemm_read(qv_engine *eng, double *ms14, double *flops1
     for (int i = 0; i < 14; ++i) launches14[i] = n[i];
     return QV_OK;
 }
+
+extern "C" int qv_profile_replay_gemm(qv_engine *eng, int32_t which, int32_t iters, double *avg_us, double *flops_per_launch,
+                                      void *stream) {
+    if (!eng || !avg_us || !flops_per_launch) return QV_ERR_ARG;
+    if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
+    return qv_model_replay_gemm(eng, eng->model, which, iters, avg_us, flops_per_launch, (hipStream_t)stream);
+}

@@ -557,6 +557,44 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     return QV_OK;
 }
 
+// Measurement hook: replay ONE GEMM of layer 0 (on the engine's own activations / weights, with
+// the row count of the last forward) `iters` times back to back between two HIP events on `s`.
+// which: 0 FFN-up (N 2048, K 512, Swish), 1 FFN-down (N 512, K 2048, residual), 2 QKV, 3 attention
+// out-projection, 4 pointwise-conv + GLU.  The residual variants run with alpha = 0 so replaying
+// them does not disturb the stream.
+int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s) {
+    int M = m->last_batch * m->last_tmax;
+    if (M <= 0 || iters < 1) { qv_set_error(eng, "replay needs a previous forward"); return QV_ERR_ARG; }
+    const LayerW &L = m->L[0];
+    GemmArgs a = {};
+    int epi;
+    a.M = M; a.out2 = m->vt; a.t_max = m->last_tmax; a.t_pad = (m->last_tmax + 31) / 32 * 32; a.alpha = 1.f;
+    switch (which) {
+        case 0: epi = EPI_F16_SWISH; a.A = m->ln; a.W = L.ff1_w1; a.bias = L.ff1_b1; a.out = m->hbuf; a.N = QV_FF; a.K = QV_D; a.ldo = QV_FF; break;
+        case 1: epi = EPI_RESID; a.A = m->hbuf; a.W = L.ff1_w2; a.bias = L.ff1_b2; a.out = m->x; a.N = QV_D; a.K = QV_FF; a.ldo = QV_D; a.alpha = 0.f; break;
+        case 2: epi = EPI_QKV; a.A = m->ln; a.W = L.qkv_w; a.bias = L.qkv_b; a.out = m->qk; a.N = 3 * QV_D; a.K = QV_D; a.ldo = 2 * QV_D; break;
+        case 3: epi = EPI_RESID; a.A = m->att; a.W = L.out_w; a.bias = L.out_b; a.out = m->x; a.N = QV_D; a.K = QV_D; a.ldo = QV_D; a.alpha = 0.f; break;
+        case 4: epi = EPI_GLU; a.A = m->ln; a.W = L.pw1_w; a.bias = L.pw1_b; a.out = m->glu; a.N = 2 * QV_D; a.K = QV_D; a.ldo = QV_D; break;
+        default: return QV_ERR_ARG;
+    }
+    a.lda = a.K; a.ldw = a.K;
+    hipEvent_t e0, e1;
+    QV_HIP(hipEventCreate(&e0));
+    QV_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm(epi, a, s);
+    QV_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_gemm(epi, a, s);
+    QV_HIP(hipEventRecord(e1, s));
+    QV_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    QV_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1e3 / iters;
+    *flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
+    return QV_OK;
+}
+
 int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hipStream_t s) {
     size_t M = (size_t)m->last_batch * m->last_tmax;
     if (what == 0) {

@@ -92,6 +92,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_debug_forward_tap.argtypes = [vp, i32, i32, vp, vp]
     lib.qv_profile_gemm.argtypes = [vp, i32]
     lib.qv_profile_gemm_read.argtypes = [vp, vp, vp, vp]
+    lib.qv_profile_replay_gemm.argtypes = [vp, i32, i32, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -298,6 +299,19 @@ class Engine:
                 out.append({"kernel": f"k_gemm<{self.GEMM_EPILOGUES[c // 2]},{128 if c % 2 else 64}>",
                             "ms": float(ms[c]), "flops": float(fl[c]), "launches": int(n[c])})
         return out
+
+    REPLAY_KERNELS = ["k_gemm<f16_swish,128>", "k_gemm<resid,64>", "k_gemm<qkv,128>", "k_gemm<resid,64>", "k_gemm<glu,128>"]
+    REPLAY_SHAPES = ["FFN-up [M,512]x[512,2048]+Swish", "FFN-down [M,2048]x[2048,512]+residual", "QKV [M,512]x[512,1536]",
+                     "attention out [M,512]x[512,512]+residual", "pointwise conv [M,512]x[512,1024]+GLU"]
+
+    def replay_gemm(self, which: int, iters: int = 50) -> dict:
+        """average duration (HIP events on the launch stream) of `iters` back-to-back launches of one
+        layer-0 GEMM with the shapes of the last forward."""
+        us, fl = C.c_double(), C.c_double()
+        self._check(self.lib.qv_profile_replay_gemm(self.h, which, iters, C.byref(us), C.byref(fl), self._stream()),
+                    "qv_profile_replay_gemm")
+        return {"kernel": self.REPLAY_KERNELS[which], "shape": self.REPLAY_SHAPES[which], "avg_us": us.value,
+                "flops": fl.value, "launches": iters}
 
     # ---------------------------------------------------------------- debug ------
     def debug_retrieve(self, transcript: str) -> dict:
