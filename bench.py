@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24, help="clips timed on the host for cpu_baseline")
     ap.add_argument("--literal", action="store_true", help="run search()/pass-3 even when the gate passes")
+    ap.add_argument("--precision", choices=("fp16", "mixed"), default="fp16",
+                    help="fp16 = BASELINE configs[1] (the headline line); mixed = int4 Linear weights (W4A16)")
     return ap.parse_args()
 
 
@@ -118,7 +120,7 @@ def main():
     audio = torch.from_numpy(audio_np).cuda(local_rank).contiguous()
     lengths = [n] * B
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=n,
-                 skip_unused_passes=not args.literal)
+                 precision=1 if args.precision == "mixed" else 0, skip_unused_passes=not args.literal)
     gathered = torch.empty((world * B, 4), dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else None
 
     def step():
@@ -208,7 +210,7 @@ def main():
                                    "(BASELINE.json configs[1]); seeded random weights (real ONNX absent)",
                        "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
-                       "skip_unused_passes": not args.literal},
+                       "skip_unused_passes": not args.literal, "weights": args.precision},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -176,6 +176,12 @@ int qv_profile_gemm_read(qv_engine *e, double *ms14, double *flops14, int32_t *l
 int qv_profile_replay_gemm(qv_engine *e, int32_t which, int32_t iters, double *avg_us, double *flops_per_launch,
                            void *stream);
 
+/* Host-only: block-128 symmetric int4 quantisation of one Linear weight w[N][K] (f32 row-major,
+ * N % 64 == 0, K % 128 == 0) followed by the inverse of the device packing, i.e. the f32 matrix
+ * (q - 8) * half(scale) the W4A16 GEMM multiplies by under QV_PREC_MIXED_INT4_INT8.  Needs no GPU;
+ * the parity tests compare it with the oracle's quantiser. */
+int qv_debug_int4_roundtrip(const float *w, int32_t n_rows, int32_t k, float *out);
+
 /* Library build info: "gfx950;hip-x.y;..." */
 const char *qv_build_info(void);
 

@@ -21,6 +21,27 @@ extern "C" const char *qv_last_error(const qv_engine *e) {
     return e ? e->last_error.c_str() : g_create_error.c_str();
 }
 
+extern "C" int qv_debug_int4_roundtrip(const float *w, int32_t N, int32_t K, float *out) {
+    if (!w || !out || N < 64 || N % 64 != 0 || K < 128 || K % 128 != 0) return QV_ERR_ARG;
+    std::vector<uint8_t> q((size_t)N * K / 2, 0);
+    std::vector<half_t> sc((size_t)N * (K / 128) * 2);
+    qv_pack_w4(w, N, K, q.data(), sc.data());
+    // walk the device layout exactly as the kernel does (qv_kernels.h: GemmArgs::Wq / wscale)
+    const int nk = K / 64;
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            int kt = k >> 6, c = (k & 63) >> 3, e = k & 7, p = e >> 1;
+            const uint8_t *tile = q.data() + ((size_t)(n >> 6) * nk + kt) * 2048 + (size_t)(n & 63) * 32;
+            uint32_t chunk;
+            memcpy(&chunk, tile + 4 * (c ^ ((n >> 2) & 7)), 4);
+            uint32_t pair = (chunk >> (4 * p)) & 0x000F000Fu;
+            int code = (e & 1) ? (int)(pair >> 16) : (int)(pair & 0xFFFF);
+            const half_t *sz = sc.data() + ((size_t)(k >> 7) * N + n) * 2;
+            out[(size_t)n * K + k] = ((float)code - ((float)sz[1] - 1024.f)) * (float)sz[0];
+        }
+    return QV_OK;
+}
+
 extern "C" const char *qv_build_info(void) {
     static char buf[128];
     snprintf(buf, sizeof buf, "libqverse gfx950 hip-%d.%d", HIP_VERSION_MAJOR, HIP_VERSION_MINOR);

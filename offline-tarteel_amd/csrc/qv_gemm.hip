@@ -27,14 +27,31 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 
 constexpr bool epi_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; }
 
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// 8 int4 codes (one 4-byte chunk of the W4 layout) -> 8 halves (q - zp) * scale, in k order.
+// 0x6400 | x is the half 1024 + x, so the integer->float conversion is one OR; the subtraction of
+// off = 1024 + zp is exact and the product rounds once, i.e. the result is half((q - zp) * scale).
+__device__ __forceinline__ half8 dequant8(uint32_t q, half2_t s2, half2_t off) {
+    half8 r;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t bits = ((q >> (4 * p)) & 0x000F000Fu) | 0x64006400u;
+        half2_t h = (__builtin_bit_cast(half2_t, bits) - off) * s2;
+        r[2 * p] = h[0];
+        r[2 * p + 1] = h[1];
+    }
+    return r;
+}
+
 }  // namespace
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool W4>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     constexpr int BM = 128, BK = 64;
     constexpr int WN = BN / 2;   // columns per wave
     constexpr int NF = WN / 32;  // 32-wide B fragments per wave
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : BN * BK * 2;
     constexpr int NST = 2;                       // LDS stages (64 KB: two blocks fit a CU; deeper prefetch at one block/CU measured slower)
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int G = 4 + BN / 32;               // direct loads per wave per stage
@@ -75,6 +92,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             grow = grow < g.M ? grow : g.M - 1;
             glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
         }
+        if (W4) {
+            // 64 x 64 nibble tiles are 2 KB contiguous in HBM and already swizzled: one load per
+            // 32 tile rows, the first BN / 32 waves issue it
+            if (wave < BN / 32)
+                glds16(g.Wq + ((size_t)((n0 >> 6) + (wave >> 1)) * nk + kt) * 2048 + (wave & 1) * 1024 + lane * 16,
+                       (unsigned char *)sB + wave * 1024);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < BN / 32; ++q) {
             int chunk = wave * (BN / 32) + q;
@@ -83,6 +108,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             glds16(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8, sB + chunk * 512);
         }
     };
+
+    // W4: this tile's scales [K/128][BN] live in LDS behind the operand stages for the whole K loop
+    half2_t *sS = (half2_t *)(smem + NST * STAGE_BYTES);   // {scale, 1024 + zero point}
+    if (W4) {
+        const int nkb = g.K >> 7;
+        for (int idx = tid; idx < BN * nkb; idx += 256) {
+            int kb = idx / BN, n = idx - kb * BN;
+            sS[idx] = ((const half2_t *)g.wscale)[(size_t)kb * g.N + n0 + n];
+        }
+        __syncthreads();
+    }
 
     // Software pipeline with counted waits: a wave waits only for ITS OWN loads of tile kt
     // (vmcnt = loads issued after them), then one raw s_barrier makes every wave's part of the
@@ -100,6 +136,15 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         if (kt + NST - 1 < nk) stage(kt + NST - 1);
         const half_t *sA = (const half_t *)(smem + (kt % NST) * STAGE_BYTES);
         const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
+        half2_t sc[NF], zo[NF];
+        if (W4) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                half2_t sz = sS[(kt >> 1) * BN + wn * WN + j * 32 + (lane & 31)];
+                sc[j] = half2_t{sz[0], sz[0]};
+                zo[j] = half2_t{sz[1], sz[1]};
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             half8 a[2], b[NF];
@@ -112,7 +157,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 int row = wn * WN + j * 32 + (lane & 31);
-                b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                if (W4) {
+                    // 32-byte rows, 4-byte chunks at c ^ ((row >> 2) & 7): the 64 lanes of the
+                    // ds_read_b32 hit 64 different banks
+                    uint32_t qv = *(const uint32_t *)((const unsigned char *)sB + row * 32 + ((c ^ ((row >> 2) & 7)) << 2));
+                    b[j] = dequant8(qv, sc[j], zo[j]);
+                } else {
+                    b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -246,13 +298,46 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool W4>
 static void launch_one(const GemmArgs &g, hipStream_t s) {
     dim3 grid(g.N / BN, (g.M + 127) / 128);
-    size_t lds = 2 * ((128 * 64 * 2) + (BN * 64 * 2));
+    size_t lds = W4 ? 2 * ((128 * 64 * 2) + (BN * 32)) + (size_t)BN * (g.K / 128) * 4
+                    : 2 * ((128 * 64 * 2) + (BN * 64 * 2));
     size_t epi = epi_is_f32(EPI) ? (size_t)128 * (BN + 4) * 4 : (size_t)128 * (BN + 8) * 2;
     if (epi > lds) lds = epi;
-    hipLaunchKernelGGL((k_gemm<EPI, BN>), grid, dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_gemm<EPI, BN, W4>), grid, dim3(256), lds, s, g);
+}
+
+// Symmetric block-128 int4: per row and per 128 consecutive k, scale = v / -8 where v is the
+// element of largest magnitude (first one on ties), q = clamp(floor(w / scale + 8.5), 0, 15),
+// w' = (q - 8) * half(scale).  oracle/fastconformer_ref.py:quant_dequant_int4 mirrors this exactly.
+void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out) {
+    const int nk = K / 64, nkb = K / 128;
+    for (int n = 0; n < N; ++n) {
+        const float *row = w + (size_t)n * K;
+        for (int kb = 0; kb < nkb; ++kb) {
+            float vmax = 0.f, amax = -1.f;
+            for (int k = 0; k < 128; ++k) {
+                float a = fabsf(row[kb * 128 + k]);
+                if (a > amax) { amax = a; vmax = row[kb * 128 + k]; }
+            }
+            float scale = vmax / -8.0f;
+            float rs = scale != 0.f ? 1.0f / scale : 0.f;
+            scale_out[((size_t)kb * N + n) * 2] = (half_t)scale;
+            scale_out[((size_t)kb * N + n) * 2 + 1] = (half_t)(1024.f + 8.f);  // symmetric: zero point 8
+            for (int k = 0; k < 128; ++k) {
+                float t = row[kb * 128 + k] * rs + 8.0f;
+                int q = (int)floorf(t + 0.5f);
+                q = q < 0 ? 0 : q > 15 ? 15 : q;
+                int kk = kb * 128 + k, kt = kk >> 6, c = (kk & 63) >> 3, e = kk & 7;
+                int nib = (e >> 1) + 4 * (e & 1);  // k = 2p -> nibble p, k = 2p + 1 -> nibble p + 4
+                int pos = c ^ ((n >> 2) & 7);
+                size_t byte = ((size_t)(n >> 6) * nk + kt) * 2048 + (size_t)(n & 63) * 32 + pos * 4 + (nib >> 1);
+                if (nib & 1) q_out[byte] = (uint8_t)((q_out[byte] & 0x0F) | (q << 4));
+                else q_out[byte] = (uint8_t)((q_out[byte] & 0xF0) | q);
+            }
+        }
+    }
 }
 
 // ---- measurement hook: HIP-event timing of every GEMM launch, per (epilogue, tile) class ----
@@ -286,11 +371,28 @@ void qv_gemm_prof_collect(double *ms, double *flops, int *n) {
 }
 
 static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow) {
+    if (g.Wq) {
+        // int4 weights: the Linear layers only (FFN, QKV, attention out, linear_pos)
+        switch (epi) {
+#define CASE(E)                                                   \
+    case E:                                                       \
+        if (narrow) launch_one<E, 64, true>(g, s);                \
+        else launch_one<E, 128, true>(g, s);                      \
+        break;
+            CASE(EPI_F16)
+            CASE(EPI_F16_SWISH)
+            CASE(EPI_RESID)
+            CASE(EPI_QKV)
+#undef CASE
+            default: abort();
+        }
+        return;
+    }
     switch (epi) {
 #define CASE(E)                                                   \
     case E:                                                       \
-        if (narrow) launch_one<E, 64>(g, s);                      \
-        else launch_one<E, 128>(g, s);                            \
+        if (narrow) launch_one<E, 64, false>(g, s);               \
+        else launch_one<E, 128, false>(g, s);                     \
         break;
         CASE(EPI_F16)
         CASE(EPI_F16_SWISH)
@@ -299,13 +401,13 @@ static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool na
         CASE(EPI_F32)
         CASE(EPI_QKV)
 #undef CASE
-        case EPI_GLU: launch_one<EPI_GLU, 128>(g, s); break;
+        case EPI_GLU: launch_one<EPI_GLU, 128, false>(g, s); break;
         default: abort();
     }
 }
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
-    if (g.K % 64 != 0 || g.N % 64 != 0) {
+    if (g.K % 64 != 0 || g.N % 64 != 0 || (g.Wq && g.K % 128 != 0)) {
         fprintf(stderr, "launch_gemm: unsupported shape N=%d K=%d\n", g.N, g.K);
         abort();
     }

@@ -47,10 +47,20 @@ struct GemmArgs {
     int M, N, K, lda, ldw, ldo;
     float alpha;
     int t_max, t_pad;     // EPI_QKV
+    // W4A16 variant (Wq != nullptr, W unused): block-128 int4 weights, w = (q - zero_point) * scale.
+    //   Wq      [N/64][K/64][64 rows][32 B]: one 64 x 64 tile of nibbles is 2 KB contiguous; inside a
+    //           row's 32 B the 4-byte chunk c (k = 8c .. 8c+7) sits at position c ^ ((n >> 2) & 7),
+    //           and in a chunk nibble p holds k = 2p, nibble p + 4 holds k = 2p + 1 (p = 0..3)
+    //   wscale  f16 [K/128][N][2] = {scale, 1024 + zero_point}
+    const uint8_t *Wq;
+    const half_t *wscale;
 };
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool W4>
 __global__ void k_gemm(GemmArgs g);
+
+// host-side packer for the W4A16 layout above (w: [N][K] f32 row-major; N % 64 == 0, K % 128 == 0)
+void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out);
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);
 

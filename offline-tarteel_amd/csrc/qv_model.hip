@@ -146,9 +146,16 @@ int load_weight_file(qv_engine *eng, const char *path, HostWeights &hw) {
     return QV_OK;
 }
 
+// one GEMM weight matrix: f16 [N][K], or (int4 mode, Linear layers) packed nibbles + f16 scales
+struct WMat {
+    const half_t *w = nullptr;
+    const uint8_t *q = nullptr;
+    const half_t *sc = nullptr;
+};
+
 struct LayerW {
     const float *ln_g[5], *ln_b[5];  // ff1, att, conv, ff2, out
-    const half_t *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *qkv_w, *out_w, *pw1_w, *pw2_w;
+    WMat ff1_w1, ff1_w2, ff2_w1, ff2_w2, qkv_w, out_w, pw1_w, pw2_w;
     const float *ff1_b1, *ff1_b2, *ff2_b1, *ff2_b2, *qkv_b, *out_b, *pw1_b, *pw2_b;
     const float *bias_u, *bias_v, *dw_w, *dw_b;
 };
@@ -159,7 +166,9 @@ struct QvModel {
     std::vector<void *> allocs;
     FrontendTab ft;
     const float *c0_w, *c0_b, *dw2_w, *dw2_b, *dw5_w, *dw5_b, *pw3_b, *pw6_b, *sub_out_b, *head_b;
-    const half_t *pw3_w, *pw6_w, *sub_out_w, *head_w, *pos_w;
+    const half_t *pw3_w, *pw6_w, *sub_out_w, *head_w;
+    WMat pos_w;
+    bool w4;             // QV_PREC_MIXED_INT4_INT8: Linear-layer weights are block-128 int4
     LayerW L[N_LAYERS];
     // capacities
     int max_batch, tm_cap, t1_cap, t2_cap, t3_cap;
@@ -212,6 +221,16 @@ std::vector<half_t> to_half(const std::vector<float> &v) {
 }
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// upload a Linear weight [N][K]: f16, or int4 nibbles + scales when the model runs W4A16
+int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K, WMat *out) {
+    if (!m->w4) return up(eng, m, to_half(w), &out->w);
+    std::vector<uint8_t> q((size_t)N * K / 2, 0);
+    std::vector<half_t> sc((size_t)N * (K / 128) * 2);
+    qv_pack_w4(w.data(), N, K, q.data(), sc.data());
+    TRY(up(eng, m, q, &out->q));
+    return up(eng, m, sc, &out->sc);
+}
 
 int build_frontend(qv_engine *eng, QvModel *m) {
     // symmetric Hann(400) centred in 512
@@ -291,7 +310,7 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
         TRY(up(eng, m, p, &m->head_w));
         TRY(up(eng, m, pb, &m->head_b));
     }
-    std::vector<half_t> posw((size_t)N_LAYERS * QV_D * QV_D);
+    std::vector<float> posw((size_t)N_LAYERS * QV_D * QV_D);
     for (int i = 0; i < N_LAYERS; ++i) {
         std::string p = "encoder.layers." + std::to_string(i) + ".";
         LayerW &L = m->L[i];
@@ -300,13 +319,13 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
             TRY(up(eng, m, hw.get(p + lns[k] + ".weight"), &L.ln_g[k]));
             TRY(up(eng, m, hw.get(p + lns[k] + ".bias"), &L.ln_b[k]));
         }
-        TRY(up(eng, m, to_half(hw.get(p + "feed_forward1.linear1.weight")), &L.ff1_w1));
+        TRY(up_mat(eng, m, hw.get(p + "feed_forward1.linear1.weight"), QV_FF, QV_D, &L.ff1_w1));
         TRY(up(eng, m, hw.get(p + "feed_forward1.linear1.bias"), &L.ff1_b1));
-        TRY(up(eng, m, to_half(hw.get(p + "feed_forward1.linear2.weight")), &L.ff1_w2));
+        TRY(up_mat(eng, m, hw.get(p + "feed_forward1.linear2.weight"), QV_D, QV_FF, &L.ff1_w2));
         TRY(up(eng, m, hw.get(p + "feed_forward1.linear2.bias"), &L.ff1_b2));
-        TRY(up(eng, m, to_half(hw.get(p + "feed_forward2.linear1.weight")), &L.ff2_w1));
+        TRY(up_mat(eng, m, hw.get(p + "feed_forward2.linear1.weight"), QV_FF, QV_D, &L.ff2_w1));
         TRY(up(eng, m, hw.get(p + "feed_forward2.linear1.bias"), &L.ff2_b1));
-        TRY(up(eng, m, to_half(hw.get(p + "feed_forward2.linear2.weight")), &L.ff2_w2));
+        TRY(up_mat(eng, m, hw.get(p + "feed_forward2.linear2.weight"), QV_D, QV_FF, &L.ff2_w2));
         TRY(up(eng, m, hw.get(p + "feed_forward2.linear2.bias"), &L.ff2_b2));
         {
             std::vector<float> w, b;
@@ -316,16 +335,16 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
                 w.insert(w.end(), ww.begin(), ww.end());
                 b.insert(b.end(), bb.begin(), bb.end());
             }
-            TRY(up(eng, m, to_half(w), &L.qkv_w));
+            TRY(up_mat(eng, m, w, 3 * QV_D, QV_D, &L.qkv_w));
             TRY(up(eng, m, b, &L.qkv_b));
         }
-        TRY(up(eng, m, to_half(hw.get(p + "self_attn.linear_out.weight")), &L.out_w));
+        TRY(up_mat(eng, m, hw.get(p + "self_attn.linear_out.weight"), QV_D, QV_D, &L.out_w));
         TRY(up(eng, m, hw.get(p + "self_attn.linear_out.bias"), &L.out_b));
         TRY(up(eng, m, hw.get(p + "self_attn.pos_bias_u"), &L.bias_u));
         TRY(up(eng, m, hw.get(p + "self_attn.pos_bias_v"), &L.bias_v));
         {
             const auto &pw = hw.get(p + "self_attn.linear_pos.weight");
-            for (size_t k = 0; k < pw.size(); ++k) posw[(size_t)i * QV_D * QV_D + k] = (half_t)pw[k];
+            for (size_t k = 0; k < pw.size(); ++k) posw[(size_t)i * QV_D * QV_D + k] = pw[k];
         }
         {
             // GLU pairing: 64-column groups = [32 value channels | their 32 gate channels]
@@ -344,7 +363,7 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
                     pb[da] = b[ra];
                     pb[dg] = b[rg];
                 }
-            TRY(up(eng, m, pwm, &L.pw1_w));
+            TRY(up(eng, m, pwm, &L.pw1_w.w));
             TRY(up(eng, m, pb, &L.pw1_b));
         }
         {
@@ -364,10 +383,10 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
             TRY(up(eng, m, tap_major(fw, QV_D), &L.dw_w));
             TRY(up(eng, m, fb, &L.dw_b));
         }
-        TRY(up(eng, m, to_half(hw.get(p + "conv.pointwise_conv2.weight")), &L.pw2_w));
+        TRY(up(eng, m, to_half(hw.get(p + "conv.pointwise_conv2.weight")), &L.pw2_w.w));
         TRY(up(eng, m, hw.get(p + "conv.pointwise_conv2.bias"), &L.pw2_b));
     }
-    TRY(up(eng, m, posw, &m->pos_w));
+    TRY(up_mat(eng, m, posw, N_LAYERS * QV_D, QV_D, &m->pos_w));
     return QV_OK;
 }
 
@@ -392,7 +411,7 @@ int get_pos(qv_engine *eng, QvModel *m, int t_max, hipStream_t stream, const hal
     QV_HIP(hipMalloc((void **)&d_out, (size_t)R * N_LAYERS * QV_D * sizeof(half_t)));
     QV_HIP(hipMemcpyAsync(d_pe, pe.data(), pe.size() * sizeof(half_t), hipMemcpyHostToDevice, stream));
     GemmArgs g = {};
-    g.A = d_pe; g.W = m->pos_w; g.bias = nullptr; g.out = d_out;
+    g.A = d_pe; g.W = m->pos_w.w; g.Wq = m->pos_w.q; g.wscale = m->pos_w.sc; g.bias = nullptr; g.out = d_out;
     g.M = R; g.N = N_LAYERS * QV_D; g.K = QV_D; g.lda = QV_D; g.ldw = QV_D; g.ldo = N_LAYERS * QV_D; g.alpha = 1.f;
     launch_gemm(EPI_F16, g, stream);
     QV_HIP(hipStreamSynchronize(stream));
@@ -406,12 +425,15 @@ int get_pos(qv_engine *eng, QvModel *m, int t_max, hipStream_t stream, const hal
 }  // namespace
 
 int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
-    if (cfg->precision != QV_PREC_FP16) {
-        qv_set_error(eng, "only QV_PREC_FP16 weights are implemented (int4/int8 weight path: next round)");
+    if (cfg->precision != QV_PREC_FP16 && cfg->precision != QV_PREC_MIXED_INT4_INT8) {
+        qv_set_error(eng, "unknown precision (QV_PREC_FP16 or QV_PREC_MIXED_INT4_INT8)");
         return QV_ERR_ARG;
     }
     QvModel *m = new QvModel();
     *out = m;  // owned by the engine from here on (qv_destroy frees it on failure too)
+    // mixed: the Linear layers (FFN, Q/K/V, attention out, linear_pos) carry block-128 int4 weights
+    // and run W4A16; convolutions, pre_encode.out and the CTC head keep f16 weights
+    m->w4 = cfg->precision == QV_PREC_MIXED_INT4_INT8;
     HostWeights hw;
     if (cfg->weights_path && cfg->weights_path[0]) TRY(load_weight_file(eng, cfg->weights_path, hw));
     else init_random(hw, cfg->random_weights_seed);
@@ -506,10 +528,10 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     launch_layernorm(m->x, m->L[0].ln_g[0], m->L[0].ln_b[0], m->ln, M, s);
     for (int l = 0; l < N_LAYERS; ++l) {
         const LayerW &L = m->L[l];
-        auto gemm = [&](int epi, const half_t *A, int K, const half_t *W, const float *bias, void *out, int N, int ldo,
+        auto gemm = [&](int epi, const half_t *A, int K, const WMat &W, const float *bias, void *out, int N, int ldo,
                         float alpha) {
             GemmArgs a = {};
-            a.A = A; a.W = W; a.bias = bias; a.out = out; a.out2 = m->vt;
+            a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.bias = bias; a.out = out; a.out2 = m->vt;
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
             launch_gemm(epi, a, s);
         };
@@ -569,14 +591,16 @@ int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, doubl
     GemmArgs a = {};
     int epi;
     a.M = M; a.out2 = m->vt; a.t_max = m->last_tmax; a.t_pad = (m->last_tmax + 31) / 32 * 32; a.alpha = 1.f;
+    const WMat *W;
     switch (which) {
-        case 0: epi = EPI_F16_SWISH; a.A = m->ln; a.W = L.ff1_w1; a.bias = L.ff1_b1; a.out = m->hbuf; a.N = QV_FF; a.K = QV_D; a.ldo = QV_FF; break;
-        case 1: epi = EPI_RESID; a.A = m->hbuf; a.W = L.ff1_w2; a.bias = L.ff1_b2; a.out = m->x; a.N = QV_D; a.K = QV_FF; a.ldo = QV_D; a.alpha = 0.f; break;
-        case 2: epi = EPI_QKV; a.A = m->ln; a.W = L.qkv_w; a.bias = L.qkv_b; a.out = m->qk; a.N = 3 * QV_D; a.K = QV_D; a.ldo = 2 * QV_D; break;
-        case 3: epi = EPI_RESID; a.A = m->att; a.W = L.out_w; a.bias = L.out_b; a.out = m->x; a.N = QV_D; a.K = QV_D; a.ldo = QV_D; a.alpha = 0.f; break;
-        case 4: epi = EPI_GLU; a.A = m->ln; a.W = L.pw1_w; a.bias = L.pw1_b; a.out = m->glu; a.N = 2 * QV_D; a.K = QV_D; a.ldo = QV_D; break;
+        case 0: epi = EPI_F16_SWISH; a.A = m->ln; W = &L.ff1_w1; a.bias = L.ff1_b1; a.out = m->hbuf; a.N = QV_FF; a.K = QV_D; a.ldo = QV_FF; break;
+        case 1: epi = EPI_RESID; a.A = m->hbuf; W = &L.ff1_w2; a.bias = L.ff1_b2; a.out = m->x; a.N = QV_D; a.K = QV_FF; a.ldo = QV_D; a.alpha = 0.f; break;
+        case 2: epi = EPI_QKV; a.A = m->ln; W = &L.qkv_w; a.bias = L.qkv_b; a.out = m->qk; a.N = 3 * QV_D; a.K = QV_D; a.ldo = 2 * QV_D; break;
+        case 3: epi = EPI_RESID; a.A = m->att; W = &L.out_w; a.bias = L.out_b; a.out = m->x; a.N = QV_D; a.K = QV_D; a.ldo = QV_D; a.alpha = 0.f; break;
+        case 4: epi = EPI_GLU; a.A = m->ln; W = &L.pw1_w; a.bias = L.pw1_b; a.out = m->glu; a.N = 2 * QV_D; a.K = QV_D; a.ldo = QV_D; break;
         default: return QV_ERR_ARG;
     }
+    a.W = W->w; a.Wq = W->q; a.wscale = W->sc;
     a.lda = a.K; a.ldw = a.K;
     hipEvent_t e0, e1;
     QV_HIP(hipEventCreate(&e0));

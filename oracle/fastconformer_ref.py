@@ -146,6 +146,50 @@ def random_weights(seed: int = 20260630, n_layers: int = N_LAYERS) -> dict[str, 
     return out
 
 
+# ------------------------------------------------------------------- int4 weights -----
+# The reference's "mixed" model file stores the Linear-layer MatMuls as 4-bit MatMulNBits
+# ("MatMulNBitsQuantizer int4", experiments/c2c-direct-mixed/run.py:1-9; the script it names,
+# scripts/quantize_mixed.py, is not part of /root/reference, so block size and symmetry are the
+# onnxruntime defaults at best).  [EXT: onnxruntime's quantiser is not in /root/reference either;
+# the rule below (block 128, scale = extreme value / -8, zero point 8) restates MLAS's symmetric
+# Q4 blockwise quantiser and is UNPINNED like the rest of this file.  The device format carries a
+# per-block zero point, so an asymmetric file maps onto it unchanged.]
+# qv_pack_w4 (offline-tarteel_amd/csrc/qv_gemm.hip) performs the identical f32 arithmetic.
+def quant_dequant_int4(w2d: np.ndarray, block: int = 128) -> np.ndarray:
+    """[N][K] f32 -> the f32 matrix the W4A16 GEMM effectively multiplies by."""
+    w2d = np.ascontiguousarray(w2d, dtype=np.float32)
+    N, K = w2d.shape
+    assert K % block == 0
+    wb = w2d.reshape(N, K // block, block)
+    idx = np.abs(wb).argmax(-1)                                  # first element of largest magnitude
+    vmax = np.take_along_axis(wb, idx[..., None], -1)[..., 0]
+    scale = (vmax / np.float32(-8.0)).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        rs = np.where(scale != 0, np.float32(1.0) / scale, np.float32(0.0)).astype(np.float32)
+    t = (wb * rs[..., None]).astype(np.float32) + np.float32(8.0)
+    q = np.clip(np.floor(t + np.float32(0.5)), 0, 15).astype(np.float32)
+    sh = scale.astype(np.float16).astype(np.float32)
+    return ((q - np.float32(8.0)) * sh[..., None]).astype(np.float32).reshape(N, K)
+
+
+INT4_LINEAR_SUFFIXES = (
+    "feed_forward1.linear1.weight", "feed_forward1.linear2.weight",
+    "feed_forward2.linear1.weight", "feed_forward2.linear2.weight",
+    "self_attn.linear_q.weight", "self_attn.linear_k.weight", "self_attn.linear_v.weight",
+    "self_attn.linear_out.weight", "self_attn.linear_pos.weight",
+)
+
+
+def quantize_linear_weights(w: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+    """weights as the QV_PREC_MIXED_INT4_INT8 engine sees them: Linear layers of the 17 Conformer
+    blocks through int4 quantise -> dequantise, everything else untouched."""
+    out = dict(w)
+    for name, t in w.items():
+        if name.startswith("encoder.layers.") and name.endswith(INT4_LINEAR_SUFFIXES):
+            out[name] = torch.from_numpy(quant_dequant_int4(t.numpy()))
+    return out
+
+
 # ------------------------------------------------------------------- front-end --------
 def mel_filterbank() -> np.ndarray:
     """librosa.filters.mel(sr=16000, n_fft=512, n_mels=80, fmin=0, fmax=8000, htk=False,

@@ -30,6 +30,34 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.qv_frames_for_samples(480000) == 376
 
 
+def test_int4_packing_roundtrip_equals_oracle_quantiser():
+    """host half of the W4A16 path: quantise + device packing + unpacking == the oracle's
+    quantise->dequantise, bit for bit (zeros, ties, constant blocks and outliers included)."""
+    import numpy as np
+    from pathlib import Path
+
+    from oracle.fastconformer_ref import quant_dequant_int4
+
+    lib = ctypes.CDLL(str(Path(__file__).resolve().parent.parent / "offline-tarteel_amd" / "libqverse.so"))
+    lib.qv_debug_int4_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    rng = np.random.default_rng(5)
+    for N, K in ((64, 128), (128, 512), (192, 2048)):
+        w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        w[0, :128] = 0.0                    # all-zero block: scale 0
+        w[1, :128] = 0.25                   # constant block
+        w[2, 5] = 3.0                       # positive outlier sets the (negative) scale
+        w[3, 7] = -3.0
+        w[4, :128] = np.float32(0.1) * np.tile(np.array([1, -1], np.float32), 64)  # +-tie for the extreme
+        out = np.empty_like(w)
+        rc = lib.qv_debug_int4_roundtrip(w.ctypes.data, N, K, out.ctypes.data)
+        assert rc == 0
+        ref = quant_dequant_int4(w)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (N, K)
+        # half a step everywhere, a whole step where +max clips at code 15
+        assert np.abs(out - w).max() <= np.abs(w).max() / 8 * 1.01 + 1e-4
+    assert lib.qv_debug_int4_roundtrip(w.ctypes.data, 60, 128, out.ctypes.data) != 0
+
+
 def test_engine_refuses_to_run_without_gpu():
     import torch
 

@@ -212,3 +212,27 @@ def test_plugin_and_runner_on_synthetic_corpus(tmp_path, monkeypatch):
     assert tta["total"] == 3
     plugin._engine.close()
     monkeypatch.setattr(plugin, "_engine", None)
+
+
+def test_int4_weight_path_matches_dequantised_reference(setup):
+    """QV_PREC_MIXED_INT4_INT8: the Linear layers run W4A16 (block-128 int4 weights dequantised in
+    the GEMM).  Reference = the same fp32 PyTorch forward on quantise->dequantise weights; tolerance
+    is the fp16 path's (log-probs 1e-2), so the int4 unpacking itself has to be exact."""
+    from offline_tarteel_amd.engine import Engine
+
+    R, audio = setup["R"], setup["audio"]
+    wq = R.quantize_linear_weights(setup["w"])
+    lp_ref, t_ref = R.forward(wq, audio, LENS)
+    eng = Engine(device=0, with_model=True, seed=SEED, precision=1, max_batch=4, max_samples=80000)
+    try:
+        lp, t = eng.forward(audio.cuda().contiguous(), LENS)
+        torch.cuda.synchronize()
+        assert t == t_ref.tolist()
+        d = _maxdiff(lp, lp_ref, t)
+        assert d <= 1e-2, d
+        # and it is a different model from the fp16 one (the quantisation is really applied)
+        assert _maxdiff(lp, setup["lp_ref"], t) > 5e-2
+        res = eng.predict_batch(audio.cuda().contiguous(), LENS)
+        assert len(res) == 3
+    finally:
+        eng.close()
