@@ -83,6 +83,11 @@ typedef struct {
     double span_penalty;        /* CTC_DIRECT_SPAN_PENALTY     0.5 */
     int32_t skip_unused_passes; /* 1: skip search()/pass-3 when the gate passes (their output is
                                    unused by the mixed plugin); 0: literal */
+    int32_t n_contexts;         /* 1..4 batches in flight (default 1).  With > 1,
+                                   qv_predict_batch_async() rotates over that many execution
+                                   contexts (own activations, workspace and internal stream), so
+                                   the latency-bound decode/retrieval/CTC kernels of one batch run
+                                   under the forward pass of the next.  Memory scales with it. */
 } qv_config;
 
 /* One prediction; mirrors the dict of experiments/c2c-direct-mixed/run.py:126-133. */
@@ -135,6 +140,19 @@ int qv_predict_batch(qv_engine *e, const float *audio_dev, const int64_t *length
                      int32_t *greedy_ids_host, void *stream);
 int qv_predict_batch_async(qv_engine *e, const float *audio_dev, const int64_t *lengths_host,
                            int32_t batch, int64_t n_max, void *stream);
+
+/* ---- batches in flight (n_contexts > 1) -------------------------------------------------
+ * qv_predict_batch_async() then only ORDERS ITS INPUTS on `stream` (the audio must stay unchanged
+ * until the call's results have been joined) and runs on the context's internal stream; a call
+ * blocks the host only when the context it is about to reuse is still busy.  Results are joined
+ * per context: */
+int32_t qv_context_count(const qv_engine *e);
+int32_t qv_last_context(const qv_engine *e);     /* context used by the most recent async call */
+/* makes `stream` wait for that context's batch, then returns its packed i32[B,4] rows */
+const int32_t *qv_packed_results_ctx(qv_engine *e, int32_t ctx, void *stream);
+/* host copy of that context's results (SYNCHRONOUS) */
+int qv_fetch_results_ctx(qv_engine *e, int32_t ctx, int32_t batch, int32_t t_max, qv_result *results_host,
+                         int32_t *greedy_ids_host);
 
 /* Device pointer of the packed (surah, ayah, ayah_end, float-bits(score)) i32[B,4] rows of the
  * last async call -- the payload of the per-batch RCCL all-gather. */

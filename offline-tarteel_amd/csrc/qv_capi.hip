@@ -64,6 +64,7 @@ extern "C" void qv_config_default(qv_config *c) {
     c->text_weight = 0.0;
     c->span_penalty = 0.5;
     c->skip_unused_passes = 1;
+    c->n_contexts = 1;
 }
 
 extern "C" int32_t qv_frames_for_samples(int64_t n) {
@@ -227,7 +228,24 @@ static int load_tables(qv_engine *eng, const char *path) {
     return QV_OK;
 }
 
-static int alloc_work(qv_engine *eng) {
+// make context k the current one: the flat engine fields (and the model's activation pointers)
+// are what every launcher reads
+static void qv_select_ctx(qv_engine *eng, int k) {
+    QvCtx &old = eng->ctx[eng->cur_ctx];
+    old.last_batch = eng->last_batch;
+    old.last_tmax = eng->last_tmax;
+    QvCtx &c = eng->ctx[k];
+    eng->work = c.work;
+    eng->logprobs_ws = c.logprobs_ws;
+    eng->t_host_scratch = c.t_host_scratch;
+    eng->t_dev = c.t_dev;
+    eng->last_batch = c.last_batch;
+    eng->last_tmax = c.last_tmax;
+    eng->cur_ctx = k;
+    if (eng->model) qv_model_select_ctx(eng->model, k);
+}
+
+static int alloc_work(qv_engine *eng, int k) {
     QvWork &w = eng->work;
     int B = eng->cfg.max_batch, N = eng->tab.n_verses;
     w.max_batch = B;
@@ -263,8 +281,21 @@ static int alloc_work(qv_engine *eng) {
     QV_TRY(dalloc(eng, (size_t)1, &w.n_fail));
     QV_TRY(dalloc(eng, Bz, &eng->t_dev));
     QV_HIP(hipHostMalloc((void **)&eng->t_host_scratch, sizeof(int32_t) * Bz, hipHostMallocDefault));
+    eng->ctx[k].t_host_scratch = eng->t_host_scratch;  // owned by the context from here on
     eng->logprobs_ws = nullptr;
     if (eng->cfg.with_model) QV_TRY(dalloc(eng, Bz * w.t_cap * QV_VOCAB, &eng->logprobs_ws));
+    QvCtx &c = eng->ctx[k];
+    c.work = w;
+    c.logprobs_ws = eng->logprobs_ws;
+    c.t_host_scratch = eng->t_host_scratch;
+    c.t_dev = eng->t_dev;
+    c.busy = false;
+    c.last_batch = c.last_tmax = 0;
+    if (eng->n_ctx > 1) {
+        QV_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        QV_HIP(hipEventCreateWithFlags(&c.in_ready, hipEventDisableTiming));
+        QV_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    }
     return QV_OK;
 }
 
@@ -278,6 +309,14 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     eng->model = nullptr;
     eng->t_host_scratch = nullptr;
     eng->last_batch = eng->last_tmax = 0;
+    eng->n_ctx = cfg->n_contexts < 1 ? 1 : cfg->n_contexts;
+    eng->cur_ctx = eng->next_ctx = 0;
+    for (QvCtx &c : eng->ctx) {
+        c = QvCtx();
+        c.t_host_scratch = nullptr;
+        c.stream = nullptr;
+        c.in_ready = c.done = nullptr;
+    }
     auto fail = [&](int rc) {
         g_create_error = eng->last_error;
         qv_destroy(eng);
@@ -288,6 +327,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     if (cfg->top_text < 1 || cfg->top_text > QV_RUNNER_CAP - 1) { qv_set_error(eng, "CTC_DIRECT_TOP_TEXT must be in [1,127]"); return fail(QV_ERR_ARG); }
     if (cfg->top_span_refs < 0 || cfg->top_span_refs > 128) { qv_set_error(eng, "CTC_DIRECT_TOP_SPAN_REFS must be in [0,128]"); return fail(QV_ERR_ARG); }
     if (cfg->max_batch < 1 || cfg->max_samples < 400) { qv_set_error(eng, "bad capacity"); return fail(QV_ERR_ARG); }
+    if (cfg->n_contexts > QV_MAX_CTX) { qv_set_error(eng, "n_contexts must be in [1,4]"); return fail(QV_ERR_ARG); }
     eng->knobs = {cfg->top_text, cfg->top_span_refs, cfg->max_span, cfg->threshold, cfg->text_weight,
                   cfg->span_penalty, cfg->skip_unused_passes};
     int ndev = 0;
@@ -299,21 +339,30 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     eng->device = cfg->device;
     int rc = load_tables(eng, cfg->tables_path);
     if (rc) return fail(rc);
-    rc = alloc_work(eng);
-    if (rc) return fail(rc);
+    for (int k = 0; k < eng->n_ctx; ++k) {
+        rc = alloc_work(eng, k);
+        if (rc) return fail(rc);
+    }
     if (cfg->with_model) {
         rc = qv_model_create(eng, cfg, &eng->model);
         if (rc) return fail(rc);
     }
+    qv_select_ctx(eng, 0);
     *out = eng;
     return QV_OK;
 }
 
 extern "C" void qv_destroy(qv_engine *e) {
     if (!e) return;
+    (void)hipDeviceSynchronize();
     if (e->model) qv_model_destroy(e->model);
     for (void *p : e->allocs) (void)hipFree(p);
-    if (e->t_host_scratch) (void)hipHostFree(e->t_host_scratch);
+    for (QvCtx &c : e->ctx) {
+        if (c.t_host_scratch) (void)hipHostFree(c.t_host_scratch);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        if (c.in_ready) (void)hipEventDestroy(c.in_ready);
+        if (c.done) (void)hipEventDestroy(c.done);
+    }
     delete e;
 }
 
@@ -369,20 +418,63 @@ extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, co
     int t_max = qv_frames_for_samples(lmax);
     if (t_max > eng->work.t_cap) { qv_set_error(eng, "audio longer than engine capacity"); return QV_ERR_CAPACITY; }
     std::vector<int32_t> t_out(batch);
+    hipStream_t run = (hipStream_t)stream;
+    if (eng->n_ctx > 1) {
+        // rotate to the next context; the host blocks only if that context's previous batch is
+        // still in flight (bounds the queue and protects its pinned staging buffers)
+        int k = eng->next_ctx;
+        eng->next_ctx = (k + 1) % eng->n_ctx;
+        QvCtx &c = eng->ctx[k];
+        if (c.busy) QV_HIP(hipEventSynchronize(c.done));
+        qv_select_ctx(eng, k);
+        QV_HIP(hipEventRecord(c.in_ready, (hipStream_t)stream));
+        QV_HIP(hipStreamWaitEvent(c.stream, c.in_ready, 0));
+        run = c.stream;
+    }
     int rc = qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, eng->logprobs_ws, t_max,
-                              t_out.data(), (hipStream_t)stream);
+                              t_out.data(), run);
     if (rc) return rc;
-    return qv_post_run(eng, eng->logprobs_ws, t_max, t_out.data(), batch, (hipStream_t)stream);
+    rc = qv_post_run(eng, eng->logprobs_ws, t_max, t_out.data(), batch, run);
+    if (rc) return rc;
+    if (eng->n_ctx > 1) {
+        QvCtx &c = eng->ctx[eng->cur_ctx];
+        QV_HIP(hipEventRecord(c.done, c.stream));
+        c.busy = true;
+    }
+    return QV_OK;
 }
 
 extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
                                 int64_t n_max, qv_result *res, int32_t *greedy_host, void *stream) {
     int rc = qv_predict_batch_async(eng, audio_dev, lengths_host, batch, n_max, stream);
     if (rc) return rc;
+    if (eng->n_ctx > 1) return qv_fetch_results_ctx(eng, eng->cur_ctx, batch, eng->last_tmax, res, greedy_host);
     return qv_fetch_results(eng, batch, eng->last_tmax, res, greedy_host, stream);
 }
 
 extern "C" const int32_t *qv_packed_results_dev(qv_engine *eng) { return eng ? eng->work.packed : nullptr; }
+
+extern "C" int32_t qv_context_count(const qv_engine *eng) { return eng ? eng->n_ctx : 0; }
+extern "C" int32_t qv_last_context(const qv_engine *eng) { return eng ? eng->cur_ctx : -1; }
+
+extern "C" const int32_t *qv_packed_results_ctx(qv_engine *eng, int32_t k, void *stream) {
+    if (!eng || k < 0 || k >= eng->n_ctx) return nullptr;
+    QvCtx &c = eng->ctx[k];
+    if (eng->n_ctx > 1 && c.busy && hipStreamWaitEvent((hipStream_t)stream, c.done, 0) != hipSuccess) return nullptr;
+    return c.work.packed;
+}
+
+extern "C" int qv_fetch_results_ctx(qv_engine *eng, int32_t k, int32_t batch, int32_t t_max, qv_result *res,
+                                    int32_t *greedy_host) {
+    if (!eng || k < 0 || k >= eng->n_ctx) return QV_ERR_ARG;
+    int keep = eng->cur_ctx;
+    if (eng->n_ctx == 1) QV_HIP(hipDeviceSynchronize());  // the batch ran on a caller stream we were not given
+    qv_select_ctx(eng, k);
+    // on the context's own stream, so the copy is ordered after its batch
+    int rc = qv_fetch_results(eng, batch, t_max, res, greedy_host, eng->n_ctx > 1 ? eng->ctx[k].stream : nullptr);
+    qv_select_ctx(eng, keep);
+    return rc;
+}
 
 extern "C" int qv_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int32_t n_codes, int32_t *base_start,
                                  int32_t *base_span, double *base_score, int32_t *cand_start, int32_t *cand_span,

@@ -151,6 +151,23 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio_dev, const i
 int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out_dev, hipStream_t stream);
 int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s);
 
+void qv_model_select_ctx(QvModel *m, int k);
+
+// One execution context = everything a batch in flight owns (activations live in QvModel).
+// With n_ctx > 1, qv_predict_batch_async() round-robins the contexts, each on its own internal
+// stream, so the latency-bound post-logits kernels of one batch run under the forward of the next.
+#define QV_MAX_CTX 4
+struct QvCtx {
+    QvWork work;
+    float *logprobs_ws;
+    int32_t *t_host_scratch;
+    int32_t *t_dev;
+    hipStream_t stream;
+    hipEvent_t in_ready, done;
+    bool busy;
+    int last_batch, last_tmax;
+};
+
 struct qv_engine {
     qv_config cfg;
     QvKnobs knobs;
@@ -158,6 +175,10 @@ struct qv_engine {
     std::string last_error;
     QvTables tab;                 // device pointers
     std::vector<void *> allocs;   // everything hipMalloc'ed for tables/work
+    QvCtx ctx[QV_MAX_CTX];
+    int n_ctx, cur_ctx, next_ctx;
+    // the CURRENT context's buffers (copied from ctx[cur_ctx] by qv_select_ctx; launches capture
+    // pointer values, and all enqueueing is host-serial)
     QvWork work;
     QvModel *model;
     float *logprobs_ws;           // [max_batch][t_cap][1025] engine-owned log-prob workspace

@@ -162,7 +162,21 @@ struct LayerW {
 
 }  // namespace
 
-struct QvModel {
+// per-context state: the activations of one batch in flight
+struct QvActs {
+    float *feats, *x, *logits;
+    double *mel_stats;   // [max_batch][80][2] per-feature sum / sum of squares
+    half_t *c0, *c1, *c1p, *c2, *c2p, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
+    int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3
+    int32_t *lens_host;  // pinned
+    float *tap_x;        // [N_LAYERS+1][M][512] when save_taps
+    int last_batch, last_tmax, last_tm_max;
+};
+
+// the flat QvActs base is the CURRENT context (qv_model_select_ctx copies it in and out)
+struct QvModel : QvActs {
+    QvActs ctx_acts[QV_MAX_CTX];
+    int n_ctx, cur_ctx;
     std::vector<void *> allocs;
     FrontendTab ft;
     const float *c0_w, *c0_b, *dw2_w, *dw2_b, *dw5_w, *dw5_b, *pw3_b, *pw6_b, *sub_out_b, *head_b;
@@ -172,17 +186,15 @@ struct QvModel {
     LayerW L[N_LAYERS];
     // capacities
     int max_batch, tm_cap, t1_cap, t2_cap, t3_cap;
-    // activations
-    float *feats, *x, *logits;
-    double *mel_stats;   // [max_batch][80][2] per-feature sum / sum of squares
-    half_t *c0, *c1, *c1p, *c2, *c2p, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
-    int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3
-    int32_t *lens_host;  // pinned
     std::map<int, half_t *> pos_cache;  // t_max -> projected positions f16 [2*t_max-1][17*512]
     bool save_taps;
-    float *tap_x;        // [N_LAYERS+1][M][512] when save_taps
-    int last_batch, last_tmax, last_tm_max;
 };
+
+void qv_model_select_ctx(QvModel *m, int k) {
+    m->ctx_acts[m->cur_ctx] = *static_cast<QvActs *>(m);
+    *static_cast<QvActs *>(m) = m->ctx_acts[k];
+    m->cur_ctx = k;
+}
 
 namespace {
 
@@ -447,6 +459,13 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     m->t3_cap = stage_len(m->t2_cap);
     size_t Bz = (size_t)B, M = Bz * m->t3_cap;
     int t_pad_cap = (m->t3_cap + 31) / 32 * 32;
+    const char *tp = getenv("QVERSE_DEBUG_TAPS");
+    m->save_taps = tp && tp[0] == '1';
+    m->n_ctx = eng->n_ctx;
+    m->cur_ctx = 0;
+    for (QvActs &a : m->ctx_acts) { a = QvActs(); a.lens_host = nullptr; }
+    for (int k = m->n_ctx - 1; k >= 0; --k) {
+    m->lens_host = nullptr;
     TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
     TRY(dal(eng, m, Bz * QV_NMEL * 2, &m->mel_stats));
     TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
@@ -466,18 +485,20 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     TRY(dal(eng, m, M * HEAD_N, &m->logits));
     TRY(dal(eng, m, Bz * 5, &m->lens_dev));
     QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * Bz * 5, hipHostMallocDefault));
-    const char *tp = getenv("QVERSE_DEBUG_TAPS");
-    m->save_taps = tp && tp[0] == '1';
+    m->ctx_acts[k].lens_host = m->lens_host;  // owned by the context from here on
     m->tap_x = nullptr;
     if (m->save_taps) TRY(dal(eng, m, (size_t)(N_LAYERS + 1) * M * QV_D, &m->tap_x));
     m->last_batch = m->last_tmax = m->last_tm_max = 0;
+    m->ctx_acts[k] = *static_cast<QvActs *>(m);
+    }  // contexts, allocated last to first so that the flat fields end up being context 0
     return QV_OK;
 }
 
 void qv_model_destroy(QvModel *m) {
     if (!m) return;
     for (void *p : m->allocs) (void)hipFree(p);
-    if (m->lens_host) (void)hipHostFree(m->lens_host);
+    for (QvActs &a : m->ctx_acts)
+        if (a.lens_host) (void)hipHostFree(a.lens_host);
     delete m;
 }
 

@@ -34,7 +34,7 @@ class QvConfig(C.Structure):
         ("max_batch", C.c_int32), ("max_samples", C.c_int32),
         ("top_text", C.c_int32), ("top_span_refs", C.c_int32), ("max_span", C.c_int32),
         ("threshold", C.c_double), ("text_weight", C.c_double), ("span_penalty", C.c_double),
-        ("skip_unused_passes", C.c_int32),
+        ("skip_unused_passes", C.c_int32), ("n_contexts", C.c_int32),
     ]
 
 
@@ -87,6 +87,11 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_predict_batch_async.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.qv_packed_results_dev.argtypes = [vp]
     lib.qv_packed_results_dev.restype = vp
+    lib.qv_context_count.argtypes = [vp]
+    lib.qv_last_context.argtypes = [vp]
+    lib.qv_packed_results_ctx.argtypes = [vp, i32, vp]
+    lib.qv_packed_results_ctx.restype = vp
+    lib.qv_fetch_results_ctx.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.qv_debug_retrieve.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.qv_debug_ctc_loss.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     lib.qv_debug_forward_tap.argtypes = [vp, i32, i32, vp, vp]
@@ -123,7 +128,7 @@ class Engine:
 
     def __init__(self, device: int = 0, with_model: bool = True, weights_path: str | None = None,
                  seed: int = 20260630, precision: int = 0, max_batch: int = 64, max_samples: int = 480000,
-                 tables_path: str | None = None, skip_unused_passes: bool = True, **knobs):
+                 tables_path: str | None = None, skip_unused_passes: bool = True, contexts: int = 1, **knobs):
         import torch
 
         if not torch.cuda.is_available():
@@ -147,6 +152,8 @@ class Engine:
         cfg.max_batch = max_batch
         cfg.max_samples = max_samples
         cfg.skip_unused_passes = int(skip_unused_passes)
+        cfg.n_contexts = int(contexts)
+        self.contexts = int(contexts)
         kn = env_knobs()
         kn.update(knobs)
         for k, v in kn.items():
@@ -264,12 +271,27 @@ class Engine:
         rc = self.lib.qv_predict_batch_async(self.h, C.c_void_p(audio.data_ptr()),
                                              ln.ctypes.data_as(C.c_void_p), B, N, self._stream())
         self._check(rc, "qv_predict_batch_async")
+        return int(self.lib.qv_last_context(self.h))
 
-    def packed_results(self, batch: int):
-        """int32 cuda tensor view [batch, 4] = (surah, ayah, ayah_end, float-bits(score)) of the
-        last async call (the payload of the per-batch all-gather)."""
+    def fetch_results(self, ctx: int, batch: int, t_max: int, want_text: bool = False) -> list[dict]:
+        """join context `ctx` (the value predict_batch_async returned) and copy its results out."""
+        res = np.zeros(batch, dtype=RESULT_DTYPE)
+        greedy = np.full((batch, t_max), -1, dtype=np.int32) if want_text else None
+        rc = self.lib.qv_fetch_results_ctx(self.h, ctx, batch, t_max, res.ctypes.data_as(C.c_void_p),
+                                           greedy.ctypes.data_as(C.c_void_p) if greedy is not None else None)
+        self._check(rc, "qv_fetch_results_ctx")
+        return self._results(res, greedy)
+
+    def packed_results(self, batch: int, ctx: int | None = None):
+        """int32 cuda tensor [batch, 4] = (surah, ayah, ayah_end, float-bits(score)) of the last
+        async call -- or, with batches in flight, of context `ctx` (joined on the current stream).
+        This is the payload of the per-batch all-gather."""
         torch = self.torch
-        ptr = self.lib.qv_packed_results_dev(self.h)
+        if ctx is None:
+            ctx = int(self.lib.qv_last_context(self.h))
+        ptr = self.lib.qv_packed_results_ctx(self.h, ctx, self._stream())
+        if not ptr:
+            raise QvError("qv_packed_results_ctx failed")
         out = torch.empty((batch, 4), dtype=torch.int32, device=f"cuda:{self.device}")
         # device-to-device copy out of the engine-owned buffer on the current stream
         import ctypes

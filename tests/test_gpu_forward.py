@@ -236,3 +236,36 @@ def test_int4_weight_path_matches_dequantised_reference(setup):
         assert len(res) == 3
     finally:
         eng.close()
+
+
+def test_batches_in_flight_equal_one_at_a_time(setup):
+    """n_contexts = 3: qv_predict_batch_async rotates three execution contexts on internal streams.
+    Every batch must come back exactly as the single-context engine computes it, whatever is
+    running next to it."""
+    from offline_tarteel_amd.engine import Engine
+
+    audio = setup["audio"].cuda().contiguous()
+    batches = [(audio, LENS), (audio[1:3].contiguous(), LENS[1:3]), (audio[:1, :30000].contiguous(), [30000]),
+               (audio[2:3].contiguous(), LENS[2:3]), (audio, LENS)]
+    want = [setup["eng"].predict_batch(a, l, want_text=False) for a, l in batches]
+    eng = Engine(device=0, with_model=True, seed=SEED, max_batch=4, max_samples=80000, contexts=3)
+    try:
+        assert eng.lib.qv_context_count(eng.h) == 3
+        for rep in range(2):
+            tickets = [eng.predict_batch_async(a, l) for a, l in batches[:3]]
+            assert tickets == [(3 * rep + i) % 3 for i in range(3)] or len(set(tickets)) == 3
+            got = [eng.fetch_results(t, a.shape[0], eng.frames_for(max(l))) for t, (a, l) in zip(tickets, batches[:3])]
+            # a 4th and 5th call reuse contexts 0 and 1 (the host waits for them if still busy)
+            t3 = eng.predict_batch_async(*batches[3])
+            t4 = eng.predict_batch_async(*batches[4])
+            got.append(eng.fetch_results(t3, 1, eng.frames_for(LENS[2])))
+            got.append(eng.fetch_results(t4, 3, eng.frames_for(max(LENS))))
+            for g, w in zip(got, want):
+                assert g == w
+            # packed rows joined on the caller's stream
+            pk = eng.packed_results(3, t4).cpu()
+            assert pk[:, 0].tolist() == [r["surah"] for r in want[4]]
+        # the synchronous entry point still works with contexts > 1
+        assert eng.predict_batch(audio, LENS, want_text=False) == want[0]
+    finally:
+        eng.close()

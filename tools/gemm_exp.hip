@@ -1,0 +1,240 @@
+// gemm_exp.hip -- dev experiment: weights in MFMA-fragment-major order, loaded global->VGPR
+// (no LDS for B); A through LDS-DMA with NST stages.  Compared with csrc/qv_gemm.hip.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_exp.hip -o tools/gemm_exp
+#include "../offline-tarteel_amd/csrc/qv_gemm.hip"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// Wf layout: [N/32][K/16][64 lanes][8 halves]; lane l of fragment (n32, k16) holds
+// W[n32*32 + (l & 31)][k16*16 + (l >> 5)*8 .. +7]
+template <int BN, int WMW, int NST, int MODE = 0>
+__global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WNW = 4 / WMW;
+    constexpr int MI = BM / (WMW * 32), NF = BN / (WNW * 32);
+    constexpr int A_BYTES = BM * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gx + blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
+    const int nk = MODE == 2 ? 2 : g.K / BK, k16n = g.K / 16;
+
+    f32x16 acc[MI][NF];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stageA = [&](int kt) {
+        half_t *sA = (half_t *)(smem + (kt % NST) * A_BYTES);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int chunk = wave * 4 + q;
+            int row = chunk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            int grow = m0 + row;
+            grow = grow < g.M ? grow : g.M - 1;
+            glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
+        }
+    };
+    const half8 *wbase = Wf + ((size_t)((n0 >> 5) + wn * NF) * k16n) * 64 + lane;
+    auto loadB = [&](int kt, half8 (&b)[NF][4]) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) b[j][ks] = wbase[((size_t)j * k16n + kt * 4 + ks) * 64];
+    };
+    auto compute = [&](int kt, half8 (&b)[NF][4]) {
+        const half_t *sA = (const half_t *)(smem + (kt % NST) * A_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 a[MI];
+            int c = ks * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int row = wm * (MI * 32) + i * 32 + (lane & 31);
+                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j][ks], a[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    half8 b0[NF][4], b1[NF][4];
+    loadB(0, b0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stageA(s);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // ---- even iteration: uses b0, prefetches b1
+        {
+            const int ahead = min(nk - 1 - kt, NST - 2);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) loadB(kt + 1, b1);
+            if (kt + NST - 1 < nk) stageA(kt + NST - 1);
+            compute(kt, b0);
+        }
+        if (kt + 1 < nk) {
+            const int k1 = kt + 1;
+            const int ahead = min(nk - 1 - k1, NST - 2);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (k1 + 1 < nk) loadB(k1 + 1, b0);
+            if (k1 + NST - 1 < nk) stageA(k1 + NST - 1);
+            compute(k1, b1);
+        }
+    }
+    __syncthreads();
+
+    // epilogue: swish + f16 through LDS (same as the product kernel)
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int LDT = BN + 8;
+    half_t *sO = (half_t *)smem;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rl = wm * (MI * 32) + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = wn * (NF * 32) + j * 32 + 8 * q + 4 * hi;
+                f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][q * 4 + e] + bb[e];
+                    x = x * sigmoidf_(x);
+                    o[e] = (half_t)x;
+                }
+                *(half4 *)(sO + rl * LDT + cl) = o;
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+        int r = idx / CPR, c = (idx % CPR) * 8;
+        if (m0 + r >= g.M) continue;
+        half8 v = *(const half8 *)(sO + r * LDT + c);
+        if (MODE == 1 && v[0] != (half_t)12345.f) continue;
+        *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c) = v;
+    }
+}
+
+static float frand(uint64_t &s) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return ((float)((s >> 33) & 0xFFFFFF) / 8388608.0f) - 1.0f;
+}
+
+template <int BN, int WMW, int NST, int MODE = 0>
+static void run2(const char *name, GemmArgs g, const half8 *Wf, int iters, const std::vector<half_t> &hA,
+                 const std::vector<half_t> &hW, const std::vector<float> &hb) {
+    dim3 grid(g.N / BN, (g.M + 127) / 128);
+    size_t lds = (size_t)NST * 128 * 64 * 2, epi = (size_t)128 * (BN + 8) * 2;
+    if (epi > lds) lds = epi;
+    CK(hipFuncSetAttribute((const void *)k_gemm2<BN, WMW, NST, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(g.out, 0, (size_t)g.M * g.ldo * 2));
+    hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    CK(hipDeviceSynchronize());
+    std::vector<half_t> ho((size_t)g.M * g.ldo);
+    CK(hipMemcpy(ho.data(), g.out, ho.size() * 2, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 256; ++t) {
+        int r = (t * 977 + 13) % g.M, c = (t * 131 + 7) % g.N;
+        double a = 0;
+        for (int k = 0; k < g.K; ++k) a += (double)(float)hA[(size_t)r * g.K + k] * (double)(float)hW[(size_t)c * g.K + k];
+        a += hb[c];
+        double want = a / (1.0 + exp(-a));
+        maxerr = fmax(maxerr, fabs(want - (double)(float)ho[(size_t)r * g.ldo + c]));
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / iters, fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s N%-5d K%-5d %8.2f us %7.1f TF/s maxerr %.2e\n", name, g.N, g.K, us, fl / us / 1e6, maxerr);
+}
+
+int main(int argc, char **argv) {
+    int iters = argc > 1 ? atoi(argv[1]) : 50;
+    const int M = 8064;
+    uint64_t seed = 1;
+    struct Sh { int N, K; } shapes[] = {{2048, 512}, {512, 2048}, {1536, 512}, {512, 512}};
+    for (auto sh : shapes) {
+        const int N = sh.N, K = sh.K;
+        std::vector<half_t> hA((size_t)M * K), hW((size_t)N * K), hWf((size_t)N * K);
+        for (auto &v : hA) v = (half_t)frand(seed);
+        for (auto &v : hW) v = (half_t)(frand(seed) * 0.05f);
+        std::vector<float> hb(N);
+        for (auto &v : hb) v = frand(seed) * 0.1f;
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k) {
+                int n32 = n >> 5, k16 = k >> 4, l = (n & 31) + 32 * ((k & 15) >> 3), e = k & 7;
+                hWf[(((size_t)n32 * (K / 16) + k16) * 64 + l) * 8 + e] = hW[(size_t)n * K + k];
+            }
+        half_t *dA, *dW, *dWf, *dO;
+        float *db;
+        CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dWf, hW.size() * 2));
+        CK(hipMalloc(&dO, (size_t)M * N * 2)); CK(hipMalloc(&db, N * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dWf, hWf.data(), hW.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+        GemmArgs g = {};
+        g.A = dA; g.W = dW; g.bias = db; g.out = dO; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.alpha = 1.f;
+        // baseline
+        {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 3; ++i) launch_gemm(EPI_F16_SWISH, g, 0);
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) launch_gemm(EPI_F16_SWISH, g, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            double us = ms * 1e3 / iters;
+            printf("%-34s N%-5d K%-5d %8.2f us %7.1f TF/s\n", "baseline (product kernel)", N, K, us, 2.0 * M * N * K / us / 1e6);
+        }
+        const half8 *Wf = (const half8 *)dWf;
+        run2<128, 1, 2, 1>("BN128 1x4 NST2 no-store", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 2, 2>("BN128 1x4 NST2 2-iter-loop", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 2>("BN128 2x2 NST2", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 3>("BN128 2x2 NST3", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 4>("BN128 2x2 NST4", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 2>("BN128 1x4 NST2", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 3>("BN128 1x4 NST3", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 4>("BN128 1x4 NST4", g, Wf, iters, hA, hW, hb);
+        run2<64, 2, 3>("BN64  2x2 NST3", g, Wf, iters, hA, hW, hb);
+        run2<64, 2, 4>("BN64  2x2 NST4", g, Wf, iters, hA, hW, hb);
+        run2<256, 2, 3>("BN256 2x2 NST3", g, Wf, iters, hA, hW, hb);
+        run2<256, 1, 3>("BN256 1x4 NST3", g, Wf, iters, hA, hW, hb);
+        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dWf)); CK(hipFree(dO)); CK(hipFree(db));
+    }
+    return 0;
+}
