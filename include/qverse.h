@@ -141,6 +141,18 @@ int qv_predict_batch(qv_engine *e, const float *audio_dev, const int64_t *length
 int qv_predict_batch_async(qv_engine *e, const float *audio_dev, const int64_t *lengths_host,
                            int32_t batch, int64_t n_max, void *stream);
 
+/* ---- a15: speed perturbation / sample-rate conversion ------------------------------------
+ * The float32 polyphase FIR behind scipy.signal.resample_poly(x, up, down), which the reference's
+ * TTA wrapper calls with (9, 10) and (11, 10) (experiments/c2c-direct-mixed-tta/run.py:60-71):
+ *   y[m] = sum_j x[xi - (P-1) + j] * h[t + up * (P-1-j)],  xi = (m0+m)*down / up, t = (m0+m)*down % up,
+ * P = ceil(n_taps / up), terms outside [0, n_in) skipped, accumulated IN THIS ORDER in float32
+ * (no FMA), which is what scipy's upfirdn does -- results are bit-identical to it.
+ * taps_host: n_taps float32 filter taps exactly as resample_poly hands them to upfirdn (designed,
+ * scaled by `up`, zero-padded in front/behind); m0 = first kept output sample (n_pre_remove).
+ * x_dev [n_in], y_dev [n_out] device pointers.  Asynchronous on `stream`. */
+int qv_upfirdn(qv_engine *e, const float *x_dev, int64_t n_in, const float *taps_host, int32_t n_taps,
+               int32_t up, int32_t down, int64_t m0, int64_t n_out, float *y_dev, void *stream);
+
 /* ---- batches in flight (n_contexts > 1) -------------------------------------------------
  * qv_predict_batch_async() then only ORDERS ITS INPUTS on `stream` (the audio must stay unchanged
  * until the call's results have been joined) and runs on the context's internal stream; a call

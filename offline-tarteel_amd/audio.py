@@ -76,6 +76,46 @@ def load_audio(path: str, sr: int = TARGET_SR) -> np.ndarray:
     return resample(audio, native, sr)
 
 
+_PLAN_CACHE: dict = {}
+
+
+def resample_plan(up: int, down: int, n_in: int):
+    """Host half of resample_poly for float32 input: (up, down, taps float32, first kept output
+    index, n_out).  The taps are what scipy hands to upfirdn -- firwin(2*half_len+1, 1/max_rate,
+    window=("kaiser", 5.0)) cast to float32, scaled by `up` in float32, zero-padded in front so
+    that output sample 0 is centred and behind until the FIR produces enough samples.  The FIR
+    itself runs on the GPU (Engine.resample_poly -> qv_upfirdn)."""
+    import math
+
+    g = math.gcd(int(up), int(down))
+    up, down = int(up) // g, int(down) // g
+    if up == down == 1:
+        return 1, 1, None, 0, n_in      # resample_poly returns a copy
+    n_out = (n_in * up + down - 1) // down
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    key = (up, down)
+    if key not in _PLAN_CACHE:
+        from scipy.signal import firwin
+
+        h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)).astype(np.float32)
+        h *= up
+        _PLAN_CACHE[key] = h
+    h = _PLAN_CACHE[key]
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+
+    def out_len(len_h: int) -> int:
+        nt = (n_in + (len_h + (-len_h % up)) // up - 1) * up
+        return nt // down + (1 if nt % down else 0)
+
+    n_post_pad = 0
+    while out_len(len(h) + n_pre_pad + n_post_pad) < n_out + n_pre_remove:
+        n_post_pad += 1
+    taps = np.concatenate((np.zeros(n_pre_pad, np.float32), h, np.zeros(n_post_pad, np.float32)))
+    return up, down, np.ascontiguousarray(taps), n_pre_remove, n_out
+
+
 def speed_perturb(audio_16k: np.ndarray, factor: float) -> np.ndarray:
     """0.9 = 10 % slower, 1.1 = 10 % faster: resample_poly(x, int(factor*10), 10), default Kaiser
     FIR -- the same scipy call the reference's TTA wrapper makes."""

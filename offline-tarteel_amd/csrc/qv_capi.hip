@@ -2,6 +2,7 @@
 
 #include "qv_common.h"
 #include "qv_kernels.h"
+#include "qv_layers.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -450,6 +451,32 @@ extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const in
     if (rc) return rc;
     if (eng->n_ctx > 1) return qv_fetch_results_ctx(eng, eng->cur_ctx, batch, eng->last_tmax, res, greedy_host);
     return qv_fetch_results(eng, batch, eng->last_tmax, res, greedy_host, stream);
+}
+
+extern "C" int qv_upfirdn(qv_engine *eng, const float *x_dev, int64_t n_in, const float *taps, int32_t n_taps, int32_t up,
+                          int32_t down, int64_t m0, int64_t n_out, float *y_dev, void *stream) {
+    if (!eng || !x_dev || !taps || !y_dev || n_in < 1 || n_taps < 1 || up < 1 || down < 1 || m0 < 0 || n_out < 0) return QV_ERR_ARG;
+    const qv_engine::Fir *fir = nullptr;
+    for (const auto &f : eng->firs)
+        if (f.up == up && (int)f.taps.size() == n_taps && memcmp(f.taps.data(), taps, sizeof(float) * n_taps) == 0) fir = &f;
+    if (!fir) {
+        // first use of this filter: per-phase, time-reversed rows (what upfirdn builds as h_trans_flip)
+        int P = (n_taps + up - 1) / up;
+        std::vector<float> hf((size_t)up * P, 0.f);
+        for (int t = 0; t < up; ++t)
+            for (int j = 0; j < P; ++j) {
+                int k = t + up * (P - 1 - j);
+                if (k < n_taps) hf[(size_t)t * P + j] = taps[k];
+            }
+        float *d = nullptr;
+        QV_TRY(dalloc(eng, hf.size(), &d));
+        QV_HIP(hipMemcpy(d, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+        eng->firs.push_back({up, std::vector<float>(taps, taps + n_taps), d, P});
+        fir = &eng->firs.back();
+    }
+    launch_upfirdn(x_dev, n_in, fir->hflip_dev, fir->P, up, down, m0, n_out, y_dev, (hipStream_t)stream);
+    QV_HIP(hipGetLastError());
+    return QV_OK;
 }
 
 extern "C" const int32_t *qv_packed_results_dev(qv_engine *eng) { return eng ? eng->work.packed : nullptr; }

@@ -184,6 +184,9 @@ struct qv_engine {
     float *logprobs_ws;           // [max_batch][t_cap][1025] engine-owned log-prob workspace
     int32_t *t_host_scratch;      // pinned [max_batch]
     int32_t *t_dev;               // [max_batch]
+    // resampler filters already arranged per phase and resident in HBM (qv_upfirdn)
+    struct Fir { int up; std::vector<float> taps; float *hflip_dev; int P; };
+    std::vector<Fir> firs;
     // host copies of small table parts used by debug/entry code
     std::vector<uint8_t> h_surah;
     std::vector<uint16_t> h_ayah;

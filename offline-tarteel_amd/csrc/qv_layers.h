@@ -29,3 +29,5 @@ void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, half_t *y, int t_max, int batch,
                      hipStream_t s);
 void launch_logsoftmax(const float *logits, int ld, float *out, int M, hipStream_t s);
+void launch_upfirdn(const float *x, int64_t n_in, const float *hflip, int P, int up, int down, int64_t m0, int64_t n_out,
+                    float *y, hipStream_t s);

@@ -582,3 +582,33 @@ void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const i
 void launch_logsoftmax(const float *logits, int ld, float *out, int M, hipStream_t s) {
     hipLaunchKernelGGL(k_logsoftmax, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, out, M);
 }
+
+// ---------------------------------------------------------------- a15: polyphase resampler ----
+// scipy.signal.upfirdn's float32 inner loop, one output sample per thread (tta/run.py:60-71 reaches
+// it through resample_poly).  hflip[t][j] = h[t + up * (P - 1 - j)] (zero beyond n_taps) is built
+// on the host, so a thread walks x forwards and its phase row forwards, exactly scipy's order;
+// out-of-range inputs are skipped like scipy's index clamping does, not added as zeros.
+namespace {
+__global__ __launch_bounds__(256) void k_upfirdn(const float *__restrict__ x, int64_t n_in, const float *__restrict__ hflip,
+                                                 int P, int up, int down, int64_t m0, int64_t n_out, float *__restrict__ y) {
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_out) return;
+    int64_t pos = (m0 + m) * down;
+    int64_t xi = pos / up;
+    int t = (int)(pos - xi * up);
+    const float *h = hflip + (size_t)t * P;
+    int64_t first = xi - (P - 1);
+    int j0 = first < 0 ? (int)(-first) : 0;
+    int64_t last = xi < n_in - 1 ? xi : n_in - 1;   // last valid input index
+    float acc = 0.f;
+    for (int64_t i = first + j0; i <= last; ++i) acc = __fadd_rn(acc, __fmul_rn(x[i], h[i - first]));
+    y[m] = acc;
+}
+}  // namespace
+
+void launch_upfirdn(const float *x, int64_t n_in, const float *hflip, int P, int up, int down, int64_t m0, int64_t n_out,
+                    float *y, hipStream_t s) {
+    if (n_out <= 0) return;
+    hipLaunchKernelGGL(k_upfirdn, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, x, n_in, hflip, P, up, down, m0,
+                       n_out, y);
+}

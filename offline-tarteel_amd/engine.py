@@ -87,6 +87,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_predict_batch_async.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.qv_packed_results_dev.argtypes = [vp]
     lib.qv_packed_results_dev.restype = vp
+    lib.qv_upfirdn.argtypes = [vp, vp, i64, vp, i32, i32, i32, i64, i64, vp, vp]
     lib.qv_context_count.argtypes = [vp]
     lib.qv_last_context.argtypes = [vp]
     lib.qv_packed_results_ctx.argtypes = [vp, i32, vp]
@@ -301,6 +302,28 @@ class Engine:
         if rc != 0:
             raise QvError(f"hipMemcpyAsync failed ({rc})")
         return out
+
+    def resample_poly(self, x, up: int, down: int):
+        """scipy.signal.resample_poly(x, up, down) for a float32 cuda vector, computed on the GPU
+        and bit-identical to scipy's float32 result (a15: the TTA wrapper's 0.9x / 1.1x speed
+        perturbation, c2c-direct-mixed-tta/run.py:60-71)."""
+        from .audio import resample_plan
+
+        torch = self.torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 1 and x.is_contiguous()
+        n_in = int(x.numel())
+        up, down, taps, m0, n_out = resample_plan(up, down, n_in)
+        if up == down == 1:
+            return x.clone()
+        y = torch.empty(n_out, dtype=torch.float32, device=x.device)
+        rc = self.lib.qv_upfirdn(self.h, C.c_void_p(x.data_ptr()), n_in, taps.ctypes.data_as(C.c_void_p), len(taps),
+                                 up, down, m0, n_out, C.c_void_p(y.data_ptr()), self._stream())
+        self._check(rc, "qv_upfirdn")
+        return y
+
+    def speed_perturb(self, x, factor: float):
+        """0.9 = 10 % slower, 1.1 = 10 % faster (tta/run.py:60-71: up = int(factor * 10), down = 10)."""
+        return x if factor == 1.0 else self.resample_poly(x, int(factor * 10), 10)
 
     # ---------------------------------------------------------------- measurement
     GEMM_EPILOGUES = ["f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"]

@@ -22,7 +22,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .audio import load_audio, speed_perturb
+from .audio import load_audio
 
 _PROFILE = os.getenv("C2C_DIRECT_MIXED_PROFILE", "") not in ("", "0", "false", "False")
 CONFIDENCE_SKIP_THRESHOLD = 0.5  # c2c-direct-mixed-tta/run.py:57
@@ -131,11 +131,21 @@ def model_size() -> int:
 def predict_tta(audio_path: str) -> dict:
     """c2c-direct-mixed-tta/run.py:117-149: anchor pass, gate 0.5, 0.9x / 1.1x passes (batched
     into ONE engine call instead of two threads on one session), majority else score pick."""
+    import torch
+
     audio = load_audio(audio_path)
     anchor = predict_arrays([audio], round_score=False)[0]
     if anchor["score"] >= CONFIDENCE_SKIP_THRESHOLD:
         return anchor
-    p09, p11 = predict_arrays([speed_perturb(audio, 0.9), speed_perturb(audio, 1.1)], round_score=False)
+    # 0.9x / 1.1x copies are made on the GPU (qv_upfirdn, bit-identical to the reference's
+    # scipy.signal.resample_poly call) and go through the engine as one batch of two
+    eng = _ensure_engine()
+    dev = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).cuda(eng.device)
+    a09, a11 = eng.speed_perturb(dev, 0.9), eng.speed_perturb(dev, 1.1)
+    pair = torch.zeros((2, max(a09.numel(), a11.numel())), dtype=torch.float32, device=dev.device)
+    pair[0, : a09.numel()] = a09
+    pair[1, : a11.numel()] = a11
+    p09, p11 = (_to_dict(r, False) for r in eng.predict_batch(pair, [a09.numel(), a11.numel()]))
     preds = [p09, anchor, p11]
     keys = [(p["surah"], p["ayah"]) for p in preds]
     top, n = Counter(keys).most_common(1)[0]

@@ -96,6 +96,41 @@ def test_load_audio_wav_mono_and_resample(tmp_path):
         load_audio(str(tmp_path / "c.mp3"))
 
 
+def upfirdn_restatement(x, taps, up, down, m0, n_out):
+    """numpy restatement of k_upfirdn's arithmetic (include/qverse.h: qv_upfirdn): per output
+    sample, products accumulated in float32 in ascending input order."""
+    P = (len(taps) + up - 1) // up
+    hp = np.zeros(up * P, np.float32)
+    hp[: len(taps)] = taps
+    m = np.arange(m0, m0 + n_out, dtype=np.int64)
+    xi, t = (m * down) // up, (m * down) % up
+    acc = np.zeros(n_out, np.float32)
+    for j in range(P):
+        i = xi - (P - 1) + j
+        ok = (i >= 0) & (i < len(x))
+        prod = (x[np.clip(i, 0, len(x) - 1)] * hp[t + up * (P - 1 - j)]).astype(np.float32)
+        acc = np.where(ok, (acc + prod).astype(np.float32), acc)
+    return acc
+
+
+def test_resample_plan_and_fir_order_match_scipy_bitwise():
+    """a15: the host plan (taps, first kept sample, output count) + the kernel's summation order
+    reproduce scipy.signal.resample_poly on float32 input bit for bit."""
+    from scipy.signal import resample_poly
+
+    from offline_tarteel_amd.audio import resample_plan
+
+    rng = np.random.default_rng(3)
+    for n_in, (up, down) in ((16000, (9, 10)), (16001, (11, 10)), (777, (9, 10)), (5, (11, 10)), (4410, (160, 441)),
+                             (1000, (18, 20))):
+        x = rng.standard_normal(n_in).astype(np.float32)
+        u, d, taps, m0, n_out = resample_plan(up, down, n_in)
+        want = resample_poly(x, up, down)
+        assert want.dtype == np.float32 and len(want) == n_out
+        got = upfirdn_restatement(x, taps, u, d, m0, n_out)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n_in, up, down)
+
+
 def test_shard_plan_covers_batch_once():
     from offline_tarteel_amd.dist import shard_plan
 
