@@ -103,7 +103,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    # QVERSE_BENCH_FORCE_DIST=1 runs the collective path with a single rank too (1-GPU check of the
+    # RCCL plumbing under torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or os.environ.get("QVERSE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -124,7 +127,7 @@ def main():
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=n,
                  precision=1 if args.precision == "mixed" else 0, skip_unused_passes=not args.literal,
                  contexts=args.contexts)
-    gathered = torch.empty((world * B, 4), dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else None
+    gathered = torch.empty((world * B, 4), dtype=torch.int32, device=f"cuda:{local_rank}") if use_dist else None
     pending = []   # contexts whose packed rows have not been all-gathered yet
 
     def gather(ctx):
@@ -135,7 +138,7 @@ def main():
         # every step runs the WHOLE hot path on one batch; with contexts > 1 up to that many batches
         # are in flight, so the all-gather of a batch is issued (contexts - 1) steps later
         ctx = eng.predict_batch_async(audio, lengths)
-        if world > 1:
+        if use_dist:
             pending.append(ctx)
             if len(pending) >= args.contexts:
                 gather(pending.pop(0))
@@ -144,7 +147,7 @@ def main():
         while pending:
             gather(pending.pop(0))
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -156,7 +159,7 @@ def main():
         step()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -229,7 +232,10 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
+        # the last gathered block must hold this rank's own rows
+        own = gathered[rank * B: (rank + 1) * B].cpu()
+        assert own.shape == (B, 4)
         dist.destroy_process_group()
 
 
