@@ -17,6 +17,9 @@ void launch_melapply(const float *feats, const int32_t *n_samples, int tm_max, c
                      hipStream_t s);
 void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const double *stats, const float *w,
                   const float *bias, half_t *out, int t1_max, int batch, hipStream_t s);
+void launch_sub01(const float *feats, int tm_max, const int32_t *len_mel, const double *stats, const float *w0,
+                  const float *b0, const int32_t *len1, const float *w1, const float *b1, half_t *out, int t2_max, int batch,
+                  hipStream_t s);
 void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,
                      half_t *out, int tout_max, int fout, int batch, hipStream_t s);
 void launch_mask_rows(half_t *x, int t_max, int row_elems, const int32_t *len, int batch, hipStream_t s);

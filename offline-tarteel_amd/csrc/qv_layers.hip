@@ -223,6 +223,99 @@ __global__ __launch_bounds__(256) void k_dwconv2d(const half_t *__restrict__ in,
 
 // zero rows t >= len[b] of a channels-last f16 activation (so the next strided stage and the
 // out-projection see exactly what the unpadded single-utterance run sees)
+// conv0 + ReLU + first depthwise conv in one kernel: the [B][T1][40][256] activation (657 MB at
+// B = 64 x 10 s) never goes to HBM.  Block = (64-channel group, 4 output frames, utterance): the
+// 19 normalised mel rows it needs sit in LDS, the 9 x 40 x 64 conv0 tile is computed once into LDS
+// as f16 (same rounding as the two-kernel path), then the depthwise 3x3/s2 reads it from there.
+// Both convolutions are per-channel, so the only redundancy is the one-row halo (9 rows per 8).
+#define SUB_TT 4                    // c1 frames per block
+#define SUB_R1 (2 * SUB_TT + 1)     // c0 rows per block
+#define SUB_RM (2 * SUB_R1 + 1)     // mel rows per block
+#define SUB_CG 64                   // channels per block
+__global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_mel,
+                                               const double *__restrict__ stats, const float *__restrict__ w0t,
+                                               const float *__restrict__ b0, const int32_t *__restrict__ len1,
+                                               const float *__restrict__ w1t, const float *__restrict__ b1,
+                                               half_t *__restrict__ out, int t2_max) {
+    __shared__ float rows[SUB_RM][QV_NMEL + 2];
+    __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
+    __shared__ __attribute__((aligned(16))) half_t tile[SUB_R1][40][SUB_CG];
+    const int b = blockIdx.z, t2_0 = blockIdx.y * SUB_TT, cg = blockIdx.x * SUB_CG, tid = threadIdx.x;
+    const int tin = len_mel[b], l1 = len1[b];
+    const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
+    __syncthreads();
+    const int t1_0 = 2 * t2_0 - 1;         // first c0 row of the tile
+    const int tm_0 = 2 * t1_0 - 1;         // first mel row
+    for (int i = tid; i < SUB_RM * (QV_NMEL + 2); i += 256) {
+        int r = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = tm_0 + r;
+        rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? (x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f] : 0.f;
+    }
+    const int c8 = (tid & 7) * 8, pl = tid >> 3;   // 8 channels per thread, 32 positions per pass
+    float w[9][8], bs[8];
+    auto load_w = [&](const float *wt, const float *bias) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            f32x4 wa = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8), wb = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { w[k][c] = wa[c]; w[k][4 + c] = wb[c]; }
+        }
+        f32x4 ba = *(const f32x4 *)(bias + cg + c8), bb = *(const f32x4 *)(bias + cg + c8 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
+    };
+    load_w(w0t, b0);
+    __syncthreads();
+    // ---- conv0 + ReLU into the LDS tile (rows outside [0, l1) are the depthwise conv's zero padding)
+    for (int p = pl; p < SUB_R1 * 40; p += 32) {
+        int r = p / 40, f1 = p - r * 40, t1 = t1_0 + r;
+        half8 o;
+        if (t1 < 0 || t1 >= l1) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
+        } else {
+            float acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = bs[c];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    float v = rows[2 * r + dt][2 * f1 + df];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * v;
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] > 0.f ? acc[c] : 0.f);
+        }
+        *(half8 *)&tile[r][f1][c8] = o;
+    }
+    load_w(w1t, b1);
+    __syncthreads();
+    // ---- depthwise 3x3 stride 2 over the tile
+    for (int p = pl; p < SUB_TT * 20; p += 32) {
+        int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
+        if (t2 >= t2_max) continue;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = bs[c];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                int f = 2 * fo - 1 + df;
+                if (f < 0 || f >= 40) continue;
+                half8 v = *(const half8 *)&tile[2 * tl + dt][f][c8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * (float)v[c];
+            }
+        half8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
+        *(half8 *)(out + (((size_t)b * t2_max + t2) * 20 + fo) * QV_SUBC + cg + c8) = o;
+    }
+}
+
 __global__ void k_mask_rows(half_t *__restrict__ x, int t_max, int row_elems, const int32_t *__restrict__ len) {
     const int b = blockIdx.z, t = blockIdx.y;
     if (t < len[b]) return;
@@ -543,6 +636,13 @@ void launch_melapply(const float *feats, const int32_t *n_samples, int tm_max, c
 void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const double *stats, const float *w,
                   const float *bias, half_t *out, int t1_max, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k_conv0, dim3(1, t1_max, batch), dim3(256), 0, s, feats, tm_max, len_in, stats, w, bias, out, t1_max);
+}
+
+void launch_sub01(const float *feats, int tm_max, const int32_t *len_mel, const double *stats, const float *w0,
+                  const float *b0, const int32_t *len1, const float *w1, const float *b1, half_t *out, int t2_max, int batch,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_sub01, dim3(QV_SUBC / SUB_CG, (t2_max + SUB_TT - 1) / SUB_TT, batch), dim3(256), 0, s, feats, tm_max,
+                       len_mel, stats, w0, b0, len1, w1, b1, out, t2_max);
 }
 
 void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,

@@ -463,12 +463,16 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     m->save_taps = tp && tp[0] == '1';
     m->n_ctx = eng->n_ctx;
     m->cur_ctx = 0;
+    const char *su = getenv("QVERSE_SUB_UNFUSED");
+    const bool sub_unfused = su && su[0] == '1';
     for (QvActs &a : m->ctx_acts) { a = QvActs(); a.lens_host = nullptr; }
     for (int k = m->n_ctx - 1; k >= 0; --k) {
     m->lens_host = nullptr;
     TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
     TRY(dal(eng, m, Bz * QV_NMEL * 2, &m->mel_stats));
-    TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
+    // the conv0 activation only exists on the two-kernel cross-check path (QVERSE_SUB_UNFUSED=1)
+    m->c0 = nullptr;
+    if (sub_unfused) TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
     TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1));
     TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1p));
     TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2));
@@ -529,8 +533,13 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     TRY(get_pos(eng, m, T, s, &posp));
 
     launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, m->mel_stats, B, s);
-    launch_conv0(m->feats, tm_max, d_tm, m->mel_stats, m->c0_w, m->c0_b, m->c0, t1m, B, s);
-    launch_dwconv2d(m->c0, t1m, 40, d_l1, m->dw2_w, m->dw2_b, m->c1, t2m, 20, B, s);
+    if (m->c0) {
+        // cross-check path: conv0 and the depthwise conv as two kernels through HBM
+        launch_conv0(m->feats, tm_max, d_tm, m->mel_stats, m->c0_w, m->c0_b, m->c0, t1m, B, s);
+        launch_dwconv2d(m->c0, t1m, 40, d_l1, m->dw2_w, m->dw2_b, m->c1, t2m, 20, B, s);
+    } else {
+        launch_sub01(m->feats, tm_max, d_tm, m->mel_stats, m->c0_w, m->c0_b, d_l1, m->dw2_w, m->dw2_b, m->c1, t2m, B, s);
+    }
     GemmArgs g = {};
     g.alpha = 1.f;
     g.A = m->c1; g.W = m->pw3_w; g.bias = m->pw3_b; g.out = m->c1p;

@@ -141,6 +141,127 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
     }
 }
 
+// k_gemm3: as k_gemm2 but B is prefetched TWO K-steps ahead (three register sets) and A has NST
+// stages, so that every operand has >= 2 K-steps of latency cover.
+template <int BN, int WMW, int NST>
+__global__ __launch_bounds__(256) void k_gemm3(GemmArgs g, const half8 *Wf) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WNW = 4 / WMW;
+    constexpr int MI = BM / (WMW * 32), NF = BN / (WNW * 32);
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int NB = NF * 4;  // B loads per wave per K-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gx + blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
+    const int nk = g.K / BK, k16n = g.K / 16;
+
+    f32x16 acc[MI][NF];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stageA = [&](int kt) {
+        half_t *sA = (half_t *)(smem + (kt % NST) * A_BYTES);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int chunk = wave * 4 + q;
+            int row = chunk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            int grow = m0 + row;
+            grow = grow < g.M ? grow : g.M - 1;
+            glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
+        }
+    };
+    const half8 *wbase = Wf + ((size_t)((n0 >> 5) + wn * NF) * k16n) * 64 + lane;
+    auto loadB = [&](int kt, half8 (&b)[NF][4]) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) b[j][ks] = wbase[((size_t)j * k16n + kt * 4 + ks) * 64];
+    };
+    auto compute = [&](int kt, half8 (&b)[NF][4]) {
+        const half_t *sA = (const half_t *)(smem + (kt % NST) * A_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 a[MI];
+            int c = ks * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int row = wm * (MI * 32) + i * 32 + (lane & 31);
+                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j][ks], a[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    // issue order inside a K-step: B(kt+2) then A(kt+NST-1).  Loads issued after A(kt) when step
+    // kt starts: (NST-2) steps x (NB + 4) -- exact only while nothing was skipped, else drain.
+    auto step = [&](int kt, half8 (&use)[NF][4], half8 (&ld)[NF][4]) {
+        if (kt + 2 < nk && kt + NST - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NB + 4)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) loadB(kt + 2, ld);
+        if (kt + NST - 1 < nk) stageA(kt + NST - 1);
+        compute(kt, use);
+    };
+
+    half8 s0[NF][4], s1[NF][4], s2[NF][4];
+    loadB(0, s0);
+    if (nk > 1) loadB(1, s1);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stageA(s);
+    for (int kt = 0; kt < nk; kt += 3) {
+        step(kt, s0, s2);
+        if (kt + 1 < nk) step(kt + 1, s1, s0);
+        if (kt + 2 < nk) step(kt + 2, s2, s1);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int LDT = BN + 8;
+    half_t *sO = (half_t *)smem;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rl = wm * (MI * 32) + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = wn * (NF * 32) + j * 32 + 8 * q + 4 * hi;
+                f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][q * 4 + e] + bb[e];
+                    x = x * sigmoidf_(x);
+                    o[e] = (half_t)x;
+                }
+                *(half4 *)(sO + rl * LDT + cl) = o;
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+        int r = idx / CPR, c = (idx % CPR) * 8;
+        if (m0 + r >= g.M) continue;
+        *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c) = *(const half8 *)(sO + r * LDT + c);
+    }
+}
+
 static float frand(uint64_t &s) {
     s = s * 6364136223846793005ull + 1442695040888963407ull;
     return ((float)((s >> 33) & 0xFFFFFF) / 8388608.0f) - 1.0f;
@@ -172,6 +293,41 @@ static void run2(const char *name, GemmArgs g, const half8 *Wf, int iters, const
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / iters, fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s N%-5d K%-5d %8.2f us %7.1f TF/s maxerr %.2e\n", name, g.N, g.K, us, fl / us / 1e6, maxerr);
+}
+
+typedef void (*kern_t)(GemmArgs, const half8 *);
+
+static void run_k(const char *name, kern_t kern, int BN, int NST, GemmArgs g, const half8 *Wf, int iters,
+                  const std::vector<half_t> &hA, const std::vector<half_t> &hW, const std::vector<float> &hb) {
+    dim3 grid(g.N / BN, (g.M + 127) / 128);
+    size_t lds = (size_t)NST * 128 * 64 * 2, epi = (size_t)128 * (BN + 8) * 2;
+    if (epi > lds) lds = epi;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(g.out, 0, (size_t)g.M * g.ldo * 2));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, g, Wf);
+    CK(hipDeviceSynchronize());
+    std::vector<half_t> ho((size_t)g.M * g.ldo);
+    CK(hipMemcpy(ho.data(), g.out, ho.size() * 2, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 256; ++t) {
+        int r = (t * 977 + 13) % g.M, c = (t * 131 + 7) % g.N;
+        double a = 0;
+        for (int k = 0; k < g.K; ++k) a += (double)(float)hA[(size_t)r * g.K + k] * (double)(float)hW[(size_t)c * g.K + k];
+        a += hb[c];
+        double want = a / (1.0 + exp(-a));
+        maxerr = fmax(maxerr, fabs(want - (double)(float)ho[(size_t)r * g.ldo + c]));
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, g, Wf);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, g, Wf);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -222,18 +378,13 @@ int main(int argc, char **argv) {
             printf("%-34s N%-5d K%-5d %8.2f us %7.1f TF/s\n", "baseline (product kernel)", N, K, us, 2.0 * M * N * K / us / 1e6);
         }
         const half8 *Wf = (const half8 *)dWf;
-        run2<128, 1, 2, 1>("BN128 1x4 NST2 no-store", g, Wf, iters, hA, hW, hb);
-        run2<128, 1, 2, 2>("BN128 1x4 NST2 2-iter-loop", g, Wf, iters, hA, hW, hb);
-        run2<128, 2, 2>("BN128 2x2 NST2", g, Wf, iters, hA, hW, hb);
-        run2<128, 2, 3>("BN128 2x2 NST3", g, Wf, iters, hA, hW, hb);
-        run2<128, 2, 4>("BN128 2x2 NST4", g, Wf, iters, hA, hW, hb);
         run2<128, 1, 2>("BN128 1x4 NST2", g, Wf, iters, hA, hW, hb);
-        run2<128, 1, 3>("BN128 1x4 NST3", g, Wf, iters, hA, hW, hb);
-        run2<128, 1, 4>("BN128 1x4 NST4", g, Wf, iters, hA, hW, hb);
-        run2<64, 2, 3>("BN64  2x2 NST3", g, Wf, iters, hA, hW, hb);
-        run2<64, 2, 4>("BN64  2x2 NST4", g, Wf, iters, hA, hW, hb);
-        run2<256, 2, 3>("BN256 2x2 NST3", g, Wf, iters, hA, hW, hb);
-        run2<256, 1, 3>("BN256 1x4 NST3", g, Wf, iters, hA, hW, hb);
+        run_k("deep BN128 1x4 NST3", k_gemm3<128, 1, 3>, 128, 3, g, Wf, iters, hA, hW, hb);
+        run_k("deep BN128 1x4 NST4", k_gemm3<128, 1, 4>, 128, 4, g, Wf, iters, hA, hW, hb);
+        run_k("deep BN128 2x2 NST3", k_gemm3<128, 2, 3>, 128, 3, g, Wf, iters, hA, hW, hb);
+        run_k("deep BN128 2x2 NST4", k_gemm3<128, 2, 4>, 128, 4, g, Wf, iters, hA, hW, hb);
+        run_k("deep BN64  2x2 NST4", k_gemm3<64, 2, 4>, 64, 4, g, Wf, iters, hA, hW, hb);
+        run_k("deep BN64  1x2? 2x2 NST3", k_gemm3<64, 2, 3>, 64, 3, g, Wf, iters, hA, hW, hb);
         CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dWf)); CK(hipFree(dO)); CK(hipFree(db));
     }
     return 0;
