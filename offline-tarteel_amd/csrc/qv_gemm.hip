@@ -189,7 +189,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + wm * 64 + i * 32 + l31;
             if (row >= g.M) continue;
-            int b = row / g.t_max, t = row - b * g.t_max;
+            // rows are packed utterance after utterance: find the owner (<= 7 probes at B = 64)
+            int b = 0, hi_b = g.n_utt;
+            while (hi_b - b > 1) {
+                int mid = (b + hi_b) >> 1;
+                if (g.row_off[mid] <= row) b = mid;
+                else hi_b = mid;
+            }
+            const int t = row - g.row_off[b];
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll

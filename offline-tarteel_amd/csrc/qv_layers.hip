@@ -316,12 +316,15 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
     }
 }
 
-__global__ void k_mask_rows(half_t *__restrict__ x, int t_max, int row_elems, const int32_t *__restrict__ len) {
+// dense [B][t_max][row_elems] -> packed [sum of len][row_elems]: utterance b's valid frames become
+// rows row_off[b] .. row_off[b] + len[b] - 1 (from here on padding frames do not exist)
+__global__ void k_pack_rows(const half_t *__restrict__ x, int t_max, int row_elems, const int32_t *__restrict__ len,
+                            const int32_t *__restrict__ row_off, half_t *__restrict__ y) {
     const int b = blockIdx.z, t = blockIdx.y;
-    if (t < len[b]) return;
-    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    half_t *p = x + ((size_t)b * t_max + t) * row_elems;
-    for (int i = threadIdx.x * 8; i < row_elems; i += blockDim.x * 8) *(half8 *)(p + i) = z;
+    if (t >= len[b]) return;
+    const half_t *p = x + ((size_t)b * t_max + t) * row_elems;
+    half_t *q = y + ((size_t)row_off[b] + t) * row_elems;
+    for (int i = threadIdx.x * 8; i < row_elems; i += blockDim.x * 8) *(half8 *)(q + i) = *(const half8 *)(p + i);
 }
 
 // ------------------------------------------------------------------ LayerNorm ----------
@@ -403,31 +406,27 @@ __global__ void k_to_half(const float *__restrict__ x, half_t *__restrict__ y, s
 __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
                                                    const half_t *__restrict__ pos, int pos_ld, const float *__restrict__ bias_u,
                                                    const float *__restrict__ bias_v, const int32_t *__restrict__ len,
-                                                   half_t *__restrict__ out, int t_max, int t_pad) {
+                                                   const int32_t *__restrict__ row_off, half_t *__restrict__ out, int t_max,
+                                                   int t_pad) {
     __shared__ float slab[4][32 * ATT_LDS_LD];
     const int b = blockIdx.y, h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int T = len[b];
+    const size_t row0 = (size_t)row_off[b];   // activations are packed: utterance b owns rows [row0, row0 + T)
     const int l31 = lane & 31, hi = lane >> 5;
-    const half_t *qb = qk + (size_t)b * t_max * (2 * QV_D) + h * QV_DK;            // q row stride 1024
+    const half_t *qb = qk + row0 * (2 * QV_D) + h * QV_DK;                           // q row stride 1024
     const half_t *kb = qb + QV_D;
     const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;                  // [64][t_pad]
     const half_t *pb = pos + h * QV_DK;                                             // [2*t_max-1][pos_ld]
     const int n_qt = (T + 31) >> 5, n_kt = (T + 31) >> 5;
     float *sl = slab[wave];
-    for (int qt = wave; qt < (t_max + 31) / 32; qt += 4) {
+    for (int qt = wave; qt < n_qt; qt += 4) {
         const int i0 = qt * 32;
-        half_t *orow = out + ((size_t)b * t_max + i0) * QV_D + h * QV_DK;
-        if (qt >= n_qt) {
-            // padded query rows: defined output (zeros)
-            for (int r = 0; r < 32 && i0 + r < t_max; ++r)
-                if (lane < 8) *(half8 *)(orow + (size_t)r * QV_D + lane * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            continue;
-        }
+        half_t *orow = out + (row0 + i0) * QV_D + h * QV_DK;
         // B fragments (queries on the column axis): (q+u) and (q+v), row i0 + l31, d = ks*16 + hi*8..
         half8 qu[4], qv[4];
         {
             int qi = i0 + l31;
-            qi = qi < t_max ? qi : t_max - 1;
+            qi = qi < T ? qi : T - 1;   // never touch another utterance's rows
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 int d = ks * 16 + hi * 8;
@@ -447,7 +446,7 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
         for (int kt = 0; kt < n_kt; ++kt) {
             const int j0 = kt * 32;
             int kj = j0 + l31;
-            kj = kj < t_max ? kj : t_max - 1;
+            kj = kj < T ? kj : T - 1;
             // relative-position rows for this tile: rr0 + c, c in [0,64)
             const int rr0 = t_max - 1 - i0 - 31 + j0;
             int pr0 = rr0 + l31, pr1 = rr0 + 32 + l31;
@@ -519,8 +518,8 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
             }
         }
         // O^T column (query i0 + l31): d = (r&3) + 8*(r>>2) + 4*hi (+32)
-        if (i0 + l31 < t_max) {
-            float inv = (i0 + l31 < T) ? 1.f / l_run : 0.f;
+        if (i0 + l31 < T) {
+            float inv = 1.f / l_run;
             half_t *o = orow + (size_t)l31 * QV_D;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -543,10 +542,11 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 #define DW_TT 4
 __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, const float *__restrict__ wt /*[9][512]*/,
                                                   const float *__restrict__ bias, const int32_t *__restrict__ len,
-                                                  half_t *__restrict__ y, int t_max) {
+                                                  const int32_t *__restrict__ row_off, half_t *__restrict__ y) {
     const int b = blockIdx.y, t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DW_TT, lane = threadIdx.x & 63;
-    if (t0 >= t_max) return;
     const int T = len[b], c0 = lane * 8;
+    if (t0 >= T) return;
+    const size_t row0 = (size_t)row_off[b];   // packed rows of utterance b
     float w[9][8], bs[8];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, 
     for (int i = 0; i < DW_TT + 8; ++i) {
         int tt = t0 - 4 + i;
         if (tt < 0 || tt >= T) continue;
-        half8 v = *(const half8 *)(x + ((size_t)b * t_max + tt) * QV_D + c0);
+        half8 v = *(const half8 *)(x + (row0 + tt) * QV_D + c0);
         float vf[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) vf[c] = (float)v[c];
@@ -582,19 +582,28 @@ __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, 
     }
 #pragma unroll
     for (int j = 0; j < DW_TT; ++j) {
-        if (t0 + j >= t_max) break;
+        if (t0 + j >= T) break;
         half8 o;
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[j][c] * sigmoidf_(acc[j][c]));
-        *(half8 *)(y + ((size_t)b * t_max + t0 + j) * QV_D + c0) = o;
+        *(half8 *)(y + (row0 + t0 + j) * QV_D + c0) = o;
     }
 }
 
 // ------------------------------------------------------------------ log-softmax --------
 // logits f32 [M][ld] (first 1025 valid) -> log-probs f32 [B][t_max][1025]; one wave per row.
-__global__ __launch_bounds__(256) void k_logsoftmax(const float *__restrict__ logits, int ld, float *__restrict__ out, int M) {
+__global__ __launch_bounds__(256) void k_logsoftmax(const float *__restrict__ logits, int ld, float *__restrict__ out, int M,
+                                                    const int32_t *__restrict__ row_off, int n_utt, int t_out) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
+    // packed row -> (utterance, frame); the caller's log-prob tensor is dense [B][t_out][1025]
+    int ub = 0, uh = n_utt;
+    while (uh - ub > 1) {
+        int mid = (ub + uh) >> 1;
+        if (row_off[mid] <= row) ub = mid;
+        else uh = mid;
+    }
+    const size_t orow = (size_t)ub * t_out + (row - row_off[ub]);
     const float *p = logits + (size_t)row * ld;
     float v[17];
     float mx = -INFINITY;
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(256) void k_logsoftmax(const float *__restrict__ lo
 #pragma unroll
     for (int i = 0; i < 17; ++i) s += (lane + 64 * i < 1025) ? expf(v[i] - mx) : 0.f;
     float lse = mx + logf(wave_sum(s));
-    float *o = out + (size_t)row * 1025;
+    float *o = out + orow * 1025;
 #pragma unroll
     for (int i = 0; i < 17; ++i) {
         int c = lane + 64 * i;
@@ -651,8 +660,9 @@ void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_
                        tout_max, fout);
 }
 
-void launch_mask_rows(half_t *x, int t_max, int row_elems, const int32_t *len, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_mask_rows, dim3(1, t_max, batch), dim3(256), 0, s, x, t_max, row_elems, len);
+void launch_pack_rows(const half_t *x, int t_max, int row_elems, const int32_t *len, const int32_t *row_off, half_t *y,
+                      int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_rows, dim3(1, t_max, batch), dim3(256), 0, s, x, t_max, row_elems, len, row_off, y);
 }
 
 void launch_layernorm(const float *x, const float *g, const float *b, half_t *y, int M, hipStream_t s) {
@@ -670,17 +680,20 @@ void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s) {
 }
 
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
-                      const int32_t *len, half_t *out, int t_max, int t_pad, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, out, t_max, t_pad);
+                      const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_pad, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out, t_max,
+                       t_pad);
 }
 
-void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, half_t *y, int t_max, int batch,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(k_dwconv1d, dim3((t_max + 4 * DW_TT - 1) / (4 * DW_TT), batch), dim3(256), 0, s, x, w, bias, len, y, t_max);
+void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,
+                     int t_max, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_dwconv1d, dim3((t_max + 4 * DW_TT - 1) / (4 * DW_TT), batch), dim3(256), 0, s, x, w, bias, len, row_off,
+                       y);
 }
 
-void launch_logsoftmax(const float *logits, int ld, float *out, int M, hipStream_t s) {
-    hipLaunchKernelGGL(k_logsoftmax, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, out, M);
+void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_off, int n_utt, int t_out,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_logsoftmax, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, out, M, row_off, n_utt, t_out);
 }
 
 // ---------------------------------------------------------------- a15: polyphase resampler ----

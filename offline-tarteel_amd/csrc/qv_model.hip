@@ -166,11 +166,11 @@ struct LayerW {
 struct QvActs {
     float *feats, *x, *logits;
     double *mel_stats;   // [max_batch][80][2] per-feature sum / sum of squares
-    half_t *c0, *c1, *c1p, *c2, *c2p, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
-    int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3
+    half_t *c0, *c1, *c1p, *c2, *c2p, *c2k, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
+    int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3; then [max_batch + 1] packed row offsets
     int32_t *lens_host;  // pinned
     float *tap_x;        // [N_LAYERS+1][M][512] when save_taps
-    int last_batch, last_tmax, last_tm_max;
+    int last_batch, last_tmax, last_tm_max, last_rows;
 };
 
 // the flat QvActs base is the CURRENT context (qv_model_select_ctx copies it in and out)
@@ -477,6 +477,7 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1p));
     TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2));
     TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2p));
+    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2k));
     TRY(dal(eng, m, M * QV_D, &m->x));
     TRY(dal(eng, m, M * QV_D, &m->ln));
     TRY(dal(eng, m, M * QV_FF, &m->hbuf));
@@ -487,12 +488,12 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     TRY(dal(eng, m, M * QV_D, &m->dw));
     TRY(dal(eng, m, M * QV_D, &m->xh));
     TRY(dal(eng, m, M * HEAD_N, &m->logits));
-    TRY(dal(eng, m, Bz * 5, &m->lens_dev));
-    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * Bz * 5, hipHostMallocDefault));
+    TRY(dal(eng, m, Bz * 6 + 1, &m->lens_dev));
+    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * (Bz * 6 + 1), hipHostMallocDefault));
     m->ctx_acts[k].lens_host = m->lens_host;  // owned by the context from here on
     m->tap_x = nullptr;
     if (m->save_taps) TRY(dal(eng, m, (size_t)(N_LAYERS + 1) * M * QV_D, &m->tap_x));
-    m->last_batch = m->last_tmax = m->last_tm_max = 0;
+    m->last_batch = m->last_tmax = m->last_tm_max = m->last_rows = 0;
     m->ctx_acts[k] = *static_cast<QvActs *>(m);
     }  // contexts, allocated last to first so that the flat fields end up being context 0
     return QV_OK;
@@ -510,7 +511,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
                      float *logprobs, int t_max_out, int32_t *t_out_host, hipStream_t s) {
     if (batch < 1 || batch > m->max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
     int B = batch, MB = m->max_batch;
-    int tm_max = 0, t1m = 0, t2m = 0, t3m = 0;
+    int tm_max = 0, t1m = 0, t2m = 0, t3m = 0, rows = 0;
     int32_t *lh = m->lens_host;
     for (int b = 0; b < B; ++b) {
         int64_t n = len_host[b];
@@ -522,13 +523,21 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         lh[0 * MB + b] = (int32_t)n; lh[1 * MB + b] = tm; lh[2 * MB + b] = l1; lh[3 * MB + b] = l2; lh[4 * MB + b] = l3;
         tm_max = std::max(tm_max, tm); t1m = std::max(t1m, l1); t2m = std::max(t2m, l2); t3m = std::max(t3m, l3);
         t_out_host[b] = l3;
+        lh[5 * MB + b] = rows;   // first packed row of utterance b
+        rows += l3;
     }
+    lh[5 * MB + B] = rows;
     if (t_max_out < t3m) { qv_set_error(eng, "t_max smaller than the longest utterance's frame count"); return QV_ERR_ARG; }
-    const int T = t3m;   // dense row stride of every [M][*] activation
-    const int M = B * T;
+    // Encoder activations are PACKED: utterance b owns rows [off[b], off[b] + l3[b]) of every [M][*]
+    // tensor and M = sum of the valid frame counts, so a ragged batch pays for no padding frames
+    // (equal lengths give off[b] = b * T, the dense layout).  T = longest utterance: attention tile
+    // count, relative-position table, Vt row pitch.
+    const int T = t3m;
+    const int M = rows;
     const int t_pad = (T + 31) / 32 * 32;
-    QV_HIP(hipMemcpyAsync(m->lens_dev, lh, sizeof(int32_t) * MB * 5, hipMemcpyHostToDevice, s));
-    const int32_t *d_n = m->lens_dev, *d_tm = d_n + MB, *d_l1 = d_n + 2 * MB, *d_l2 = d_n + 3 * MB, *d_l3 = d_n + 4 * MB;
+    QV_HIP(hipMemcpyAsync(m->lens_dev, lh, sizeof(int32_t) * (MB * 6 + 1), hipMemcpyHostToDevice, s));
+    const int32_t *d_n = m->lens_dev, *d_tm = d_n + MB, *d_l1 = d_n + 2 * MB, *d_l2 = d_n + 3 * MB, *d_l3 = d_n + 4 * MB,
+                  *d_off = d_n + 5 * MB;
     const half_t *posp = nullptr;
     TRY(get_pos(eng, m, T, s, &posp));
 
@@ -548,9 +557,9 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     launch_dwconv2d(m->c1p, t2m, 20, d_l2, m->dw5_w, m->dw5_b, m->c2, t3m, 10, B, s);
     g.A = m->c2; g.W = m->pw6_w; g.bias = m->pw6_b; g.out = m->c2p; g.M = B * t3m * 10;
     launch_gemm(EPI_F16_RELU, g, s);
-    launch_mask_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, B, s);
+    launch_pack_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, d_off, m->c2k, B, s);
     // Linear(2560 -> 512) and xscaling (x * sqrt(d_model)) in one epilogue
-    g.A = m->c2p; g.W = m->sub_out_w; g.bias = m->sub_out_b; g.out = m->x;
+    g.A = m->c2k; g.W = m->sub_out_w; g.bias = m->sub_out_b; g.out = m->x;
     g.M = M; g.N = QV_D; g.K = 2560; g.lda = 2560; g.ldw = 2560; g.ldo = QV_D; g.alpha = sqrtf((float)QV_D);
     launch_gemm(EPI_F32, g, s);
     if (m->save_taps) QV_HIP(hipMemcpyAsync(m->tap_x, m->x, sizeof(float) * (size_t)M * QV_D, hipMemcpyDeviceToDevice, s));
@@ -563,6 +572,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             GemmArgs a = {};
             a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.bias = bias; a.out = out; a.out2 = m->vt;
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
+            a.row_off = d_off; a.n_utt = B;
             launch_gemm(epi, a, s);
         };
         // 1/2 FFN
@@ -571,12 +581,12 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         // rel-pos MHSA
         launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         gemm(EPI_QKV, m->ln, QV_D, L.qkv_w, L.qkv_b, m->qk, 3 * QV_D, 2 * QV_D, 1.f);
-        launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, m->att, T, t_pad, B, s);
+        launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
         gemm(EPI_RESID, m->att, QV_D, L.out_w, L.out_b, m->x, QV_D, QV_D, 1.f);
         // conv module
         launch_layernorm(m->x, L.ln_g[2], L.ln_b[2], m->ln, M, s);
         gemm(EPI_GLU, m->ln, QV_D, L.pw1_w, L.pw1_b, m->glu, 2 * QV_D, QV_D, 1.f);
-        launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, m->dw, T, B, s);
+        launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, d_off, m->dw, T, B, s);
         gemm(EPI_RESID, m->dw, QV_D, L.pw2_w, L.pw2_b, m->x, QV_D, QV_D, 1.f);
         // 1/2 FFN
         launch_layernorm(m->x, L.ln_g[3], L.ln_b[3], m->ln, M, s);
@@ -598,14 +608,10 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         a.M = M; a.N = HEAD_N; a.K = QV_D; a.lda = QV_D; a.ldw = QV_D; a.ldo = HEAD_N; a.alpha = 1.f;
         launch_gemm(EPI_F32, a, s);
     }
-    if (t_max_out == T) launch_logsoftmax(m->logits, HEAD_N, logprobs, M, s);
-    else {
-        // caller's row stride differs from the dense one: one launch per utterance
-        for (int b = 0; b < B; ++b)
-            launch_logsoftmax(m->logits + (size_t)b * T * HEAD_N, HEAD_N, logprobs + (size_t)b * t_max_out * QV_VOCAB, T, s);
-    }
+    // packed logits -> the caller's dense [B][t_max_out][1025] log-prob tensor (valid frames only)
+    launch_logsoftmax(m->logits, HEAD_N, logprobs, M, d_off, B, t_max_out, s);
     QV_HIP(hipGetLastError());
-    m->last_batch = B; m->last_tmax = T; m->last_tm_max = tm_max;
+    m->last_batch = B; m->last_tmax = T; m->last_tm_max = tm_max; m->last_rows = M;
     return QV_OK;
 }
 
@@ -615,12 +621,13 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
 // out-projection, 4 pointwise-conv + GLU.  The residual variants run with alpha = 0 so replaying
 // them does not disturb the stream.
 int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s) {
-    int M = m->last_batch * m->last_tmax;
+    int M = m->last_rows;
     if (M <= 0 || iters < 1) { qv_set_error(eng, "replay needs a previous forward"); return QV_ERR_ARG; }
     const LayerW &L = m->L[0];
     GemmArgs a = {};
     int epi;
     a.M = M; a.out2 = m->vt; a.t_max = m->last_tmax; a.t_pad = (m->last_tmax + 31) / 32 * 32; a.alpha = 1.f;
+    a.row_off = m->lens_dev + 5 * m->max_batch; a.n_utt = m->last_batch;
     const WMat *W;
     switch (which) {
         case 0: epi = EPI_F16_SWISH; a.A = m->ln; W = &L.ff1_w1; a.bias = L.ff1_b1; a.out = m->hbuf; a.N = QV_FF; a.K = QV_D; a.ldo = QV_FF; break;
@@ -650,7 +657,7 @@ int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, doubl
 }
 
 int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hipStream_t s) {
-    size_t M = (size_t)m->last_batch * m->last_tmax;
+    size_t M = (size_t)m->last_rows;
     if (what == 0) {
         // normalised features are never materialised on the fast path (conv0 normalises on load)
         launch_melapply(m->feats, m->lens_dev, m->last_tm_max, m->mel_stats, out, m->last_batch, s);
@@ -658,7 +665,15 @@ int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hi
         if (!m->save_taps) { qv_set_error(eng, "set QVERSE_DEBUG_TAPS=1 before creating the engine"); return QV_ERR_ARG; }
         int idx = what == 1 ? 0 : layer + 1;
         if (idx < 0 || idx > N_LAYERS) return QV_ERR_ARG;
-        QV_HIP(hipMemcpyAsync(out, m->tap_x + (size_t)idx * M * QV_D, sizeof(float) * M * QV_D, hipMemcpyDeviceToDevice, s));
+        // unpack to the dense [B][t_max][512] view the tests read (padding frames zero)
+        const int T = m->last_tmax;
+        QV_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)m->last_batch * T * QV_D, s));
+        for (int b = 0; b < m->last_batch; ++b) {
+            const int32_t *off = m->lens_host + 5 * m->max_batch;   // offsets of this context's last forward
+            int r0 = off[b], n = off[b + 1] - r0;
+            QV_HIP(hipMemcpyAsync(out + (size_t)b * T * QV_D, m->tap_x + ((size_t)idx * M + r0) * QV_D,
+                                  sizeof(float) * (size_t)n * QV_D, hipMemcpyDeviceToDevice, s));
+        }
     }
     QV_HIP(hipStreamSynchronize(s));
     return QV_OK;

@@ -283,48 +283,6 @@ class Engine:
         self._check(rc, "qv_fetch_results_ctx")
         return self._results(res, greedy)
 
-    @staticmethod
-    def length_buckets(lengths, max_batch: int, keep: float = 0.8, min_rows: int = 8) -> list[list[int]]:
-        """Split a ragged batch into sub-batches of similar length (indices into `lengths`, longest
-        first): a bucket is closed when the next utterance is shorter than `keep` x the bucket's
-        longest one (and the bucket already has `min_rows` rows) or when it is full.  Every
-        activation of the model is dense [rows x T_max], so padding is paid in every kernel."""
-        order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
-        buckets: list[list[int]] = []
-        for i in order:
-            cur = buckets[-1] if buckets else None
-            if cur is not None and len(cur) < max_batch and (
-                    int(lengths[i]) >= keep * int(lengths[cur[0]]) or len(cur) < min_rows):
-                cur.append(i)
-            else:
-                buckets.append([i])
-        return buckets
-
-    def predict_ragged(self, audio, lengths, keep: float = 0.8, min_rows: int = 8) -> list[dict]:
-        """predict_batch for a batch of very different lengths: length-bucketed sub-batches, one
-        engine call each, pipelined over the engine's contexts; results in the caller's order."""
-        torch = self.torch
-        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
-        out: list = [None] * len(lengths)
-        inflight = []
-
-        def join():
-            ctx, idx, sub, t_max = inflight.pop(0)
-            for i, r in zip(idx, self.fetch_results(ctx, len(idx), t_max)):
-                out[i] = r
-
-        for idx in self.length_buckets(lengths, self.max_batch, keep, min_rows):
-            n = int(lengths[idx[0]])
-            sub = audio[torch.as_tensor(idx, device=audio.device), :n].contiguous()
-            lens = [int(lengths[i]) for i in idx]
-            if len(inflight) >= max(1, self.contexts):
-                join()
-            ctx = self.predict_batch_async(sub, lens)
-            inflight.append((ctx, idx, sub, self.frames_for(n)))   # `sub` must outlive the batch
-        while inflight:
-            join()
-        return out
-
     def packed_results(self, batch: int, ctx: int | None = None):
         """int32 cuda tensor [batch, 4] = (surah, ayah, ayah_end, float-bits(score)) of the last
         async call -- or, with batches in flight, of context `ctx` (joined on the current stream).

@@ -271,25 +271,6 @@ def test_batches_in_flight_equal_one_at_a_time(setup):
         eng.close()
 
 
-def test_predict_ragged_equals_predict_batch(setup):
-    """the length-bucketing scheduler only regroups utterances; answers are those of predict_batch
-    on the same utterance (batch invariance), for 1 and for 3 contexts."""
-    from offline_tarteel_amd.engine import Engine
-
-    audio = torch.from_numpy(synth_audio(4, 64000, seed=21)).cuda()
-    lens = [64000, 20000, 51000, 33000]
-    for b, n in enumerate(lens):
-        audio[b, n:] = 0
-    want = setup["eng"].predict_batch(audio.contiguous(), lens, want_text=False)
-    assert setup["eng"].predict_ragged(audio, lens, keep=0.9, min_rows=1) == want
-    eng = Engine(device=0, with_model=True, seed=SEED, max_batch=4, max_samples=80000, contexts=3)
-    try:
-        assert eng.predict_ragged(audio, lens, keep=0.9, min_rows=1) == want
-        assert eng.predict_ragged(audio, lens) == want        # one bucket
-    finally:
-        eng.close()
-
-
 def test_fused_subsampling_equals_two_kernel_path(setup, monkeypatch):
     """k_sub01 (conv0 + ReLU + first depthwise conv through LDS) against the same two convolutions
     as separate kernels through HBM (QVERSE_SUB_UNFUSED=1): bit-identical log-probs."""

@@ -173,20 +173,3 @@ def test_all_gather_results_gloo_world2(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
 
-
-def test_length_buckets_partition_and_bounds():
-    from offline_tarteel_amd.engine import Engine
-
-    rng = np.random.default_rng(1)
-    lens = [int(x) for x in rng.integers(80000, 480001, size=64)]
-    for keep, min_rows, cap in ((0.8, 8, 64), (0.9, 1, 16), (0.5, 4, 7)):
-        b = Engine.length_buckets(lens, cap, keep, min_rows)
-        assert sorted(i for g in b for i in g) == list(range(64))          # a partition
-        flat = [lens[i] for g in b for i in g]
-        assert flat == sorted(lens, reverse=True)                           # longest first, contiguous
-        for g in b:
-            assert 1 <= len(g) <= cap
-            tail = [lens[i] for i in g[min_rows:]]
-            assert all(x >= keep * lens[g[0]] for x in tail)                # bounded padding past min_rows
-    assert Engine.length_buckets([], 8) == []
-    assert Engine.length_buckets([5], 8) == [[0]]

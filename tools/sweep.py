@@ -64,22 +64,6 @@ def main():
                      "audio_seconds_per_s": round(secs * args.steps / dt, 1),
                      "encoder_frames_max": eng.frames_for(n)})
         print(json.dumps(rows[-1]), flush=True)
-        if name.startswith("mixed"):
-            # same batch through the length-bucketing scheduler (results fetched per sub-batch)
-            for _ in range(2):
-                eng.predict_ragged(audio, lens)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                eng.predict_ragged(audio, lens)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            rows.append({"case": name + "_bucketed", "batch": B, "audio_seconds_per_batch": round(secs, 1),
-                         "ms_per_batch": round(dt / args.steps * 1e3, 3),
-                         "utterances_per_s": round(B * args.steps / dt, 1),
-                         "audio_seconds_per_s": round(secs * args.steps / dt, 1),
-                         "sub_batches": [len(b) for b in eng.length_buckets(lens, B)]})
-            print(json.dumps(rows[-1]), flush=True)
     doc = {"what": "c2c-direct-mixed hot path, one MI355X, synthetic clips resident in HBM, whole path per batch",
            "batches_in_flight": args.contexts, "weights": args.precision, "steps": args.steps, "rows": rows}
     if args.out:
