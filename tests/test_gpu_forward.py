@@ -286,3 +286,23 @@ def test_fused_subsampling_equals_two_kernel_path(setup, monkeypatch):
             assert torch.equal(lp[i, :n], setup["lp"][i, :n])
     finally:
         eng.close()
+
+
+def test_tiny_and_long_utterances_share_a_packed_batch(setup):
+    """shortest legal clip (400 samples -> 1 encoder frame) next to long ones: packed rows of very
+    different lengths, reference parity on every valid frame and exact batch invariance."""
+    eng, R, w = setup["eng"], setup["R"], setup["w"]
+    lens = [400, 80000, 1234, 16000]
+    a = torch.from_numpy(synth_audio(4, 80000, seed=77))
+    for b, n in enumerate(lens):
+        a[b, n:] = 0
+    lp, t = eng.forward(a.cuda().contiguous(), lens)
+    lp_ref, t_ref = R.forward(w, a, lens)
+    assert t == t_ref.tolist() and t[0] == 1
+    assert _maxdiff(lp, lp_ref, t) <= 1e-2
+    for b in (0, 2):
+        one, t1 = eng.forward(a[b:b + 1, :lens[b]].cuda().contiguous(), [lens[b]])
+        assert t1[0] == t[b]
+        assert float((one[0, :t1[0]] - lp[b, :t1[0]]).abs().max()) <= 1e-5
+    res = eng.predict_batch(a.cuda().contiguous(), lens)
+    assert len(res) == 4 and res[0]["t_frames"] == 1
