@@ -8,7 +8,13 @@ verse retrieval -> CTC rerank) over one batch of synthetic 10 s / 16 kHz clips t
 resident in HBM: BASELINE.json configs[1] ("Single MI355X, batch=64 synthetic 10 s/16 kHz
 clips, fp16 forward + CTC rerank").  For N > 1 every rank processes its own batch of 64
 (utterances are independent: pure data parallel, weak scaling) and the packed
-(surah, ayah, ayah_end, score) rows are all-gathered over RCCL each step.
+(surah, ayah, ayah_end, score) rows of every batch are all-gathered over RCCL.
+
+The engine keeps --contexts (default 3) batches in flight on internal streams: each step still
+runs the whole path on its own batch of 64, but the latency-bound post-logits kernels of one
+batch execute under the forward pass of the next (DESIGN.md "Batches in flight"; --contexts 1
+gives the one-batch-at-a-time figure).  The timed region ends after every batch has finished
+(device synchronise) and, for N > 1, after every batch's rows have been gathered.
 
 Prints ONE JSON line on rank 0 (contract in the task description) including
   roofline      dominant kernel (the FFN-up GEMM class) measured with HIP events on its stream
@@ -36,8 +42,8 @@ FLOP_PER_UTT_10S = 28.5e9    # algorithmic forward FLOPs of one 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
