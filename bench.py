@@ -64,6 +64,45 @@ def cpu_baseline(audio_np, n_clips: int):
     from oracle import fastconformer_ref as R
     from oracle.oracle import Oracle
 
+    # when onnxruntime and the reference's model file are both on this node, the
+    # forward leg is the reference's own call -- InferenceSession.run, batch 1, default session
+    # options, CPUExecutionProvider (experiments/c2c-direct-mixed/run.py:48-63) -- and the line
+    # is labelled "reference"; otherwise the fp32 PyTorch restatement stands in ("port").
+    ort_sess = None
+    ref_onnx = os.environ.get("QV_REF_ONNX", "")
+    if ref_onnx and os.path.exists(ref_onnx):
+        try:
+            import onnxruntime as ort
+
+            ort_sess = ort.InferenceSession(ref_onnx, providers=["CPUExecutionProvider"])
+        except Exception:
+            ort_sess = None
+    if ort_sess is not None:
+        orc = Oracle()
+        n = audio_np.shape[1]
+        feed = lambda i: {"audio_signal": audio_np[i: i + 1].astype("float32"), "length": np.array([n], dtype=np.int64)}
+        ort_sess.run(None, feed(0))
+        t_fwd = t_post = 0.0
+        done = 0
+        for i in range(n_clips):
+            if t_fwd + t_post > 30.0:
+                break
+            done += 1
+            t0 = time.perf_counter()
+            lp = ort_sess.run(None, feed(i))[0][0]
+            t1 = time.perf_counter()
+            orc.predict_logprobs(np.ascontiguousarray(lp, dtype=np.float32))
+            t2 = time.perf_counter()
+            t_fwd += t1 - t0
+            t_post += t2 - t1
+        return {
+            "value": round(done / (t_fwd + t_post), 4), "unit": "utterances/s", "cores": os.cpu_count(),
+            "kind": "reference",
+            "sample": f"{done} of the benchmark's 10 s clips, batch 1: onnxruntime CPUExecutionProvider on "
+                      f"{os.path.basename(ref_onnx)} with default session options ({t_fwd / done:.2f} s per clip) + C "
+                      f"post-logits ({t_post / done:.2f} s per clip)",
+        }
+
     # intra-op threads: batch-1 GEMMs of this size stop scaling (and then collapse) long before a
     # 256-thread host is full; 16 is what the timing below actually uses and reports
     torch.set_num_threads(min(16, os.cpu_count() or 1))
