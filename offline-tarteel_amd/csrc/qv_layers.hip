@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
             float2 u = src[j * len + k], v = src[j * len + k + 256];
             // twiddle w = exp(-2 pi i * k / (2 len))
             float2 w = ft.twiddle[k * (256 >> p)];
-            float2 vw = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            float2 vw = make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
             dst[j * 2 * len + k] = make_float2(u.x + vw.x, u.y + vw.y);
             dst[j * 2 * len + k + len] = make_float2(u.x - vw.x, u.y - vw.y);
         }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, 
             for (int df = 0; df < 3; ++df) {
                 float v = rows[dt][2 * f1 + df];  // input f = 2*f1 - 1 + df, stored at +1
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * v;
+                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], v, acc[c]);
             }
         half8 o;
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_dwconv2d(const half_t *__restrict__ in,
                 if (f < 0 || f >= fin) continue;
                 half8 v = *(const half8 *)(in + (((size_t)b * tin_max + t) * fin + f) * QV_SUBC + c0);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * (float)v[c];
+                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
             }
         }
         half8 o;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
                 for (int df = 0; df < 3; ++df) {
                     float v = rows[2 * r + dt][2 * f1 + df];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * v;
+                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], v, acc[c]);
                 }
 #pragma unroll
             for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] > 0.f ? acc[c] : 0.f);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
                 if (f < 0 || f >= 40) continue;
                 half8 v = *(const half8 *)&tile[2 * tl + dt][f][c8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += w[dt * 3 + df][c] * (float)v[c];
+                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
             }
         half8 o;
 #pragma unroll
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, 
             int k = i - j;  // tap index: tt = (t0 + j) + k - 4
             if (k < 0 || k > 8) continue;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[j][c] += w[k][c] * vf[c];
+            for (int c = 0; c < 8; ++c) acc[j][c] = __builtin_fmaf(w[k][c], vf[c], acc[j][c]);
         }
     }
 #pragma unroll
