@@ -189,14 +189,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + wm * 64 + i * 32 + l31;
             if (row >= g.M) continue;
-            // rows are packed utterance after utterance: find the owner (<= 7 probes at B = 64)
-            int b = 0, hi_b = g.n_utt;
-            while (hi_b - b > 1) {
-                int mid = (b + hi_b) >> 1;
-                if (g.row_off[mid] <= row) b = mid;
-                else hi_b = mid;
-            }
-            const int t = row - g.row_off[b];
+            // rows are packed utterance after utterance: (utterance << 16 | frame) of every row
+            const int bt = g.row_map[row];
+            const int b = bt >> 16, t = bt & 0xFFFF;
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll

@@ -47,8 +47,7 @@ struct GemmArgs {
     int M, N, K, lda, ldw, ldo;
     float alpha;
     int t_max, t_pad;     // EPI_QKV
-    const int32_t *row_off;  // EPI_QKV: [n_utt + 1] first packed row of each utterance
-    int n_utt;
+    const int32_t *row_map;  // EPI_QKV: [M] (utterance << 16 | frame) of each packed row
     // W4A16 variant (Wq != nullptr, W unused): block-128 int4 weights, w = (q - zero_point) * scale.
     //   Wq      [N/64][K/64][64 rows][32 B]: one 64 x 64 tile of nibbles is 2 KB contiguous; inside a
     //           row's 32 B the 4-byte chunk c (k = 8c .. 8c+7) sits at position c ^ ((n >> 2) & 7),

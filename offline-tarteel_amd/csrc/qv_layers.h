@@ -23,7 +23,7 @@ void launch_sub01(const float *feats, int tm_max, const int32_t *len_mel, const 
 void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,
                      half_t *out, int tout_max, int fout, int batch, hipStream_t s);
 void launch_pack_rows(const half_t *x, int t_max, int row_elems, const int32_t *len, const int32_t *row_off, half_t *y,
-                      int batch, hipStream_t s);
+                      int32_t *row_map, int batch, hipStream_t s);
 void launch_layernorm(const float *x, const float *g, const float *b, half_t *y, int M, hipStream_t s);
 void launch_layernorm2(float *x, const float *g1, const float *b1, const float *g2, const float *b2, half_t *y, int M,
                        hipStream_t s);
@@ -32,7 +32,6 @@ void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_pad, int batch, hipStream_t s);
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,
                      int t_max, int batch, hipStream_t s);
-void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_off, int n_utt, int t_out,
-                       hipStream_t s);
+void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_map, int t_out, hipStream_t s);
 void launch_upfirdn(const float *x, int64_t n_in, const float *hflip, int P, int up, int down, int64_t m0, int64_t n_out,
                     float *y, hipStream_t s);

@@ -317,13 +317,16 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
 }
 
 // dense [B][t_max][row_elems] -> packed [sum of len][row_elems]: utterance b's valid frames become
-// rows row_off[b] .. row_off[b] + len[b] - 1 (from here on padding frames do not exist)
+// rows row_off[b] .. row_off[b] + len[b] - 1 (from here on padding frames do not exist).  Also
+// records each packed row's owner, row_map[row] = utterance << 16 | frame, for the kernels that
+// have to go back from a row to its utterance (V transpose in the QKV epilogue, log-softmax).
 __global__ void k_pack_rows(const half_t *__restrict__ x, int t_max, int row_elems, const int32_t *__restrict__ len,
-                            const int32_t *__restrict__ row_off, half_t *__restrict__ y) {
+                            const int32_t *__restrict__ row_off, half_t *__restrict__ y, int32_t *__restrict__ row_map) {
     const int b = blockIdx.z, t = blockIdx.y;
     if (t >= len[b]) return;
     const half_t *p = x + ((size_t)b * t_max + t) * row_elems;
     half_t *q = y + ((size_t)row_off[b] + t) * row_elems;
+    if (threadIdx.x == 0) row_map[row_off[b] + t] = (b << 16) | t;
     for (int i = threadIdx.x * 8; i < row_elems; i += blockDim.x * 8) *(half8 *)(q + i) = *(const half8 *)(p + i);
 }
 
@@ -593,17 +596,12 @@ __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, 
 // ------------------------------------------------------------------ log-softmax --------
 // logits f32 [M][ld] (first 1025 valid) -> log-probs f32 [B][t_max][1025]; one wave per row.
 __global__ __launch_bounds__(256) void k_logsoftmax(const float *__restrict__ logits, int ld, float *__restrict__ out, int M,
-                                                    const int32_t *__restrict__ row_off, int n_utt, int t_out) {
+                                                    const int32_t *__restrict__ row_map, int t_out) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     // packed row -> (utterance, frame); the caller's log-prob tensor is dense [B][t_out][1025]
-    int ub = 0, uh = n_utt;
-    while (uh - ub > 1) {
-        int mid = (ub + uh) >> 1;
-        if (row_off[mid] <= row) ub = mid;
-        else uh = mid;
-    }
-    const size_t orow = (size_t)ub * t_out + (row - row_off[ub]);
+    const int bt = row_map[row];
+    const size_t orow = (size_t)(bt >> 16) * t_out + (bt & 0xFFFF);
     const float *p = logits + (size_t)row * ld;
     float v[17];
     float mx = -INFINITY;
@@ -661,8 +659,8 @@ void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_
 }
 
 void launch_pack_rows(const half_t *x, int t_max, int row_elems, const int32_t *len, const int32_t *row_off, half_t *y,
-                      int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack_rows, dim3(1, t_max, batch), dim3(256), 0, s, x, t_max, row_elems, len, row_off, y);
+                      int32_t *row_map, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_rows, dim3(1, t_max, batch), dim3(256), 0, s, x, t_max, row_elems, len, row_off, y, row_map);
 }
 
 void launch_layernorm(const float *x, const float *g, const float *b, half_t *y, int M, hipStream_t s) {
@@ -691,9 +689,8 @@ void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const i
                        y);
 }
 
-void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_off, int n_utt, int t_out,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(k_logsoftmax, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, out, M, row_off, n_utt, t_out);
+void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_map, int t_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_logsoftmax, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, out, M, row_map, t_out);
 }
 
 // ---------------------------------------------------------------- a15: polyphase resampler ----

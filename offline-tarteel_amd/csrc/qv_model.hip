@@ -168,6 +168,7 @@ struct QvActs {
     double *mel_stats;   // [max_batch][80][2] per-feature sum / sum of squares
     half_t *c0, *c1, *c1p, *c2, *c2p, *c2k, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
     int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3; then [max_batch + 1] packed row offsets
+    int32_t *row_map;    // [M] utterance << 16 | frame of every packed row (written by k_pack_rows)
     int32_t *lens_host;  // pinned
     float *tap_x;        // [N_LAYERS+1][M][512] when save_taps
     int last_batch, last_tmax, last_tm_max, last_rows;
@@ -489,6 +490,7 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     TRY(dal(eng, m, M * QV_D, &m->xh));
     TRY(dal(eng, m, M * HEAD_N, &m->logits));
     TRY(dal(eng, m, Bz * 6 + 1, &m->lens_dev));
+    TRY(dal(eng, m, M, &m->row_map));
     QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * (Bz * 6 + 1), hipHostMallocDefault));
     m->ctx_acts[k].lens_host = m->lens_host;  // owned by the context from here on
     m->tap_x = nullptr;
@@ -557,7 +559,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     launch_dwconv2d(m->c1p, t2m, 20, d_l2, m->dw5_w, m->dw5_b, m->c2, t3m, 10, B, s);
     g.A = m->c2; g.W = m->pw6_w; g.bias = m->pw6_b; g.out = m->c2p; g.M = B * t3m * 10;
     launch_gemm(EPI_F16_RELU, g, s);
-    launch_pack_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, d_off, m->c2k, B, s);
+    launch_pack_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, d_off, m->c2k, m->row_map, B, s);
     // Linear(2560 -> 512) and xscaling (x * sqrt(d_model)) in one epilogue
     g.A = m->c2k; g.W = m->sub_out_w; g.bias = m->sub_out_b; g.out = m->x;
     g.M = M; g.N = QV_D; g.K = 2560; g.lda = 2560; g.ldw = 2560; g.ldo = QV_D; g.alpha = sqrtf((float)QV_D);
@@ -572,7 +574,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             GemmArgs a = {};
             a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.bias = bias; a.out = out; a.out2 = m->vt;
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
-            a.row_off = d_off; a.n_utt = B;
+            a.row_map = m->row_map;
             launch_gemm(epi, a, s);
         };
         // 1/2 FFN
@@ -609,7 +611,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         launch_gemm(EPI_F32, a, s);
     }
     // packed logits -> the caller's dense [B][t_max_out][1025] log-prob tensor (valid frames only)
-    launch_logsoftmax(m->logits, HEAD_N, logprobs, M, d_off, B, t_max_out, s);
+    launch_logsoftmax(m->logits, HEAD_N, logprobs, M, m->row_map, t_max_out, s);
     QV_HIP(hipGetLastError());
     m->last_batch = B; m->last_tmax = T; m->last_tm_max = tm_max; m->last_rows = M;
     return QV_OK;
@@ -627,7 +629,7 @@ int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, doubl
     GemmArgs a = {};
     int epi;
     a.M = M; a.out2 = m->vt; a.t_max = m->last_tmax; a.t_pad = (m->last_tmax + 31) / 32 * 32; a.alpha = 1.f;
-    a.row_off = m->lens_dev + 5 * m->max_batch; a.n_utt = m->last_batch;
+    a.row_map = m->row_map;
     const WMat *W;
     switch (which) {
         case 0: epi = EPI_F16_SWISH; a.A = m->ln; W = &L.ff1_w1; a.bias = L.ff1_b1; a.out = m->hbuf; a.N = QV_FF; a.K = QV_D; a.ldo = QV_FF; break;
