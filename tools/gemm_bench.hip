@@ -17,7 +17,7 @@ static float frand(uint64_t &s) {
 
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 50;
-    const int M = 8064;
+    const int M = argc > 2 ? atoi(argv[2]) : 8064;
     struct Sh { const char *name; int epi, N, K, ldo; float alpha; } shapes[] = {
         {"ff_up    swish N2048 K512 ", EPI_F16_SWISH, 2048, 512, 2048, 1.f},
         {"ff_down  resid N512 K2048 ", EPI_RESID, 512, 2048, 512, 0.5f},
@@ -38,10 +38,16 @@ int main(int argc, char **argv) {
     float *db;
     void *dO;
     CK(hipMalloc(&dA, maxA * 2)); CK(hipMalloc(&dW, maxW * 2)); CK(hipMalloc(&dO, maxO * 4)); CK(hipMalloc(&db, 4096 * 4));
-    CK(hipMalloc(&dV, (size_t)M * 512 * 2 + 65536));
+    CK(hipMalloc(&dV, (size_t)(M / 126 + 1) * 512 * 128 * 2));
     CK(hipMemcpy(dA, hA.data(), maxA * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), maxW * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), 4096 * 4, hipMemcpyHostToDevice));
+    // packed-row owner map for the QKV epilogue: utterances of 126 frames
+    std::vector<int32_t> hmap(M);
+    for (int r = 0; r < M; ++r) hmap[r] = ((r / 126) << 16) | (r % 126);
+    int32_t *dmap;
+    CK(hipMalloc(&dmap, (size_t)M * 4));
+    CK(hipMemcpy(dmap, hmap.data(), (size_t)M * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double tot_ms = 0, tot_fl = 0;
@@ -50,7 +56,7 @@ int main(int argc, char **argv) {
         GemmArgs g = {};
         g.A = dA; g.W = dW; g.bias = db; g.out = dO; g.out2 = dV;
         g.M = M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.ldo; g.alpha = sh.alpha;
-        g.t_max = 126; g.t_pad = 128;
+        g.t_max = 126; g.t_pad = 128; g.row_map = dmap;
         CK(hipMemset(dO, 0, maxO * 4));
         launch_gemm(sh.epi, g, 0);
         CK(hipDeviceSynchronize());
