@@ -46,19 +46,26 @@ __device__ __forceinline__ half8 dequant8(uint32_t q, half2_t s2, half2_t off) {
 
 }  // namespace
 
-template <int EPI, int BN, bool W4>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+// Wave specialisation: 512 threads.  Waves 0..3 (one per SIMD) are CONSUMERS: fragment reads from LDS
+// and MFMAs only (2 x 2 layout, 64 x BN/2 each), then the epilogue.  Waves 4..7 are LOADERS: they only
+// issue the direct global->LDS loads of the stage NST - 1 K-steps ahead.  A wave that does both pays
+// the issue time of its 8 loads (hundreds of cycles per K-step) in front of its 16 MFMAs; split, the
+// loads issue under the partner wave's MFMAs (tools/gemm_exp.hip: 7-17 % per GEMM at these shapes).
+template <int EPI, int BN, bool W4, int NST>
+__global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     constexpr int BM = 128, BK = 64;
-    constexpr int WN = BN / 2;   // columns per wave
-    constexpr int NF = WN / 32;  // 32-wide B fragments per wave
+    constexpr int NT = 512;
+    constexpr int WN = BN / 2;   // columns per consumer wave
+    constexpr int NF = WN / 32;  // 32-wide B fragments per consumer wave
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : BN * BK * 2;
-    constexpr int NST = 2;                       // LDS stages (64 KB: two blocks fit a CU; deeper prefetch at one block/CU measured slower)
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int G = 4 + BN / 32;               // direct loads per wave per stage
+    constexpr int G = W4 ? 5 : 4 + BN / 32;      // direct loads per loader wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const bool loader = wave >= 4;
+    const int w4 = wave & 3;                     // index inside the consumer / loader group
+    const int wm = w4 >> 1, wn = w4 & 1;
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD
     // a contiguous run of tiles that share the A row panel so its private L2 sees the reuse.
     const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         half_t *sA = (half_t *)(smem + (kt % NST) * STAGE_BYTES), *sB = (half_t *)((unsigned char *)sA + A_BYTES);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int chunk = wave * 4 + q;
+            int chunk = w4 * 4 + q;
             int row = chunk * 8 + (lane >> 3);
             int c = (lane & 7) ^ ((row >> 1) & 7);
             int grow = m0 + row;
@@ -93,16 +100,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
         }
         if (W4) {
-            // 64 x 64 nibble tiles are 2 KB contiguous in HBM and already swizzled: one load per
-            // 32 tile rows, the first BN / 32 waves issue it
-            if (wave < BN / 32)
-                glds16(g.Wq + ((size_t)((n0 >> 6) + (wave >> 1)) * nk + kt) * 2048 + (wave & 1) * 1024 + lane * 16,
-                       (unsigned char *)sB + wave * 1024);
+            // 64 x 64 nibble tiles are 2 KB contiguous in HBM and already swizzled: one load per 32
+            // tile rows.  Every loader wave issues exactly one (with 64-wide tiles waves 2, 3 repeat
+            // the loads of waves 0, 1) so that the vmcnt bookkeeping is the same for all of them.
+            const int p = w4 & (BN / 32 - 1);
+            glds16(g.Wq + ((size_t)((n0 >> 6) + (p >> 1)) * nk + kt) * 2048 + (p & 1) * 1024 + lane * 16,
+                   (unsigned char *)sB + p * 1024);
             return;
         }
 #pragma unroll
         for (int q = 0; q < BN / 32; ++q) {
-            int chunk = wave * (BN / 32) + q;
+            int chunk = w4 * (BN / 32) + q;
             int row = chunk * 8 + (lane >> 3);
             int c = (lane & 7) ^ ((row >> 1) & 7);
             glds16(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8, sB + chunk * 512);
@@ -113,27 +121,33 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     half2_t *sS = (half2_t *)(smem + NST * STAGE_BYTES);   // {scale, 1024 + zero point}
     if (W4) {
         const int nkb = g.K >> 7;
-        for (int idx = tid; idx < BN * nkb; idx += 256) {
+        for (int idx = tid; idx < BN * nkb; idx += NT) {
             int kb = idx / BN, n = idx - kb * BN;
             sS[idx] = ((const half2_t *)g.wscale)[(size_t)kb * g.N + n0 + n];
         }
         __syncthreads();
     }
 
-    // Software pipeline with counted waits: a wave waits only for ITS OWN loads of tile kt
-    // (vmcnt = loads issued after them), then one raw s_barrier makes every wave's part of the
-    // tile visible and retires the buffer that the next prefetch overwrites.  __syncthreads()
-    // would drain the whole queue (vmcnt(0)) and serialise load latency with the MFMAs.
+    // One raw s_barrier per K-step joins the two groups.  A loader arrives once ITS loads of stage
+    // kt have landed (counted vmcnt: the loads of the younger stages stay in flight), which makes
+    // the stage visible to the consumers and tells the loaders that the consumers are done with
+    // stage kt - 1, whose buffer the next prefetch overwrites.  (__syncthreads() would drain the
+    // whole queue and serialise the load latency with the MFMAs.)
+    if (loader) {
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) stage(s);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = min(nk - 1 - kt, NST - 2);  // tiles issued after tile kt
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nk) stage(s);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(nk - 1 - kt, NST - 2);  // stages issued after stage kt
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST - 1 < nk) stage(kt + NST - 1);
+        }
+    }
+    for (int kt = 0; kt < (loader ? 0 : nk); ++kt) {
         __builtin_amdgcn_s_barrier();
-        if (kt + NST - 1 < nk) stage(kt + NST - 1);
         const half_t *sA = (const half_t *)(smem + (kt % NST) * STAGE_BYTES);
         const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
         half2_t sc[NF], zo[NF];
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
         // V tile: transposed store Vt[b][h*64+d][t] straight from registers (32 lanes = 32
         // consecutive frames = 64 contiguous bytes)
+        if (loader) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + wm * 64 + i * 32 + l31;
@@ -207,11 +222,22 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         return;
     }
 
+    // this wave's bias values, requested together (g.bias is never null: one load latency, not
+    // one per register quad)
+    f32x4 bia[NF][4];
+    if (EPI != EPI_GLU && !loader) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bia[j][q] = *(const f32x4 *)(g.bias + n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
+    }
+
     if (epi_is_f32(EPI)) {
         constexpr int LDT = BN + 4;  // floats per staged row (pad keeps 16-B alignment)
         float *sO = (float *)smem;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (loader) continue;   // only the consumer waves hold accumulators
             const int rl = wm * 64 + i * 32 + l31;
 #pragma unroll
             for (int j = 0; j < NF; ++j)
@@ -219,20 +245,15 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
                 for (int q = 0; q < 4; ++q) {
                     const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
                     f32x4 v;
-                    if (g.bias) {
-                        f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
+                    const f32x4 bb = bia[j][q];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = g.alpha * (acc[i][j][q * 4 + e] + bb[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = g.alpha * acc[i][j][q * 4 + e];
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = g.alpha * (acc[i][j][q * 4 + e] + bb[e]);
                     *(f32x4 *)(sO + rl * LDT + cl) = v;
                 }
         }
         __syncthreads();
         constexpr int CPR = BN / 4;  // 16-byte chunks per row
-        for (int idx = tid; idx < BM * CPR; idx += 256) {
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
             int r = idx / CPR, c = (idx % CPR) * 4;
             if (m0 + r >= g.M) continue;
             f32x4 v = *(const f32x4 *)(sO + r * LDT + c);
@@ -254,6 +275,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         const int n0o = EPI == EPI_GLU ? n0 / 2 : n0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (loader) continue;   // only the consumer waves hold accumulators
             const int rl = wm * 64 + i * 32 + l31;
             if (EPI == EPI_GLU) {
                 // W rows interleaved in 32-channel groups: [value(32) | gate(32)] per 64 columns
@@ -277,8 +299,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
-                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-                    if (g.bias) bb = *(const f32x4 *)(g.bias + n0 + cl);
+                    const f32x4 bb = bia[j][q];
                     half4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         }
         __syncthreads();
         constexpr int CPR = BNO / 8;  // 16-byte chunks per row
-        for (int idx = tid; idx < BM * CPR; idx += 256) {
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
             int r = idx / CPR, c = (idx % CPR) * 8;
             if (m0 + r >= g.M) continue;
             *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0o + c) = *(const half8 *)(sO + r * LDT + c);
@@ -300,14 +321,35 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
 }
 
-template <int EPI, int BN, bool W4>
+template <int EPI, int BN, bool W4, int NST>
 static void launch_one(const GemmArgs &g, hipStream_t s) {
     dim3 grid(g.N / BN, (g.M + 127) / 128);
-    size_t lds = W4 ? 2 * ((128 * 64 * 2) + (BN * 32)) + (size_t)BN * (g.K / 128) * 4
-                    : 2 * ((128 * 64 * 2) + (BN * 64 * 2));
+    size_t lds = W4 ? NST * ((128 * 64 * 2) + (BN * 32)) + (size_t)BN * (g.K / 128) * 4
+                    : NST * ((128 * 64 * 2) + (BN * 64 * 2));
     size_t epi = epi_is_f32(EPI) ? (size_t)128 * (BN + 4) * 4 : (size_t)128 * (BN + 8) * 2;
     if (epi > lds) lds = epi;
-    hipLaunchKernelGGL((k_gemm<EPI, BN, W4>), grid, dim3(256), lds, s, g);
+    // more than 64 KB of dynamic LDS is opted into, once per instantiation and only where needed
+    if (lds > 64 * 1024) {
+        static size_t allowed = 0;
+        if (lds > allowed) {
+            (void)hipFuncSetAttribute((const void *)k_gemm<EPI, BN, W4, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allowed = lds;
+        }
+    }
+    hipLaunchKernelGGL((k_gemm<EPI, BN, W4, NST>), grid, dim3(512), lds, s, g);
+}
+
+// tile width BN in {64, 128} and LDS stage count NST in {2, 3, 4} (see launch_gemm)
+template <int EPI, bool W4>
+static void launch_shape(const GemmArgs &g, hipStream_t s, bool narrow, int nst) {
+    if (narrow) {
+        if (nst == 2) launch_one<EPI, 64, W4, 2>(g, s);
+        else launch_one<EPI, 64, W4, 3>(g, s);
+    } else {
+        if (nst == 2) launch_one<EPI, 128, W4, 2>(g, s);
+        else if (nst == 3) launch_one<EPI, 128, W4, 3>(g, s);
+        else launch_one<EPI, 128, W4, 4>(g, s);
+    }
 }
 
 // Symmetric block-128 int4: per row and per 128 consecutive k, scale = v / -8 where v is the
@@ -372,38 +414,26 @@ void qv_gemm_prof_collect(double *ms, double *flops, int *n) {
     g_prof.flops.clear();
 }
 
-static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow) {
+static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow, int nst) {
     if (g.Wq) {
         // int4 weights: the Linear layers only (FFN, QKV, attention out, linear_pos)
         switch (epi) {
-#define CASE(E)                                                   \
-    case E:                                                       \
-        if (narrow) launch_one<E, 64, true>(g, s);                \
-        else launch_one<E, 128, true>(g, s);                      \
-        break;
-            CASE(EPI_F16)
-            CASE(EPI_F16_SWISH)
-            CASE(EPI_RESID)
-            CASE(EPI_QKV)
-#undef CASE
+            case EPI_F16: launch_shape<EPI_F16, true>(g, s, narrow, nst); break;
+            case EPI_F16_SWISH: launch_shape<EPI_F16_SWISH, true>(g, s, narrow, nst); break;
+            case EPI_RESID: launch_shape<EPI_RESID, true>(g, s, narrow, nst); break;
+            case EPI_QKV: launch_shape<EPI_QKV, true>(g, s, narrow, nst); break;
             default: abort();
         }
         return;
     }
     switch (epi) {
-#define CASE(E)                                                   \
-    case E:                                                       \
-        if (narrow) launch_one<E, 64, false>(g, s);               \
-        else launch_one<E, 128, false>(g, s);                     \
-        break;
-        CASE(EPI_F16)
-        CASE(EPI_F16_SWISH)
-        CASE(EPI_F16_RELU)
-        CASE(EPI_RESID)
-        CASE(EPI_F32)
-        CASE(EPI_QKV)
-#undef CASE
-        case EPI_GLU: launch_one<EPI_GLU, 128, false>(g, s); break;
+        case EPI_F16: launch_shape<EPI_F16, false>(g, s, narrow, nst); break;
+        case EPI_F16_SWISH: launch_shape<EPI_F16_SWISH, false>(g, s, narrow, nst); break;
+        case EPI_F16_RELU: launch_shape<EPI_F16_RELU, false>(g, s, narrow, nst); break;
+        case EPI_RESID: launch_shape<EPI_RESID, false>(g, s, narrow, nst); break;
+        case EPI_F32: launch_shape<EPI_F32, false>(g, s, narrow, nst); break;
+        case EPI_QKV: launch_shape<EPI_QKV, false>(g, s, narrow, nst); break;
+        case EPI_GLU: launch_shape<EPI_GLU, false>(g, s, false, nst); break;
         default: abort();
     }
 }
@@ -413,18 +443,26 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
         fprintf(stderr, "launch_gemm: unsupported shape N=%d K=%d\n", g.N, g.K);
         abort();
     }
-    // narrow-N GEMMs on few row panels get 64-wide tiles so the grid still covers the chip
-    static const int min_tiles = [] { const char *e = getenv("QVERSE_GEMM_MIN_TILES"); return e ? atoi(e) : 512; }();
-    bool narrow = (g.N % 128 != 0) || ((g.N / 128) * ((g.M + 127) / 128) < min_tiles && epi != EPI_GLU);
-    if (!g_prof.on) { launch_gemm_inner(epi, g, s, narrow); return; }
+    // Tile and pipeline choice (measured per shape, tools/gemm_exp.hip): 128-wide tiles whenever N allows;
+    // with >= 400 tiles two 64 KB blocks share a CU (2 stages), with fewer tiles one block per CU
+    // gets a deeper pipeline instead (3 stages, 4 when the K loop is long).
+    static const int env_nst = [] { const char *e = getenv("QVERSE_GEMM_NST"); return e ? atoi(e) : 0; }();
+    static const int env_narrow = [] { const char *e = getenv("QVERSE_GEMM_NARROW"); return e ? atoi(e) : -1; }();
+    bool narrow = g.N % 128 != 0;
+    if (env_narrow >= 0 && g.N % 128 == 0 && epi != EPI_GLU) narrow = env_narrow != 0;
+    const int tiles = (g.N / (narrow ? 64 : 128)) * ((g.M + 127) / 128);
+    int nst = tiles >= 400 ? 2 : (g.K / 64 >= 16 ? 4 : 3);
+    if (narrow && nst > 3) nst = 3;
+    if (env_nst >= 2 && env_nst <= (narrow ? 3 : 4)) nst = env_nst;
+    if (!g_prof.on) { launch_gemm_inner(epi, g, s, narrow, nst); return; }
     size_t i = g_prof.cls.size();
     while (g_prof.ev.size() < 2 * (i + 1)) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { launch_gemm_inner(epi, g, s, narrow); return; }
+        if (hipEventCreate(&e) != hipSuccess) { launch_gemm_inner(epi, g, s, narrow, nst); return; }
         g_prof.ev.push_back(e);
     }
     (void)hipEventRecord(g_prof.ev[2 * i], s);
-    launch_gemm_inner(epi, g, s, narrow);
+    launch_gemm_inner(epi, g, s, narrow, nst);
     (void)hipEventRecord(g_prof.ev[2 * i + 1], s);
     g_prof.cls.push_back(epi * 2 + (narrow ? 0 : 1));
     g_prof.flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);

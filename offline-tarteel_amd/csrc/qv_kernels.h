@@ -57,7 +57,7 @@ struct GemmArgs {
     const half_t *wscale;
 };
 
-template <int EPI, int BN, bool W4>
+template <int EPI, int BN, bool W4, int NST>
 __global__ void k_gemm(GemmArgs g);
 
 // host-side packer for the W4A16 layout above (w: [N][K] f32 row-major; N % 64 == 0, K % 128 == 0)

@@ -183,6 +183,7 @@ struct QvModel : QvActs {
     const float *c0_w, *c0_b, *dw2_w, *dw2_b, *dw5_w, *dw5_b, *pw3_b, *pw6_b, *sub_out_b, *head_b;
     const half_t *pw3_w, *pw6_w, *sub_out_w, *head_w;
     WMat pos_w;
+    const float *zero_bias;
     bool w4;             // QV_PREC_MIXED_INT4_INT8: Linear-layer weights are block-128 int4
     LayerW L[N_LAYERS];
     // capacities
@@ -400,6 +401,8 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
         TRY(up(eng, m, hw.get(p + "conv.pointwise_conv2.bias"), &L.pw2_b));
     }
     TRY(up_mat(eng, m, posw, N_LAYERS * QV_D, QV_D, &m->pos_w));
+    // linear_pos has no bias; the GEMM epilogue always reads one
+    TRY(up(eng, m, std::vector<float>((size_t)N_LAYERS * QV_D, 0.f), &m->zero_bias));
     return QV_OK;
 }
 
@@ -424,7 +427,7 @@ int get_pos(qv_engine *eng, QvModel *m, int t_max, hipStream_t stream, const hal
     QV_HIP(hipMalloc((void **)&d_out, (size_t)R * N_LAYERS * QV_D * sizeof(half_t)));
     QV_HIP(hipMemcpyAsync(d_pe, pe.data(), pe.size() * sizeof(half_t), hipMemcpyHostToDevice, stream));
     GemmArgs g = {};
-    g.A = d_pe; g.W = m->pos_w.w; g.Wq = m->pos_w.q; g.wscale = m->pos_w.sc; g.bias = nullptr; g.out = d_out;
+    g.A = d_pe; g.W = m->pos_w.w; g.Wq = m->pos_w.q; g.wscale = m->pos_w.sc; g.bias = m->zero_bias; g.out = d_out;
     g.M = R; g.N = N_LAYERS * QV_D; g.K = QV_D; g.lda = QV_D; g.ldw = QV_D; g.ldo = N_LAYERS * QV_D; g.alpha = 1.f;
     launch_gemm(EPI_F16, g, stream);
     QV_HIP(hipStreamSynchronize(stream));

@@ -12,7 +12,7 @@
 
 // Wf layout: [N/32][K/16][64 lanes][8 halves]; lane l of fragment (n32, k16) holds
 // W[n32*32 + (l & 31)][k16*16 + (l >> 5)*8 .. +7]
-template <int BN, int WMW, int NST, int MODE = 0>
+template <int BN, int WMW, int NST, int MODE = 0, int BUF = 0>
 __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
     constexpr int BM = 128, BK = 64;
     constexpr int WNW = 4 / WMW;
@@ -38,8 +38,26 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // BUF: A through buffer_load_dwordx4 ... lds (SGPR descriptor + 32-bit lane offset + scalar K offset)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
+    unsigned voffA[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int chunk = wave * 4 + q;
+        int row = chunk * 8 + (lane >> 3);
+        int c = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = m0 + row;
+        grow = grow < g.M ? grow : g.M - 1;
+        voffA[q] = (unsigned)(((size_t)grow * g.lda + c * 8) * 2);
+    }
     auto stageA = [&](int kt) {
         half_t *sA = (half_t *)(smem + (kt % NST) * A_BYTES);
+        if (BUF) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sA + (wave * 4 + q) * 512), 16, voffA[q], kt * BK * 2, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int chunk = wave * 4 + q;
@@ -66,7 +84,8 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 int row = wm * (MI * 32) + i * 32 + (lane & 31);
-                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                if (MODE == 5) a[i] = b[0][ks];   // no LDS traffic at all
+                else a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -88,9 +107,11 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) loadB(kt + 1, b1);
-            if (kt + NST - 1 < nk) stageA(kt + NST - 1);
+            if (MODE < 4) __builtin_amdgcn_s_barrier();
+            if (MODE < 3) {
+                if (kt + 1 < nk) loadB(kt + 1, b1);
+                if (kt + NST - 1 < nk) stageA(kt + NST - 1);
+            }
             compute(kt, b0);
         }
         if (kt + 1 < nk) {
@@ -99,10 +120,12 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (k1 + 1 < nk) loadB(k1 + 1, b0);
-            if (k1 + NST - 1 < nk) stageA(k1 + NST - 1);
-            compute(k1, b1);
+            if (MODE < 4) __builtin_amdgcn_s_barrier();
+            if (MODE < 3) {
+                if (k1 + 1 < nk) loadB(k1 + 1, b0);
+                if (k1 + NST - 1 < nk) stageA(k1 + NST - 1);
+            }
+            compute(k1, MODE >= 3 ? b0 : b1);
         }
     }
     __syncthreads();
@@ -138,6 +161,134 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
         half8 v = *(const half8 *)(sO + r * LDT + c);
         if (MODE == 1 && v[0] != (half_t)12345.f) continue;
         *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c) = v;
+    }
+}
+
+// k_gemm4: wave specialisation.  512 threads: waves 0..3 (one per SIMD) only read fragments from LDS
+// and issue MFMAs (2 x 2 layout, 64 x 64 each); waves 4..7 only issue the global->LDS loads of the
+// stage NST - 1 steps ahead (A and W, both through LDS as in the product kernel).  One s_barrier per
+// K-step joins the two groups: the loaders arrive after their vmcnt says stage kt + 1 has landed.
+template <int BN, int NST>
+__global__ __launch_bounds__(512) void k_gemm4(GemmArgs g, const half8 *) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WN = BN / 2, NF = WN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int G = 4 + BN / 32;   // loads per loader wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gx + blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
+    const int nk = g.K / BK;
+
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stage = [&](int kt) {
+        half_t *sA = (half_t *)(smem + (kt % NST) * STAGE_BYTES), *sB = (half_t *)((unsigned char *)sA + A_BYTES);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int chunk = w4 * 4 + q;
+            int row = chunk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            int grow = m0 + row;
+            grow = grow < g.M ? grow : g.M - 1;
+            glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            int chunk = w4 * (BN / 32) + q;
+            int row = chunk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            glds16(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8, sB + chunk * 512);
+        }
+    };
+
+    if (loader) {
+        // stages 0 .. NST-2 in flight before the first barrier
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nk) stage(s);
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt must have landed: stages kt+1 .. kt+NST-2 may still be in flight
+            const int ahead = min(nk - 1 - kt, NST - 2);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // stage kt visible; buffer (kt-1) % NST is free
+            if (kt + NST - 1 < nk) stage(kt + NST - 1);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            const half_t *sA = (const half_t *)(smem + (kt % NST) * STAGE_BYTES);
+            const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                half8 a[2], b[NF];
+                int c = ks * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int row = wm * 64 + i * 32 + (lane & 31);
+                    a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    int row = wn * WN + j * 32 + (lane & 31);
+                    b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // epilogue (consumers hold the accumulators; all 512 threads do the coalesced store)
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int LDT = BN + 8;
+    half_t *sO = (half_t *)smem;
+    if (!loader) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = wm * 64 + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
+                    f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][q * 4 + e] + bb[e];
+                        x = x * sigmoidf_(x);
+                        o[e] = (half_t)x;
+                    }
+                    *(half4 *)(sO + rl * LDT + cl) = o;
+                }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int idx = tid; idx < BM * CPR; idx += 512) {
+        int r = idx / CPR, c = (idx % CPR) * 8;
+        if (m0 + r >= g.M) continue;
+        *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c) = *(const half8 *)(sO + r * LDT + c);
     }
 }
 
@@ -267,15 +418,15 @@ static float frand(uint64_t &s) {
     return ((float)((s >> 33) & 0xFFFFFF) / 8388608.0f) - 1.0f;
 }
 
-template <int BN, int WMW, int NST, int MODE = 0>
+template <int BN, int WMW, int NST, int MODE = 0, int BUF = 0>
 static void run2(const char *name, GemmArgs g, const half8 *Wf, int iters, const std::vector<half_t> &hA,
                  const std::vector<half_t> &hW, const std::vector<float> &hb) {
     dim3 grid(g.N / BN, (g.M + 127) / 128);
     size_t lds = (size_t)NST * 128 * 64 * 2, epi = (size_t)128 * (BN + 8) * 2;
     if (epi > lds) lds = epi;
-    CK(hipFuncSetAttribute((const void *)k_gemm2<BN, WMW, NST, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k_gemm2<BN, WMW, NST, MODE, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(g.out, 0, (size_t)g.M * g.ldo * 2));
-    hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE, BUF>), grid, dim3(256), lds, 0, g, Wf);
     CK(hipDeviceSynchronize());
     std::vector<half_t> ho((size_t)g.M * g.ldo);
     CK(hipMemcpy(ho.data(), g.out, ho.size() * 2, hipMemcpyDeviceToHost));
@@ -290,9 +441,9 @@ static void run2(const char *name, GemmArgs g, const half8 *Wf, int iters, const
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE, BUF>), grid, dim3(256), lds, 0, g, Wf);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE>), grid, dim3(256), lds, 0, g, Wf);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_gemm2<BN, WMW, NST, MODE, BUF>), grid, dim3(256), lds, 0, g, Wf);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -304,13 +455,14 @@ static void run2(const char *name, GemmArgs g, const half8 *Wf, int iters, const
 typedef void (*kern_t)(GemmArgs, const half8 *);
 
 static void run_k(const char *name, kern_t kern, int BN, int NST, GemmArgs g, const half8 *Wf, int iters,
-                  const std::vector<half_t> &hA, const std::vector<half_t> &hW, const std::vector<float> &hb) {
+                  const std::vector<half_t> &hA, const std::vector<half_t> &hW, const std::vector<float> &hb,
+                  int threads = 256, size_t stage_bytes = 128 * 64 * 2) {
     dim3 grid(g.N / BN, (g.M + 127) / 128);
-    size_t lds = (size_t)NST * 128 * 64 * 2, epi = (size_t)128 * (BN + 8) * 2;
+    size_t lds = (size_t)NST * stage_bytes, epi = (size_t)128 * (BN + 8) * 2;
     if (epi > lds) lds = epi;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(g.out, 0, (size_t)g.M * g.ldo * 2));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, g, Wf);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, g, Wf);
     CK(hipDeviceSynchronize());
     std::vector<half_t> ho((size_t)g.M * g.ldo);
     CK(hipMemcpy(ho.data(), g.out, ho.size() * 2, hipMemcpyDeviceToHost));
@@ -325,9 +477,9 @@ static void run_k(const char *name, kern_t kern, int BN, int NST, GemmArgs g, co
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, g, Wf);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, g, Wf);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, g, Wf);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, g, Wf);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -340,7 +492,7 @@ int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 50;
     const int M = 8064;
     uint64_t seed = 1;
-    struct Sh { int N, K; } shapes[] = {{2048, 512}, {512, 2048}, {1536, 512}, {512, 512}};
+    struct Sh { int N, K; } shapes[] = {{2048, 512}, {512, 2048}, {1536, 512}, {512, 512}, {1024, 512}, {1152, 512}, {512, 2560}};
     for (auto sh : shapes) {
         const int N = sh.N, K = sh.K;
         std::vector<half_t> hA((size_t)M * K), hW((size_t)N * K), hWf((size_t)N * K);
@@ -379,6 +531,22 @@ int main(int argc, char **argv) {
         }
         const half8 *Wf = (const half8 *)dWf;
         run2<128, 1, 2>("BN128 1x4 NST2", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 2, 3>("  1x4 no in-loop loads", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 2, 4>("  1x4 + no barriers", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 2, 5>("  1x4 + no ds_reads (MFMA only)", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 2, 0, 1>("BN128 1x4 NST2 buffer-lds A", g, Wf, iters, hA, hW, hb);
+        run2<128, 1, 3, 0, 1>("BN128 1x4 NST3 buffer-lds A", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 2, 0, 1>("BN128 2x2 NST2 buffer-lds A", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 2>("BN128 2x2 NST2", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 2, 3>("  2x2 no in-loop loads", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 2, 4>("  2x2 + no barriers", g, Wf, iters, hA, hW, hb);
+        run2<128, 2, 2, 5>("  2x2 + no ds_reads (MFMA only)", g, Wf, iters, hA, hW, hb);
+        run_k("specialised BN128 NST2", k_gemm4<128, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("specialised BN128 NST3", k_gemm4<128, 3>, 128, 3, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("specialised BN128 NST4", k_gemm4<128, 4>, 128, 4, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("specialised BN64  NST2", k_gemm4<64, 2>, 64, 2, g, Wf, iters, hA, hW, hb, 512, 24576);
+        run_k("specialised BN64  NST3", k_gemm4<64, 3>, 64, 3, g, Wf, iters, hA, hW, hb, 512, 24576);
+        run_k("specialised BN64  NST4", k_gemm4<64, 4>, 64, 4, g, Wf, iters, hA, hW, hb, 512, 24576);
         run_k("deep BN128 1x4 NST3", k_gemm3<128, 1, 3>, 128, 3, g, Wf, iters, hA, hW, hb);
         run_k("deep BN128 1x4 NST4", k_gemm3<128, 1, 4>, 128, 4, g, Wf, iters, hA, hW, hb);
         run_k("deep BN128 2x2 NST3", k_gemm3<128, 2, 3>, 128, 3, g, Wf, iters, hA, hW, hb);
