@@ -197,27 +197,43 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     const int l31 = lane & 31, hi = lane >> 5;
 
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
-        // V tile: transposed store Vt[b][h*64+d][t] straight from registers (32 lanes = 32
-        // consecutive frames = 64 contiguous bytes)
-        if (loader) return;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = m0 + wm * 64 + i * 32 + l31;
-            if (row >= g.M) continue;
-            // rows are packed utterance after utterance: (utterance << 16 | frame) of every row
-            const int bt = g.row_map[row];
-            const int b = bt >> 16, t = bt & 0xFFFF;
+        // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  The tile goes through LDS as [d][frame] so
+        // that all 8 waves write it out with the 64 lanes of a store on 128 consecutive frames of
+        // one d (4-byte pairs, 256 B per instruction); stores straight from the accumulator layout
+        // (2-byte elements, 32 frames per d) cost 8 us per GEMM.
+        constexpr int LDV = BM + 2;   // halves per d row (odd dword pitch: d rows rotate over the banks)
+        half_t *sT = (half_t *)smem;
+        if (!loader) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int col = n0 + wn * WN + j * 32 + 8 * q + 4 * hi;
-                    f32x4 bb = *(const f32x4 *)(g.bias + col);
+                    const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
+                    const f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        ((half_t *)g.out2)[((size_t)b * QV_D + (col - 2 * QV_D + e)) * g.t_pad + t] =
-                            (half_t)(acc[i][j][q * 4 + e] + bb[e]);
+                    for (int i = 0; i < 2; ++i) {
+                        const int rl = wm * 64 + i * 32 + l31;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sT[(cl + e) * LDV + rl] = (half_t)(acc[i][j][q * 4 + e] + bb[e]);
+                    }
                 }
+        }
+        __syncthreads();
+        // thread -> frame pair (fixed), then d = tid / 64 + 8 k
+        const int r0 = m0 + 2 * lane, r1 = r0 + 1;
+        const int bt0 = r0 < g.M ? g.row_map[r0] : -1, bt1 = r1 < g.M ? g.row_map[r1] : -1;
+        const bool pair = bt0 >= 0 && bt1 == bt0 + 1 && (bt0 & 1) == 0;   // same utterance, even frame: one 4-byte store
+        half_t *vt = (half_t *)g.out2;
+        for (int d = wave; d < BN; d += NT / 64) {
+            const size_t drow = (size_t)(n0 - 2 * QV_D + d);
+            const half_t v0 = sT[d * LDV + 2 * lane], v1 = sT[d * LDV + 2 * lane + 1];
+            if (pair) {
+                half2_t v = {v0, v1};
+                *(half2_t *)(vt + ((size_t)(bt0 >> 16) * QV_D + drow) * g.t_pad + (bt0 & 0xFFFF)) = v;
+            } else {
+                if (bt0 >= 0) vt[((size_t)(bt0 >> 16) * QV_D + drow) * g.t_pad + (bt0 & 0xFFFF)] = v0;
+                if (bt1 >= 0) vt[((size_t)(bt1 >> 16) * QV_D + drow) * g.t_pad + (bt1 & 0xFFFF)] = v1;
+            }
         }
         return;
     }

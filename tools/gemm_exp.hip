@@ -168,16 +168,19 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
 // and issue MFMAs (2 x 2 layout, 64 x 64 each); waves 4..7 only issue the global->LDS loads of the
 // stage NST - 1 steps ahead (A and W, both through LDS as in the product kernel).  One s_barrier per
 // K-step joins the two groups: the loaders arrive after their vmcnt says stage kt + 1 has landed.
-template <int BN, int NST>
-__global__ __launch_bounds__(512) void k_gemm4(GemmArgs g, const half8 *) {
+template <int BN, int NST, int NL = 4>
+__global__ __launch_bounds__((4 + NL) * 64) void k_gemm4(GemmArgs g, const half8 *) {
     constexpr int BM = 128, BK = 64;
     constexpr int WN = BN / 2, NF = WN / 32;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int G = 4 + BN / 32;   // loads per loader wave per stage
+    constexpr int AQ = 16 / NL, BQ = BN / 8 / NL;
+    constexpr int G = AQ + BQ;   // loads per loader wave per stage
+    constexpr int NT = (4 + NL) * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= 4;
     const int w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int li = wave - 4;   // loader index
     const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
     int wg = blockIdx.y * gx + blockIdx.x;
     {
@@ -198,8 +201,8 @@ __global__ __launch_bounds__(512) void k_gemm4(GemmArgs g, const half8 *) {
     auto stage = [&](int kt) {
         half_t *sA = (half_t *)(smem + (kt % NST) * STAGE_BYTES), *sB = (half_t *)((unsigned char *)sA + A_BYTES);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int chunk = w4 * 4 + q;
+        for (int q = 0; q < AQ; ++q) {
+            int chunk = li * AQ + q;
             int row = chunk * 8 + (lane >> 3);
             int c = (lane & 7) ^ ((row >> 1) & 7);
             int grow = m0 + row;
@@ -207,8 +210,8 @@ __global__ __launch_bounds__(512) void k_gemm4(GemmArgs g, const half8 *) {
             glds16(g.A + (size_t)grow * g.lda + kt * BK + c * 8, sA + chunk * 512);
         }
 #pragma unroll
-        for (int q = 0; q < BN / 32; ++q) {
-            int chunk = w4 * (BN / 32) + q;
+        for (int q = 0; q < BQ; ++q) {
+            int chunk = li * BQ + q;
             int row = chunk * 8 + (lane >> 3);
             int c = (lane & 7) ^ ((row >> 1) & 7);
             glds16(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8, sB + chunk * 512);
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(512) void k_gemm4(GemmArgs g, const half8 *) {
     }
     __syncthreads();
     constexpr int CPR = BN / 8;
-    for (int idx = tid; idx < BM * CPR; idx += 512) {
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
         int r = idx / CPR, c = (idx % CPR) * 8;
         if (m0 + r >= g.M) continue;
         *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c) = *(const half8 *)(sO + r * LDT + c);
@@ -543,6 +546,11 @@ int main(int argc, char **argv) {
         run2<128, 2, 2, 5>("  2x2 + no ds_reads (MFMA only)", g, Wf, iters, hA, hW, hb);
         run_k("specialised BN128 NST2", k_gemm4<128, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
         run_k("specialised BN128 NST3", k_gemm4<128, 3>, 128, 3, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("specialised BN128 NST2 2 loaders", k_gemm4<128, 2, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 384, 32768);
+        run_k("specialised BN128 NST2 8 loaders", k_gemm4<128, 2, 8>, 128, 2, g, Wf, iters, hA, hW, hb, 768, 32768);
+        run_k("specialised BN128 NST3 8 loaders", k_gemm4<128, 3, 8>, 128, 3, g, Wf, iters, hA, hW, hb, 768, 32768);
+        run_k("specialised BN128 NST4 8 loaders", k_gemm4<128, 4, 8>, 128, 4, g, Wf, iters, hA, hW, hb, 768, 32768);
+        run_k("specialised BN128 NST4 2 loaders", k_gemm4<128, 4, 2>, 128, 4, g, Wf, iters, hA, hW, hb, 384, 32768);
         run_k("specialised BN128 NST4", k_gemm4<128, 4>, 128, 4, g, Wf, iters, hA, hW, hb, 512, 32768);
         run_k("specialised BN64  NST2", k_gemm4<64, 2>, 64, 2, g, Wf, iters, hA, hW, hb, 512, 24576);
         run_k("specialised BN64  NST3", k_gemm4<64, 3>, 64, 3, g, Wf, iters, hA, hW, hb, 512, 24576);
