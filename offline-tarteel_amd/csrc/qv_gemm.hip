@@ -268,16 +268,28 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                 }
         }
         __syncthreads();
-        constexpr int CPR = BN / 4;  // 16-byte chunks per row
-        for (int idx = tid; idx < BM * CPR; idx += NT) {
-            int r = idx / CPR, c = (idx % CPR) * 4;
+        constexpr int CPR = BN / 4;            // 16-byte chunks per row
+        constexpr int IT = BM * CPR / NT;      // chunks per thread (exact)
+        // residual: all of a thread's old values are requested before the first store (a store
+        // followed by the next load of the same array would serialise one latency per chunk)
+        f32x4 old[IT];
+        if (EPI == EPI_RESID) {
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                int idx = tid + k * NT, r = idx / CPR, c = (idx % CPR) * 4;
+                const f32x4 *o = (const f32x4 *)((const float *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c);
+                if (m0 + r < g.M) old[k] = *o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            int idx = tid + k * NT, r = idx / CPR, c = (idx % CPR) * 4;
             if (m0 + r >= g.M) continue;
             f32x4 v = *(const f32x4 *)(sO + r * LDT + c);
             f32x4 *o = (f32x4 *)((float *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c);
             if (EPI == EPI_RESID) {
-                f32x4 old = *o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += old[e];
+                for (int e = 0; e < 4; ++e) v[e] += old[k][e];
             }
             *o = v;
         }
