@@ -229,7 +229,7 @@ def main():
         ach = rep["flops"] / (rep["avg_us"] * 1e-6) / 1e12
         traffic = None
         try:
-            pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())["kernels"]
+            pmc = json.loads((ROOT / "profiles" / "r01_i_pmc_traffic.json").read_text())["kernels"]
             traffic = pmc.get(rep["kernel"], {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
