@@ -1,7 +1,8 @@
 // qv_gemm.hip -- fused-epilogue f16 GEMM on v_mfma_f32_32x32x16_f16 (see qv_kernels.h).
 //
-// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias).  128 x BN x 64 tiles, 4 waves (2 x 2), two LDS
-// stages filled by direct global->LDS loads.  The epilogue goes back through LDS so that every
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias).  128 x BN x 64 tiles, 512 threads: 4 consumer waves
+// (2 x 2, fragment reads + MFMA + epilogue) and 4 loader waves (direct global->LDS loads of the
+// stage 1..3 K-steps ahead), 2..4 LDS stages.  The epilogue goes back through LDS so that every
 // global store is a full 16-byte lane-contiguous row segment (a wave writes 4 whole tile rows per
 // instruction); storing straight from the MFMA accumulator layout (one row per lane) cost more
 // time than the whole K loop.

@@ -6,10 +6,11 @@
 //                     natural MFMA fragment order: a lane reads 8 consecutive k of one row)
 //   accumulation      f32 in MFMA accumulators; bias / activation / residual fused in the epilogue
 //
-// GEMM: 128 x BN x 64 tiles, 256 threads (4 waves as 2 x 2), v_mfma_f32_32x32x16_f16, operands
-// staged with direct global->LDS loads (16 B per lane).  LDS rows are 128 B; the 16-B chunk index
-// is XOR-swizzled with (row & 7) ON THE GLOBAL SOURCE ADDRESS (the LDS write of a direct load is
-// lane-linear) and on the fragment read, which makes the ds_read_b128 fragment reads conflict-free.
+// GEMM: 128 x BN x 64 tiles, 512 threads (4 consumer waves as 2 x 2 on v_mfma_f32_32x32x16_f16 +
+// 4 loader waves), operands staged with direct global->LDS loads (16 B per lane).  LDS rows are
+// 128 B; the 16-B chunk index is XOR-swizzled with (row >> 1) & 7 ON THE GLOBAL SOURCE ADDRESS (the
+// LDS write of a direct load is lane-linear) and on the fragment read, which makes the
+// ds_read_b128 fragment reads conflict-free.
 #pragma once
 
 #include <hip/hip_runtime.h>
