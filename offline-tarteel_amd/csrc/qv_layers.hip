@@ -537,6 +537,200 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
     }
 }
 
+// Wave-specialised version of the same computation (same arithmetic, same order).  k_attention's
+// duration is one wave's serial chain -- per key tile two exposed global-load latencies (K and
+// position fragments, then V) in front of 16 MFMAs -- and it keeps a wave busy with one query tile
+// after the other for long utterances.  Here a block is one (head, utterance, group of 4 query
+// tiles): waves 0..3 are consumers (one query tile each; fragments come from LDS), waves 4..7 are
+// loaders that stage, TWO key tiles ahead (3 buffers), the K tile (32 keys x 64), the V^T tile
+// (64 x 32 keys) and the 32 NEW relative-position rows of the tile: the position rows the four query
+// tiles need form a sliding window of 160 rows that advances by 32 per key tile, kept in a 256-row
+// ring (window of tile kt + the 64 rows prefetched for kt + 1 and kt + 2 never overlap in it).
+#define ATT_RING 256
+#define ATT_NST 3
+__device__ __forceinline__ void att_glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l,
+                                     16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void k_attention_ws(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
+                                                      const half_t *__restrict__ pos, int pos_ld,
+                                                      const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                      const int32_t *__restrict__ len, const int32_t *__restrict__ row_off,
+                                                      half_t *__restrict__ out, int t_max, int t_pad) {
+    __shared__ __attribute__((aligned(16))) half_t sK[ATT_NST][32 * 64];    // [key][d], 16-B chunks swizzled by (key >> 1) & 7
+    __shared__ __attribute__((aligned(16))) half_t sV[ATT_NST][64 * 32];    // [d][key], 16-B chunks swizzled by (d >> 2) & 3
+    __shared__ __attribute__((aligned(16))) half_t sP[ATT_RING * 64];       // ring of position rows, swizzled like sK
+    __shared__ float slab[4][32 * ATT_LDS_LD];
+    const int b = blockIdx.z, h = blockIdx.x, qg = blockIdx.y;
+    const int T = len[b];
+    if (qg * 128 >= T) return;                       // whole block: no query of this group exists
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool loader = wave >= 4;
+    const int w4 = wave & 3, l31 = lane & 31, hi = lane >> 5;
+    const size_t row0 = (size_t)row_off[b];
+    const half_t *kb = qk + row0 * (2 * QV_D) + QV_D + h * QV_DK;
+    const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;
+    const half_t *pb = pos + h * QV_DK;
+    const int n_kt = (T + 31) >> 5;
+    const int Rb = t_max - 128 * qg - 128;           // first position row of key tile 0's window
+
+    if (loader) {
+        // one K, one V and one position load per loader wave and key tile (1 KB each)
+        auto stage = [&](int kt) {
+            const int j0 = kt * 32, buf = kt % ATT_NST;
+            {   // K: 8 keys x 128 B per wave
+                int r = w4 * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+                int kj = j0 + r;
+                kj = kj < T ? kj : T - 1;
+                att_glds16(kb + (size_t)kj * (2 * QV_D) + c * 8, sK[buf] + w4 * 512);
+            }
+            {   // V^T: 16 d rows x 64 B per wave (keys j0 .. j0 + 31 < t_pad)
+                int r = w4 * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+                att_glds16(vb + (size_t)r * t_pad + j0 + c * 8, sV[buf] + w4 * 512);
+            }
+        };
+        auto pos_rows = [&](int first, int n8) {   // n8 chunks of 8 rows starting at window row `first`, this wave's share
+            for (int q = w4; q < n8; q += 4) {
+                int wr = first + q * 8 + (lane >> 3);                 // row relative to Rb
+                int ring = wr % ATT_RING;
+                int c = (lane & 7) ^ ((ring >> 1) & 7);
+                int rr = Rb + wr;
+                rr = rr < 0 ? 0 : (rr > 2 * t_max - 2 ? 2 * t_max - 2 : rr);
+                att_glds16(pb + (size_t)rr * pos_ld + c * 8, sP + (size_t)((first + q * 8) % ATT_RING) * 64);
+            }
+        };
+        // per wave: unit(0) = 5 position chunks + K + V, unit(kt >= 1) = K + V + 1 position chunk (3 loads)
+        pos_rows(0, 20);        // rows 0 .. 159: the window of tile 0
+        stage(0);
+        if (n_kt > 1) {
+            stage(1);
+            pos_rows(32 + 128, 4);
+        }
+        for (int kt = 0; kt < n_kt; ++kt) {
+            // unit(kt) has landed once only unit(kt + 1) may still be in flight
+            if (kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // tile kt visible; the buffers of tile kt - 1 are free
+            if (kt + 2 < n_kt) {
+                stage(kt + 2);
+                pos_rows(32 * (kt + 2) + 128, 4);   // the 32 new rows of tile kt + 2
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumers ----------
+    const int i0 = qg * 128 + w4 * 32;
+    const bool active = i0 < T;
+    const half_t *qb = qk + row0 * (2 * QV_D) + h * QV_DK;
+    float *sl = slab[w4];
+    half8 qu[4], qv[4];
+    {
+        int qi = i0 + l31;
+        qi = qi < T ? qi : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            int d = ks * 16 + hi * 8;
+            half8 q8 = *(const half8 *)(qb + (size_t)qi * (2 * QV_D) + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float qf = (float)q8[e];
+                qu[ks][e] = (half_t)(qf + bias_u[h * QV_DK + d + e]);
+                qv[ks][e] = (half_t)(qf + bias_v[h * QV_DK + d + e]);
+            }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        if (!active) continue;
+        const int j0 = kt * 32, buf = kt % ATT_NST;
+        // window-relative position rows of this wave: 32 kt + 96 - 32 w4 + c, c in [0, 64)
+        const int wr0 = 32 * kt + 96 - 32 * w4 + l31;
+        const int ring0 = wr0 % ATT_RING, ring1 = (wr0 + 32) % ATT_RING;
+        f32x16 st, r0, r1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; r0[r] = 0.f; r1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + hi;
+            half8 kf = *(const half8 *)(sK[buf] + l31 * 64 + ((c ^ ((l31 >> 1) & 7)) << 3));
+            half8 p0 = *(const half8 *)(sP + ring0 * 64 + ((c ^ ((ring0 >> 1) & 7)) << 3));
+            half8 p1 = *(const half8 *)(sP + ring1 * 64 + ((c ^ ((ring1 >> 1) & 7)) << 3));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);
+            r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            sl[l31 * ATT_LDS_LD + c] = r0[r];
+            sl[l31 * ATT_LDS_LD + 32 + c] = r1[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float p[16];
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float bd = sl[l31 * ATT_LDS_LD + 31 - l31 + jj];
+            float sc = (st[r] + bd) * 0.125f;
+            p[r] = (j0 + jj < T) ? sc : -1e30f;
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float m_new = fmaxf(m_run, mx);
+        float corr = __expf(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float e = (j0 + jj < T) ? __expf(p[r] - m_new) : 0.f;
+            p[r] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * corr + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 pbf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pbf[e] = (half_t)p[8 * ks + e];
+            // V^T pieces: keys 16 ks + 4 hi + {0..3} and + 8 -> 16-B chunks 2 ks and 2 ks + 1, 8-byte half `hi`
+            const int da = l31, dc = 32 + l31;
+            half4 a0 = *(const half4 *)(sV[buf] + da * 32 + (((2 * ks) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
+            half4 a1 = *(const half4 *)(sV[buf] + da * 32 + (((2 * ks + 1) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
+            half4 c0 = *(const half4 *)(sV[buf] + dc * 32 + (((2 * ks) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+            half4 c1 = *(const half4 *)(sV[buf] + dc * 32 + (((2 * ks + 1) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+            half8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            half8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pbf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pbf, o1, 0, 0, 0);
+        }
+    }
+    if (active && i0 + l31 < T) {
+        float inv = 1.f / l_run;
+        half_t *o = out + (row0 + i0 + l31) * QV_D + h * QV_DK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int d = 8 * q + 4 * hi;
+            half4 h0, h1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h0[e] = (half_t)(o0[4 * q + e] * inv); h1[e] = (half_t)(o1[4 * q + e] * inv); }
+            *(half4 *)(o + d) = h0;
+            *(half4 *)(o + 32 + d) = h1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ conv module --------
 // depthwise Conv1d(512, k=9, pad 4) + folded BatchNorm + Swish on f16 [M][512]; input frames
 // t >= len[b] read as zero (the reference zeroes padded frames after GLU).  A lane owns 8
@@ -679,8 +873,14 @@ void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s) {
 
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_pad, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out, t_max,
-                       t_pad);
+    static const bool old_kernel = [] { const char *e = getenv("QVERSE_ATT_OLD"); return e && e[0] == '1'; }();
+    if (old_kernel) {
+        hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out,
+                           t_max, t_pad);
+        return;
+    }
+    hipLaunchKernelGGL(k_attention_ws, dim3(QV_H, (t_max + 127) / 128, batch), dim3(512), 0, s, qk, vt, pos, pos_ld, bu, bv,
+                       len, row_off, out, t_max, t_pad);
 }
 
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,
