@@ -25,13 +25,15 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------ front-end ----------
-// One wave per STFT frame: pre-emphasis + reflect padding + Hann window on load, 512-point
-// radix-2 Stockham FFT in LDS (9 passes, 4 butterflies per lane per pass), power spectrum,
-// sparse mel projection (each filter touches <= 32 bins), log(x + 2^-24).
+// One wave per STFT frame: pre-emphasis + reflect padding + Hann window on load; the 512 real
+// samples are packed as 256 complex ones (z[n] = x[2n] + i x[2n+1]), transformed with a 256-point
+// radix-2 Stockham FFT in LDS (8 passes, 2 butterflies per lane per pass) and unpacked to the 257
+// bins of the real transform; power spectrum, sparse mel projection (each filter touches <= 32
+// bins), log(x + 2^-24).
 __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio, int64_t n_max,
                                                 const int32_t *__restrict__ n_samples, const FrontendTab ft,
                                                 float *__restrict__ feats, int tm_max) {
-    __shared__ float2 buf[4][2][512];
+    __shared__ float2 buf[4][2][256];
     __shared__ float pw[4][264];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y, t = blockIdx.x * 4 + wave;
@@ -40,23 +42,24 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
     if (t >= tm) return;  // frames past the utterance are zeroed by the normalisation kernel
     const float *x = audio + (size_t)b * n_max;
     float2 *A = buf[wave][0], *Bf = buf[wave][1];
-    for (int i = lane; i < 512; i += 64) {
+    auto sample = [&](int i) {
         int s = t * 160 - 256 + i;
         if (s < 0) s = -s;
         if (s >= n) s = 2 * (n - 1) - s;
         s = s < 0 ? 0 : s;
         float y = x[s] - (s > 0 ? 0.97f * x[s - 1] : 0.f);
-        A[i] = make_float2(y * ft.window[i], 0.f);
-    }
-    // Stockham autosort, radix 2: pass p (len = 1 << p): out[j*2*len + k] , out[... + len]
+        return y * ft.window[i];
+    };
+    for (int i = lane; i < 256; i += 64) A[i] = make_float2(sample(2 * i), sample(2 * i + 1));
+    // Stockham autosort, radix 2, N = 256: pass p (len = 1 << p): out[j*2*len + k] , out[... + len]
     float2 *src = A, *dst = Bf;
-    for (int p = 0; p < 9; ++p) {
+    for (int p = 0; p < 8; ++p) {
         int len = 1 << p;  // half-size of the butterflies produced so far
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < 256; i += 64) {
+        for (int i = lane; i < 128; i += 64) {
             int k = i & (len - 1), j = i >> p;  // j: group, k: index within group
-            float2 u = src[j * len + k], v = src[j * len + k + 256];
-            // twiddle w = exp(-2 pi i * k / (2 len))
+            float2 u = src[j * len + k], v = src[j * len + k + 128];
+            // twiddle w = exp(-2 pi i * k / (2 len)) from the 512-point table
             float2 w = ft.twiddle[k * (256 >> p)];
             float2 vw = make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
             dst[j * 2 * len + k] = make_float2(u.x + vw.x, u.y + vw.y);
@@ -65,9 +68,21 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
         float2 *tmp = src; src = dst; dst = tmp;
     }
     __builtin_amdgcn_wave_barrier();
+    // X[k] = E[k] - i W^k O[k],  E = (Z[k] + conj Z[256-k]) / 2,  O = (Z[k] - conj Z[256-k]) / 2,  W = exp(-2 pi i / 512)
     for (int k = lane; k < 257; k += 64) {
-        float2 z = src[k];
-        float mag = sqrtf(z.x * z.x + z.y * z.y);
+        float2 X;
+        if (k == 0 || k == 256) {
+            float2 z0 = src[0];
+            X = make_float2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.f);
+        } else {
+            float2 zk = src[k], zc = src[256 - k];
+            float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+            float2 O = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+            float2 w = ft.twiddle[k];
+            float2 P = make_float2(__builtin_fmaf(w.x, O.x, -(w.y * O.y)), __builtin_fmaf(w.x, O.y, w.y * O.x));
+            X = make_float2(E.x + P.y, E.y - P.x);
+        }
+        float mag = sqrtf(X.x * X.x + X.y * X.y);
         pw[wave][k] = mag * mag;
     }
     __builtin_amdgcn_wave_barrier();
