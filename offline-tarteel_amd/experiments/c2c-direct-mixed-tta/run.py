@@ -11,5 +11,6 @@ import offline_tarteel_amd  # noqa: E402,F401
 from offline_tarteel_amd import plugin as _p  # noqa: E402
 
 predict = _p.predict_tta
+predict_batch = _p.predict_tta_batch   # used by `benchmark.runner --batch N`
 transcribe = _p.transcribe
 model_size = _p.model_size

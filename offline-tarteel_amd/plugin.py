@@ -128,24 +128,9 @@ def model_size() -> int:
 
 
 # ------------------------------------------------------------------ TTA variant --------
-def predict_tta(audio_path: str) -> dict:
-    """c2c-direct-mixed-tta/run.py:117-149: anchor pass, gate 0.5, 0.9x / 1.1x passes (batched
-    into ONE engine call instead of two threads on one session), majority else score pick."""
-    import torch
-
-    audio = load_audio(audio_path)
-    anchor = predict_arrays([audio], round_score=False)[0]
-    if anchor["score"] >= CONFIDENCE_SKIP_THRESHOLD:
-        return anchor
-    # 0.9x / 1.1x copies are made on the GPU (qv_upfirdn, bit-identical to the reference's
-    # scipy.signal.resample_poly call) and go through the engine as one batch of two
-    eng = _ensure_engine()
-    dev = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).cuda(eng.device)
-    a09, a11 = eng.speed_perturb(dev, 0.9), eng.speed_perturb(dev, 1.1)
-    pair = torch.zeros((2, max(a09.numel(), a11.numel())), dtype=torch.float32, device=dev.device)
-    pair[0, : a09.numel()] = a09
-    pair[1, : a11.numel()] = a11
-    p09, p11 = (_to_dict(r, False) for r in eng.predict_batch(pair, [a09.numel(), a11.numel()]))
+def _tta_combine(p09: dict, anchor: dict, p11: dict) -> dict:
+    """c2c-direct-mixed-tta/run.py:133-149: majority over (surah, ayah) of [0.9x, anchor, 1.1x],
+    else the highest score."""
     preds = [p09, anchor, p11]
     keys = [(p["surah"], p["ayah"]) for p in preds]
     top, n = Counter(keys).most_common(1)[0]
@@ -160,3 +145,39 @@ def predict_tta(audio_path: str) -> dict:
     best["tta_preds"] = keys
     best["tta_scores"] = [p["score"] for p in preds]
     return best
+
+
+def predict_tta_arrays(arrays) -> list[dict]:
+    """c2c-direct-mixed-tta/run.py:117-149 for a list of clips: one anchor pass over all of them,
+    gate 0.5, then the 0.9x / 1.1x copies of the gated clips -- made on the GPU (qv_upfirdn,
+    bit-identical to the reference's scipy.signal.resample_poly call) -- as further engine batches
+    (the reference runs them as two threads on one session)."""
+    import torch
+
+    eng = _ensure_engine()
+    anchors = predict_arrays(arrays, round_score=False)
+    hard = [i for i, a in enumerate(anchors) if a["score"] < CONFIDENCE_SKIP_THRESHOLD]
+    out = list(anchors)
+    per_call = max(1, eng.max_batch // 2)
+    for s in range(0, len(hard), per_call):
+        idx = hard[s: s + per_call]
+        variants = []
+        for i in idx:
+            dev = torch.from_numpy(np.ascontiguousarray(arrays[i], dtype=np.float32)).cuda(eng.device)
+            variants += [eng.speed_perturb(dev, 0.9), eng.speed_perturb(dev, 1.1)]
+        lens = [int(v.numel()) for v in variants]
+        rows = torch.zeros((len(variants), max(lens)), dtype=torch.float32, device=variants[0].device)
+        for r, v in enumerate(variants):
+            rows[r, : v.numel()] = v
+        res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens)]
+        for k, i in enumerate(idx):
+            out[i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
+    return out
+
+
+def predict_tta(audio_path: str) -> dict:
+    return predict_tta_arrays([load_audio(audio_path)])[0]
+
+
+def predict_tta_batch(audio_paths) -> list[dict]:
+    return predict_tta_arrays([load_audio(p) for p in audio_paths])

@@ -210,6 +210,12 @@ def test_plugin_and_runner_on_synthetic_corpus(tmp_path, monkeypatch):
     assert isinstance(plugin.transcribe(str(corpus / "s0.wav")), str)
     tta = runner.run_experiment(runner.discover_experiments("c2c-direct-mixed-tta")[0], samples, corpus)
     assert tta["total"] == 3
+    # the batched TTA path (anchors as one batch, 0.9x / 1.1x copies of the gated clips as another)
+    tta_b = runner.run_experiment(runner.discover_experiments("c2c-direct-mixed-tta")[0], samples, corpus, batch=3)
+    for a, b in zip(tta["per_sample"], tta_b["per_sample"]):
+        assert a["predicted"] == b["predicted"]
+    one_tta = plugin.predict_tta(str(corpus / "s1.wav"))
+    assert set(one_tta) >= {"surah", "ayah", "score"}
     plugin._engine.close()
     monkeypatch.setattr(plugin, "_engine", None)
 
