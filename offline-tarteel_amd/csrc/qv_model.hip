@@ -438,6 +438,42 @@ int get_pos(qv_engine *eng, QvModel *m, int t_max, hipStream_t stream, const hal
     return QV_OK;
 }
 
+// activations of execution context k (into the flat fields, then filed under ctx_acts[k])
+int alloc_context(qv_engine *eng, QvModel *m, int k, bool sub_unfused) {
+    const size_t Bz = (size_t)m->max_batch, M = Bz * m->t3_cap;
+    const int t_pad_cap = (m->t3_cap + 31) / 32 * 32;
+    m->lens_host = nullptr;
+    TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
+    TRY(dal(eng, m, Bz * QV_NMEL * 2, &m->mel_stats));
+    // the conv0 activation only exists on the two-kernel cross-check path (QVERSE_SUB_UNFUSED=1)
+    m->c0 = nullptr;
+    if (sub_unfused) TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
+    TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1));
+    TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1p));
+    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2));
+    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2p));
+    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2k));
+    TRY(dal(eng, m, M * QV_D, &m->x));
+    TRY(dal(eng, m, M * QV_D, &m->ln));
+    TRY(dal(eng, m, M * QV_FF, &m->hbuf));
+    TRY(dal(eng, m, M * 2 * QV_D, &m->qk));
+    TRY(dal(eng, m, Bz * QV_D * t_pad_cap, &m->vt));
+    TRY(dal(eng, m, M * QV_D, &m->att));
+    TRY(dal(eng, m, M * QV_D, &m->glu));
+    TRY(dal(eng, m, M * QV_D, &m->dw));
+    TRY(dal(eng, m, M * QV_D, &m->xh));
+    TRY(dal(eng, m, M * HEAD_N, &m->logits));
+    TRY(dal(eng, m, Bz * 6 + 1, &m->lens_dev));
+    TRY(dal(eng, m, M, &m->row_map));
+    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * (Bz * 6 + 1), hipHostMallocDefault));
+    m->ctx_acts[k].lens_host = m->lens_host;  // owned by the context from here on
+    m->tap_x = nullptr;
+    if (m->save_taps) TRY(dal(eng, m, (size_t)(N_LAYERS + 1) * M * QV_D, &m->tap_x));
+    m->last_batch = m->last_tmax = m->last_tm_max = m->last_rows = 0;
+    m->ctx_acts[k] = *static_cast<QvActs *>(m);
+    return QV_OK;
+}
+
 }  // namespace
 
 int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
@@ -470,37 +506,8 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     const char *su = getenv("QVERSE_SUB_UNFUSED");
     const bool sub_unfused = su && su[0] == '1';
     for (QvActs &a : m->ctx_acts) { a = QvActs(); a.lens_host = nullptr; }
-    for (int k = m->n_ctx - 1; k >= 0; --k) {
-    m->lens_host = nullptr;
-    TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
-    TRY(dal(eng, m, Bz * QV_NMEL * 2, &m->mel_stats));
-    // the conv0 activation only exists on the two-kernel cross-check path (QVERSE_SUB_UNFUSED=1)
-    m->c0 = nullptr;
-    if (sub_unfused) TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
-    TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1));
-    TRY(dal(eng, m, Bz * m->t2_cap * 20 * QV_SUBC, &m->c1p));
-    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2));
-    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2p));
-    TRY(dal(eng, m, Bz * m->t3_cap * 10 * QV_SUBC, &m->c2k));
-    TRY(dal(eng, m, M * QV_D, &m->x));
-    TRY(dal(eng, m, M * QV_D, &m->ln));
-    TRY(dal(eng, m, M * QV_FF, &m->hbuf));
-    TRY(dal(eng, m, M * 2 * QV_D, &m->qk));
-    TRY(dal(eng, m, Bz * QV_D * t_pad_cap, &m->vt));
-    TRY(dal(eng, m, M * QV_D, &m->att));
-    TRY(dal(eng, m, M * QV_D, &m->glu));
-    TRY(dal(eng, m, M * QV_D, &m->dw));
-    TRY(dal(eng, m, M * QV_D, &m->xh));
-    TRY(dal(eng, m, M * HEAD_N, &m->logits));
-    TRY(dal(eng, m, Bz * 6 + 1, &m->lens_dev));
-    TRY(dal(eng, m, M, &m->row_map));
-    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * (Bz * 6 + 1), hipHostMallocDefault));
-    m->ctx_acts[k].lens_host = m->lens_host;  // owned by the context from here on
-    m->tap_x = nullptr;
-    if (m->save_taps) TRY(dal(eng, m, (size_t)(N_LAYERS + 1) * M * QV_D, &m->tap_x));
-    m->last_batch = m->last_tmax = m->last_tm_max = m->last_rows = 0;
-    m->ctx_acts[k] = *static_cast<QvActs *>(m);
-    }  // contexts, allocated last to first so that the flat fields end up being context 0
+    // contexts are allocated last to first so that the flat fields end up being context 0
+    for (int k = m->n_ctx - 1; k >= 0; --k) TRY(alloc_context(eng, m, k, sub_unfused));
     return QV_OK;
 }
 
