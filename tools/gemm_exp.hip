@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs g, const half8 *Wf) {
 // and issue MFMAs (2 x 2 layout, 64 x 64 each); waves 4..7 only issue the global->LDS loads of the
 // stage NST - 1 steps ahead (A and W, both through LDS as in the product kernel).  One s_barrier per
 // K-step joins the two groups: the loaders arrive after their vmcnt says stage kt + 1 has landed.
-template <int BN, int NST, int NL = 4>
+template <int BN, int NST, int NL = 4, int VR = 0>
 __global__ __launch_bounds__((4 + NL) * 64) void k_gemm4(GemmArgs g, const half8 *) {
     constexpr int BM = 128, BK = 64;
     constexpr int WN = BN / 2, NF = WN / 32;
@@ -218,7 +218,37 @@ __global__ __launch_bounds__((4 + NL) * 64) void k_gemm4(GemmArgs g, const half8
         }
     };
 
-    if (loader) {
+    if (loader && VR) {
+        // classic path: global -> VGPR -> ds_write_b128 (same LDS image as the direct loads)
+        half8 ra[AQ], rb[BQ];
+        auto ldg = [&](int kt) {
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) {
+                int chunk = li * AQ + q, row = chunk * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+                int grow = m0 + row;
+                grow = grow < g.M ? grow : g.M - 1;
+                ra[q] = *(const half8 *)(g.A + (size_t)grow * g.lda + kt * BK + c * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) {
+                int chunk = li * BQ + q, row = chunk * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+                rb[q] = *(const half8 *)(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8);
+            }
+        };
+        auto stw = [&](int kt) {
+            half_t *sA = (half_t *)(smem + (kt % NST) * STAGE_BYTES), *sB = (half_t *)((unsigned char *)sA + A_BYTES);
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) *(half8 *)(sA + (li * AQ + q) * 512 + lane * 8) = ra[q];
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) *(half8 *)(sB + (li * BQ + q) * 512 + lane * 8) = rb[q];
+        };
+        ldg(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            stw(kt);
+            if (kt + 1 < nk) ldg(kt + 1);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else if (loader) {
         // stages 0 .. NST-2 in flight before the first barrier
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
@@ -546,6 +576,9 @@ int main(int argc, char **argv) {
         run2<128, 2, 2, 5>("  2x2 + no ds_reads (MFMA only)", g, Wf, iters, hA, hW, hb);
         run_k("specialised BN128 NST2", k_gemm4<128, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
         run_k("specialised BN128 NST3", k_gemm4<128, 3>, 128, 3, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("via-VGPR BN128 NST2", k_gemm4<128, 2, 4, 1>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("via-VGPR BN128 NST2 8 loaders", k_gemm4<128, 2, 8, 1>, 128, 2, g, Wf, iters, hA, hW, hb, 768, 32768);
+        run_k("via-VGPR BN64 NST2", k_gemm4<64, 2, 4, 1>, 64, 2, g, Wf, iters, hA, hW, hb, 512, 24576);
         run_k("specialised BN128 NST2 2 loaders", k_gemm4<128, 2, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 384, 32768);
         run_k("specialised BN128 NST2 8 loaders", k_gemm4<128, 2, 8>, 128, 2, g, Wf, iters, hA, hW, hb, 768, 32768);
         run_k("specialised BN128 NST3 8 loaders", k_gemm4<128, 3, 8>, 128, 3, g, Wf, iters, hA, hW, hb, 768, 32768);
