@@ -242,11 +242,49 @@ __global__ __launch_bounds__((4 + NL) * 64) void k_gemm4(GemmArgs g, const half8
 #pragma unroll
             for (int q = 0; q < BQ; ++q) *(half8 *)(sB + (li * BQ + q) * 512 + lane * 8) = rb[q];
         };
-        ldg(0);
-        for (int kt = 0; kt < nk; ++kt) {
-            stw(kt);
-            if (kt + 1 < nk) ldg(kt + 1);
-            __builtin_amdgcn_s_barrier();
+        if (VR == 1) {
+            ldg(0);
+            for (int kt = 0; kt < nk; ++kt) {
+                stw(kt);
+                if (kt + 1 < nk) ldg(kt + 1);
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            // two register sets: loads run two K-steps ahead of the LDS writes
+            half8 ra2[AQ], rb2[BQ];
+            auto ldg2 = [&](int kt) {
+#pragma unroll
+                for (int q = 0; q < AQ; ++q) {
+                    int chunk = li * AQ + q, row = chunk * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+                    int grow = m0 + row;
+                    grow = grow < g.M ? grow : g.M - 1;
+                    ra2[q] = *(const half8 *)(g.A + (size_t)grow * g.lda + kt * BK + c * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < BQ; ++q) {
+                    int chunk = li * BQ + q, row = chunk * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+                    rb2[q] = *(const half8 *)(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + c * 8);
+                }
+            };
+            auto stw2 = [&](int kt) {
+                half_t *sA = (half_t *)(smem + (kt % NST) * STAGE_BYTES), *sB = (half_t *)((unsigned char *)sA + A_BYTES);
+#pragma unroll
+                for (int q = 0; q < AQ; ++q) *(half8 *)(sA + (li * AQ + q) * 512 + lane * 8) = ra2[q];
+#pragma unroll
+                for (int q = 0; q < BQ; ++q) *(half8 *)(sB + (li * BQ + q) * 512 + lane * 8) = rb2[q];
+            };
+            ldg(0);
+            if (nk > 1) ldg2(1);
+            for (int kt = 0; kt < nk; kt += 2) {
+                stw(kt);
+                if (kt + 2 < nk) ldg(kt + 2);
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < nk) {
+                    stw2(kt + 1);
+                    if (kt + 3 < nk) ldg2(kt + 3);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
         }
     } else if (loader) {
         // stages 0 .. NST-2 in flight before the first barrier
@@ -576,6 +614,8 @@ int main(int argc, char **argv) {
         run2<128, 2, 2, 5>("  2x2 + no ds_reads (MFMA only)", g, Wf, iters, hA, hW, hb);
         run_k("specialised BN128 NST2", k_gemm4<128, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
         run_k("specialised BN128 NST3", k_gemm4<128, 3>, 128, 3, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("via-VGPR x2 BN128 NST2", k_gemm4<128, 2, 4, 2>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
+        run_k("via-VGPR x2 BN128 NST3", k_gemm4<128, 3, 4, 2>, 128, 3, g, Wf, iters, hA, hW, hb, 512, 32768);
         run_k("via-VGPR BN128 NST2", k_gemm4<128, 2, 4, 1>, 128, 2, g, Wf, iters, hA, hW, hb, 512, 32768);
         run_k("via-VGPR BN128 NST2 8 loaders", k_gemm4<128, 2, 8, 1>, 128, 2, g, Wf, iters, hA, hW, hb, 768, 32768);
         run_k("via-VGPR BN64 NST2", k_gemm4<64, 2, 4, 1>, 64, 2, g, Wf, iters, hA, hW, hb, 512, 24576);
