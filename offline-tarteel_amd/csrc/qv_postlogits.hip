@@ -192,27 +192,40 @@ __device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int str
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
     // the text is fetched 8 codes per (possibly unaligned) load: one memory access per 8 steps
     // of the recurrence instead of one per step; every text buffer is padded by >= 8 bytes
+    // The match masks of CH consecutive codes are requested TOGETHER, before the dependent add chain
+    // of those steps: the recurrence is one serial chain per lane, and a mask load inside every step
+    // (L1/L2 or LDS latency each) used to be most of a step's time.  Codes past the end of the text
+    // and codes outside the alphabet get an all-zero mask, which leaves V unchanged.
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    constexpr int CH = W <= 4 ? 8 : (W <= 8 ? 4 : 2);
     for (int j0 = 0; j0 < n; j0 += 8) {
         uint64_t chunk = *(const u64_unaligned *)(text + j0);
         const int cnt = n - j0 < 8 ? n - j0 : 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (e >= cnt) break;
-            int c = (int)((chunk >> (8 * e)) & 0xFF);
-            const uint64_t *M = pm + (size_t)(c < QV_NSYM ? c : 0) * stride;
-            uint64_t zero_if_other = c < QV_NSYM ? ~0ull : 0ull;
-            uint64_t carry = 0;
+        for (int g0 = 0; g0 < 8; g0 += CH) {
+            if (g0 >= cnt) break;
+            uint64_t mk[CH][W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                uint64_t v = V[w], mm = M[w] & zero_if_other;
-                uint64_t u = v & mm;
-                uint64_t s = v + u;
-                uint64_t c1 = s < v;
-                uint64_t s2 = s + carry;
-                uint64_t c2 = s2 < s;
-                carry = c1 | c2;
-                V[w] = s2 | (v & ~mm);
+            for (int e = 0; e < CH; ++e) {
+                int c = (int)((chunk >> (8 * (g0 + e))) & 0xFF);
+                const bool valid = g0 + e < cnt && c < QV_NSYM;
+                const uint64_t *M = pm + (size_t)(valid ? c : 0) * stride;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint64_t x = M[w];
+                    mk[e][w] = valid ? x : 0ull;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                unsigned long long carry = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint64_t v = V[w], mm = mk[e][w];
+                    // v + (v & mm) + carry with the carry chained through the words (add / addc)
+                    uint64_t s2 = __builtin_addcll(v, v & mm, carry, &carry);
+                    V[w] = s2 | (v & ~mm);
+                }
             }
         }
     }
@@ -562,7 +575,9 @@ __device__ __forceinline__ TextRef text_of(const QvTables &tab, int v, int varia
     return t;
 }
 
-__device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane) {
+#define FRAG_DIRECT_MAX 128   // up to two rounds of windows: evaluate them all
+#define FRAG_SCRATCH 2112      // int16 per wave: anchors [QV_MAXQ / 4 + 2] + refine list [QV_MAXQ]
+__device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane, int16_t *scratch) {
     const QvUtt &u = wk.utt[b];
     double *out = wk.fs + ((size_t)b * tab.n_verses + v) * 3 + variant;
     if (variant == 2 && tab.nobsm_len[v] == 0) { if (lane == 0) *out = -1.0; return; }
@@ -593,13 +608,43 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
     int nwin = windows ? (L - s + 1) : 0;
     // full-string LCS comes from k_lcs_full (one text per lane); lanes here = sliding windows
     int full = wk.lcsf[((size_t)b * tab.n_verses + v) * 3 + variant], best = 0;
-    for (int base = 0; base < nwin; base += 64) {
-        int job = base + lane;
-        if (job >= nwin) continue;
-        int r = lcs_dispatch(W, pm, stride, lt + job, s, s);
-        best = max(best, r);
+    // Only the maximum over the windows matters, and sliding the window by one position drops one
+    // character and appends one, so LCS(w + d) <= LCS(w) + d.  With many windows, pass 0 evaluates
+    // every 4th window (and the last one) and takes their maximum B; pass 1 evaluates exactly only
+    // the windows whose bound from BOTH neighbouring anchors still exceeds B.  The result is the
+    // exact maximum.  Up to FRAG_DIRECT_MAX windows are simply all evaluated in pass 0.
+    int16_t *cv = scratch, *list = scratch + FRAG_SCRATCH / 2;
+    const bool direct = nwin <= FRAG_DIRECT_MAX;
+    const int nco = (nwin + 3) >> 2;                          // anchors 4k, k < nco; cv[nco] = last window
+    int nlist = direct ? nwin : nco + 1;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = lane; i < nlist; i += 64) {
+            int w = pass ? (int)list[i] : (direct ? i : (i < nco ? 4 * i : nwin - 1));
+            int r = lcs_dispatch(W, pm, stride, lt + w, s, s);
+            if (!pass && !direct) cv[i] = (int16_t)r;
+            best = max(best, r);
+        }
+        best = wave_max_i(best);
+        if (direct || pass) break;
+        __builtin_amdgcn_wave_barrier();
+        nlist = 0;
+        for (int base = 0; base < nwin; base += 64) {
+            int w = base + lane;
+            bool need = false;
+            if (w < nwin - 1 && (w & 3) != 0) {
+                int k0 = w >> 2, a1 = 4 * (k0 + 1);
+                int x0 = cv[k0], x1;
+                if (a1 <= nwin - 1) x1 = cv[k0 + 1];
+                else { a1 = nwin - 1; x1 = cv[nco]; }
+                int ub = min(x0 + (w - 4 * k0), x1 + (a1 - w));
+                need = ub > best;
+            }
+            unsigned long long mask = __ballot(need);
+            if (need) list[nlist + __popcll(mask & ((1ull << lane) - 1ull))] = (int16_t)w;
+            nlist += __popcll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    best = wave_max_i(best);
     if (lane == 0) {
         double fr = ratio_from(full, m, n);
         double res = fr;
@@ -665,6 +710,8 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
 }
 
 __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode) {
+    __shared__ int16_t frag_scratch[4][FRAG_SCRATCH];
+    int16_t *scratch = frag_scratch[threadIdx.x >> 6];
     int lane = threadIdx.x & 63;
     int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
     int b;
@@ -676,10 +723,10 @@ __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode)
     if (mode == 0) {
         const int32_t *cand1 = wk.cand1 + (size_t)b * tab.n_verses;
         int jobs = u.n_cand1 * 3;
-        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, cand1[j / 3], j % 3, lane);
+        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, cand1[j / 3], j % 3, lane, scratch);
     } else {
         int jobs = tab.n_verses * 2;  // search(): clean + alt only (quran_db.py:105-110)
-        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, j >> 1, j & 1, lane);
+        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, j >> 1, j & 1, lane, scratch);
     }
 }
 

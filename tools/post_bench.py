@@ -38,7 +38,8 @@ def main():
     rng = np.random.default_rng(20260630)
     n_verses = len(eng.tables.s["tok_off"]) // 6
     rows = []
-    for name, noise, boost in (("clean (gate passes)", 1.0, 8.0), ("noisy (gate fails -> CTC rerank)", 3.5, 4.0)):
+    for name, noise, boost in (("clean (gate passes)", 1.0, 8.0), ("corrupted", 2.0, 6.0), ("corrupted more", 2.4, 6.0),
+                               ("noisy (gate fails -> CTC rerank)", 3.5, 4.0)):
         lps, used = [], 0
         while len(lps) < B:
             v = int(rng.integers(0, n_verses))
