@@ -576,6 +576,9 @@ __device__ __forceinline__ TextRef text_of(const QvTables &tab, int v, int varia
 }
 
 #define FRAG_DIRECT_MAX 128   // up to two rounds of windows: evaluate them all
+#ifndef FRAG_STEP
+#define FRAG_STEP 4          // anchor spacing of the coarse pass (power of two, >= 4)
+#endif
 #define FRAG_SCRATCH 2112      // int16 per wave: anchors [QV_MAXQ / 4 + 2] + refine list [QV_MAXQ]
 __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane, int16_t *scratch) {
     const QvUtt &u = wk.utt[b];
@@ -613,13 +616,38 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
     // every 4th window (and the last one) and takes their maximum B; pass 1 evaluates exactly only
     // the windows whose bound from BOTH neighbouring anchors still exceeds B.  The result is the
     // exact maximum.  Up to FRAG_DIRECT_MAX windows are simply all evaluated in pass 0.
+    // The window maximum only enters the score through blend(best), which is monotone in best and
+    // never below the full-string ratio fr; and no window can beat the full string: best <= full.
+    // If even blend(min(full, s)) == fr the windows cannot change the result and are skipped (the
+    // usual case for a verse shorter than the transcript, whose word-count penalty outweighs any
+    // window gain).  Otherwise the scan starts from the largest value that still blends to fr.
+    const double fr = ratio_from(full, m, n);
+    double pen = __ddiv_rn((double)vw, (double)(qw > 1 ? qw : 1));
+    if (pen > 1.0) pen = 1.0;
+    auto blend = [&](int x) -> double {
+        double frag = ratio_from(x, s, s);
+        if (!(frag > fr)) return fr;
+        double blended = __dadd_rn(__dmul_rn(0.25, fr), __dmul_rn(__dmul_rn(0.75, frag), pen));
+        return fr > blended ? fr : blended;
+    };
+    if (nwin > 0) {
+        int ub = full < s ? full : s;
+        if (blend(ub) == fr) nwin = 0;
+        else if (nwin > FRAG_DIRECT_MAX) {
+            int x = (int)(__ddiv_rn(fr, pen) * (double)s);         // estimate, then make it exact
+            x = x < 0 ? 0 : (x > ub - 1 ? ub - 1 : x);
+            while (x > 0 && blend(x) != fr) --x;
+            while (x + 1 < ub && blend(x + 1) == fr) ++x;
+            best = x;
+        }
+    }
     int16_t *cv = scratch, *list = scratch + FRAG_SCRATCH / 2;
     const bool direct = nwin <= FRAG_DIRECT_MAX;
-    const int nco = (nwin + 3) >> 2;                          // anchors 4k, k < nco; cv[nco] = last window
+    const int nco = (nwin + FRAG_STEP - 1) / FRAG_STEP;       // anchors k * FRAG_STEP, k < nco; cv[nco] = last window
     int nlist = direct ? nwin : nco + 1;
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = lane; i < nlist; i += 64) {
-            int w = pass ? (int)list[i] : (direct ? i : (i < nco ? 4 * i : nwin - 1));
+            int w = pass ? (int)list[i] : (direct ? i : (i < nco ? FRAG_STEP * i : nwin - 1));
             int r = lcs_dispatch(W, pm, stride, lt + w, s, s);
             if (!pass && !direct) cv[i] = (int16_t)r;
             best = max(best, r);
@@ -631,12 +659,12 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
         for (int base = 0; base < nwin; base += 64) {
             int w = base + lane;
             bool need = false;
-            if (w < nwin - 1 && (w & 3) != 0) {
-                int k0 = w >> 2, a1 = 4 * (k0 + 1);
+            if (w < nwin - 1 && (w & (FRAG_STEP - 1)) != 0) {
+                int k0 = w / FRAG_STEP, a1 = FRAG_STEP * (k0 + 1);
                 int x0 = cv[k0], x1;
                 if (a1 <= nwin - 1) x1 = cv[k0 + 1];
                 else { a1 = nwin - 1; x1 = cv[nco]; }
-                int ub = min(x0 + (w - 4 * k0), x1 + (a1 - w));
+                int ub = min(x0 + (w - FRAG_STEP * k0), x1 + (a1 - w));
                 need = ub > best;
             }
             unsigned long long mask = __ballot(need);
@@ -646,18 +674,9 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) {
-        double fr = ratio_from(full, m, n);
         double res = fr;
         if (sub) res = fr > 0.98 ? fr : 0.98;
-        else if (windows) {
-            double frag = ratio_from(best, s, s);
-            if (frag > fr) {
-                double pen = __ddiv_rn((double)vw, (double)(qw > 1 ? qw : 1));
-                if (pen > 1.0) pen = 1.0;
-                double blended = __dadd_rn(__dmul_rn(0.25, fr), __dmul_rn(__dmul_rn(0.75, frag), pen));
-                res = fr > blended ? fr : blended;
-            }
-        }
+        else if (windows) res = blend(best);
         *out = res;
     }
 }
@@ -798,27 +817,39 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
         int m = u.q_len, W = (m + 63) >> 6;
         const uint64_t *pm = spm;
         int per = kn.max_span - 1;
-        unsigned long long jbase = 0;
-        for (int si = 0; si < u.n_surah20; ++si) {
+        // One flat job space over the surahs of the top 20, so that every lane of the grid
+        // has a span (the surahs are not walked one after the other).  Inside a surah the
+        // lanes are span-major - neighbouring lanes hold the same number of ayat starting at
+        // consecutive verses, i.e. texts of similar length, which is what bounds a wave.  The
+        // tie-break key stays the reference's iteration rank: surahs in order, then start
+        // ayah, then span length.
+        int cum[21];
+        cum[0] = 0;
+#pragma unroll
+        for (int si = 0; si < 20; ++si)
+            cum[si + 1] = cum[si] + (si < u.n_surah20 ? tab.surah_len[u.surah20[si] - 1] * per : 0);
+        const int total = cum[20];
+        for (int g = blockIdx.x * 256 + tid; g < total; g += gridDim.x * 256) {
+            int si = 0, base = 0;
+#pragma unroll
+            for (int k = 1; k < 20; ++k)
+                if (g >= cum[k]) { si = k; base = cum[k]; }
             int s = u.surah20[si];
             int s0 = tab.surah_start[s - 1], sl = tab.surah_len[s - 1];
-            int jobs = sl * per;
-            for (int j = blockIdx.x * 256 + tid; j < jobs; j += gridDim.x * 256) {
-                int i = j / per, span = 2 + j % per;
-                if (i + span > sl) continue;
-                int v0 = s0 + i, v1 = v0 + span - 1;
-                int nl = tab.nobsm_len[v0];
-                uint32_t start = tab.clean_off[v0] + (nl ? tab.clean_len[v0] - nl : 0);
-                int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
-                int mn = m < n ? m : n;
-                if (!(ratio_from(mn, m, n) > u.best1_score)) continue;
-                int l = lcs_dispatch(W, pm, QV_MAXW, tab.clean + start, n, m);
-                double raw = ratio_from(l, m, n);
-                double sc = raw < 1.0 ? raw : 1.0;
-                unsigned long long key = jbase + (unsigned long long)j;
-                if (better(sc, key, best, bkey)) { best = sc; bkey = key; }
-            }
-            jbase += (unsigned long long)jobs;
+            int r = g - base;
+            int span = 2 + r / sl, i = r % sl;
+            if (i + span > sl) continue;
+            int v0 = s0 + i, v1 = v0 + span - 1;
+            int nl = tab.nobsm_len[v0];
+            uint32_t start = tab.clean_off[v0] + (nl ? tab.clean_len[v0] - nl : 0);
+            int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
+            int mn = m < n ? m : n;
+            if (!(ratio_from(mn, m, n) > u.best1_score)) continue;
+            int l = lcs_dispatch(W, pm, QV_MAXW, tab.clean + start, n, m);
+            double raw = ratio_from(l, m, n);
+            double sc = raw < 1.0 ? raw : 1.0;
+            unsigned long long key = (unsigned long long)base + (unsigned long long)(i * per + span - 2);
+            if (better(sc, key, best, bkey)) { best = sc; bkey = key; }
         }
     }
     block_best(best, bkey, sh_s, sh_k);
