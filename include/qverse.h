@@ -166,6 +166,32 @@ const int32_t *qv_packed_results_ctx(qv_engine *e, int32_t ctx, void *stream);
 int qv_fetch_results_ctx(qv_engine *e, int32_t ctx, int32_t batch, int32_t t_max, qv_result *results_host,
                          int32_t *greedy_ids_host);
 
+/* ---- streaming row: the verse tracker's matching step -------------------------------------
+ * Replaces VerseTracker._find_best_match (shared/verse_tracker.py:67-101) with _score_verse
+ * (:41-65) inlined: for each of `batch` accumulated texts, the scan of all 6,236 verses (clean
+ * text, and the bismillah-stripped variant where the verse has one) of
+ *     raw = blend(ratio(text, first min(n_text, n_verse) words of the verse), ratio(text, verse))
+ *           [+ 0.15 for the verse after the last emission]
+ * and the first maximum in verse order.  Texts arrive as alphabet codes (0 = ' ', 63 = a
+ * character outside the verse alphabet), concatenated, text b = codes[offsets[b] ..
+ * offsets[b+1]); n_words_host[b] = number of whitespace-separated words of text b;
+ * bonus_verse_host[b] = global index of the verse that gets the continuation bonus
+ * (QuranDB.get_next_verse of the last emission, shared/quran_db.py:81-90) or -1.
+ * out_host[b].verse = -1 when no verse scores above 0.0; the minimum-emit-score and
+ * minimum-word-count gates of the caller are NOT applied here.  Texts longer than
+ * QV_MAX_TRANSCRIPT codes are refused (QV_ERR_CAPACITY).  SYNCHRONOUS on `stream`. */
+typedef struct qv_track_match {
+    int32_t verse;     /* global verse index, -1 = none */
+    int32_t surah, ayah;
+    int32_t variant;   /* 0 = text_clean matched, 2 = text_clean_no_bsm */
+    int32_t n_words;   /* words of the matched text (what _emit trims by, verse_tracker.py:110-114) */
+    int32_t reserved;
+    double score;
+} qv_track_match;
+int qv_tracker_match(qv_engine *e, const uint8_t *codes_host, const int32_t *offsets_host,
+                     const int32_t *n_words_host, const int32_t *bonus_verse_host, int32_t batch,
+                     qv_track_match *out_host, void *stream);
+
 /* Device pointer of the packed (surah, ayah, ayah_end, float-bits(score)) i32[B,4] rows of the
  * last async call -- the payload of the per-batch RCCL all-gather. */
 const int32_t *qv_packed_results_dev(qv_engine *e);

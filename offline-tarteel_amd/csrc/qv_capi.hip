@@ -344,6 +344,14 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
         rc = alloc_work(eng, k);
         if (rc) return fail(rc);
     }
+    {   // verse tracker workspace (qv_tracker_match)
+        QvTrack &t = eng->track;
+        if ((rc = dalloc(eng, (size_t)QV_TRACK_CAP * QV_MAXQ, &t.q)) || (rc = dalloc(eng, (size_t)QV_TRACK_CAP * 4, &t.meta)) ||
+            (rc = dalloc(eng, (size_t)QV_TRACK_CAP * QV_TRACK_BLOCKS, &t.part_s)) ||
+            (rc = dalloc(eng, (size_t)QV_TRACK_CAP * QV_TRACK_BLOCKS, &t.part_k)) ||
+            (rc = dalloc(eng, (size_t)QV_TRACK_CAP, &t.out)))
+            return fail(rc);
+    }
     if (cfg->with_model) {
         rc = qv_model_create(eng, cfg, &eng->model);
         if (rc) return fail(rc);
@@ -527,6 +535,26 @@ extern "C" int qv_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int3
         QV_HIP(hipMemcpy(runner_score, eng->work.runner_score, sizeof(double) * u.n_runners, hipMemcpyDeviceToHost));
     }
     return QV_OK;
+}
+
+extern "C" int qv_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32_t *offsets_host,
+                                const int32_t *n_words_host, const int32_t *bonus_verse_host, int32_t batch,
+                                qv_track_match *out_host, void *stream) {
+    if (!eng) return QV_ERR_ARG;
+    if (batch < 0 || !offsets_host || !n_words_host || !bonus_verse_host || !out_host || (batch > 0 && !codes_host)) {
+        qv_set_error(eng, "qv_tracker_match: null argument");
+        return QV_ERR_ARG;
+    }
+    for (int b = 0; b < batch; ++b) {
+        int n = offsets_host[b + 1] - offsets_host[b];
+        if (n < 0 || bonus_verse_host[b] >= eng->tab.n_verses || n_words_host[b] < 0) {
+            qv_set_error(eng, "qv_tracker_match: bad offsets / word count / bonus verse");
+            return QV_ERR_ARG;
+        }
+        if (n > QV_MAXQ) { qv_set_error(eng, "qv_tracker_match: text longer than QV_MAX_TRANSCRIPT"); return QV_ERR_CAPACITY; }
+    }
+    return qv_post_tracker_match(eng, codes_host, offsets_host, n_words_host, bonus_verse_host, batch, out_host,
+                                 (hipStream_t)stream);
 }
 
 extern "C" int qv_debug_ctc_loss(qv_engine *eng, const float *lp, int32_t T, const uint16_t *tg, const int32_t *lens,

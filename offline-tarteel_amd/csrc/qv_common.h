@@ -135,7 +135,21 @@ struct QvKnobs {
     int skip_unused;
 };
 
+// verse tracker workspace (qv_tracker_match): QV_TRACK_CAP texts per launch
+#define QV_TRACK_CAP 256
+#define QV_TRACK_BLOCKS 32   // >= ceil(n_verses / 256) partial maxima per text
+struct QvTrack {
+    uint8_t *q;          // [CAP][QV_MAXQ] codes
+    int32_t *meta;       // [CAP][4] q_len, n_words, bonus verse, -
+    double *part_s;      // [CAP][QV_TRACK_BLOCKS]
+    uint64_t *part_k;    // [CAP][QV_TRACK_BLOCKS] verse * 2 + (no_bsm variant matched)
+    qv_track_match *out; // [CAP]
+};
+
 // post-logits launcher (qv_postlogits.hip)
+int qv_post_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32_t *offsets_host,
+                          const int32_t *n_words_host, const int32_t *bonus_host, int batch,
+                          qv_track_match *out_host, hipStream_t stream);
 int qv_post_run(qv_engine *eng, const float *logprobs_dev, int t_max, const int32_t *t_host, int batch,
                 hipStream_t stream);
 int qv_post_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int n, hipStream_t stream);
@@ -187,6 +201,7 @@ struct qv_engine {
     // resampler filters already arranged per phase and resident in HBM (qv_upfirdn)
     struct Fir { int up; std::vector<float> taps; float *hflip_dev; int P; };
     std::vector<Fir> firs;
+    QvTrack track;
     // host copies of small table parts used by debug/entry code
     std::vector<uint8_t> h_surah;
     std::vector<uint16_t> h_ayah;

@@ -1284,6 +1284,89 @@ __global__ void k_init_utts(QvWork wk, const int32_t *__restrict__ t_dev, int ba
     if (b < batch) wk.utt[b].t_frames = t_dev[b];
 }
 
+// ------------------------------------------------------------------ 12. verse tracker --
+// VerseTracker._find_best_match (shared/verse_tracker.py:67-101) with _score_verse (:41-65)
+// inlined.  grid (blocks of 256 verses, texts); the text's match masks are built in LDS by the
+// block itself, then one verse per lane: LCS(text, verse) and - when the text has fewer words
+// than the verse - LCS(text, first n_text words of the verse), both by streaming the verse
+// through the text's bit-vector.  Scores are Python double arithmetic, operation by operation.
+__global__ __launch_bounds__(256) void k_track(QvTables tab, QvTrack tw) {
+    __shared__ unsigned long long spm[QV_NSYM * QV_MAXW];
+    __shared__ double sh_s[8];
+    __shared__ unsigned long long sh_k[8];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int m = tw.meta[b * 4], n_text = tw.meta[b * 4 + 1], bonus = tw.meta[b * 4 + 2];
+    const uint8_t *q = tw.q + (size_t)b * QV_MAXQ;
+    for (int i = tid; i < QV_NSYM * QV_MAXW; i += 256) spm[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) { int c = q[i]; if (c < QV_NSYM) atomicOr(&spm[c * QV_MAXW + (i >> 6)], 1ull << (i & 63)); }
+    __syncthreads();
+    const int W = (m + 63) >> 6;
+    const int v = blockIdx.x * 256 + tid;
+    double best = 0.0;
+    unsigned long long bkey = ~0ull;
+    if (v < tab.n_verses && m > 0) {
+        double score = 0.0;
+        int matched_nb = 0;
+        const int nl = tab.nobsm_len[v];
+        // j: 0 = clean full, 1 = clean prefix, 2 = no_bsm full, 3 = no_bsm prefix (one LCS call site)
+        int lfull = 0, n = 0, plen = 0, nwv = 0;
+        const uint8_t *p = nullptr;
+        for (int j = 0; j < 4; ++j) {
+            if (j >= 2 && nl == 0) break;
+            if ((j & 1) == 0) {
+                n = j == 0 ? tab.clean_len[v] : nl;
+                p = tab.clean + tab.clean_off[v] + (j == 0 ? 0 : tab.clean_len[v] - nl);
+                nwv = tab.nw[j == 0 ? 0 : 2][v];
+                int pw = n_text < nwv ? n_text : nwv;     // prefix = first pw words of the verse
+                plen = n;
+                if (pw < nwv) {
+                    int seen = 0;
+                    plen = 0;
+                    for (int i = 0; i < n; ++i)
+                        if (p[i] == 0 && ++seen == pw) { plen = i; break; }
+                }
+            } else if (plen == n) continue;               // prefix is the whole verse
+            int l = lcs_dispatch(W, (const uint64_t *)spm, QV_MAXW, p, (j & 1) ? plen : n, m);
+            if ((j & 1) == 0) { lfull = l; if (plen != n) continue; }
+            double ps = ratio_from(l, m, plen), fs = ratio_from(lfull, m, n);
+            double cov = __ddiv_rn((double)n_text, (double)(nwv > 1 ? nwv : 1));
+            double raw = cov > 0.8 ? __dadd_rn(__dmul_rn(0.3, ps), __dmul_rn(0.7, fs))
+                                   : __dadd_rn(__dmul_rn(0.7, ps), __dmul_rn(0.3, fs));
+            if (v == bonus) raw = __dadd_rn(raw, 0.15);
+            if (j < 2) score = raw;
+            else if (raw > score) { score = raw; matched_nb = 1; }
+        }
+        best = score;
+        bkey = (unsigned long long)v * 2ull + (unsigned long long)matched_nb;
+    }
+    block_best(best, bkey, sh_s, sh_k);
+    if (tid == 0) {
+        tw.part_s[(size_t)b * QV_TRACK_BLOCKS + blockIdx.x] = best;
+        tw.part_k[(size_t)b * QV_TRACK_BLOCKS + blockIdx.x] = bkey;
+    }
+}
+
+__global__ void k_track_final(QvTables tab, QvTrack tw, int batch, int nblk) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double best = 0.0;
+    unsigned long long key = ~0ull;
+    for (int i = 0; i < nblk; ++i) {
+        double s = tw.part_s[(size_t)b * QV_TRACK_BLOCKS + i];
+        unsigned long long k = tw.part_k[(size_t)b * QV_TRACK_BLOCKS + i];
+        if (better(s, k, best, key)) { best = s; key = k; }
+    }
+    qv_track_match r;
+    r.verse = -1; r.surah = 0; r.ayah = 0; r.variant = 0; r.n_words = 0; r.reserved = 0; r.score = 0.0;
+    if (best > 0.0 && key != ~0ull) {          // "score > best_score" starts from 0.0 (verse_tracker.py:78,90)
+        int v = (int)(key >> 1), nb = (int)(key & 1ull);
+        r.verse = v; r.surah = tab.surah[v]; r.ayah = tab.ayah[v];
+        r.variant = nb ? 2 : 0; r.n_words = tab.nw[nb ? 2 : 0][v]; r.score = best;
+    }
+    tw.out[b] = r;
+}
+
 }  // namespace
 
 // ====================================================================== host side =======
@@ -1371,5 +1454,30 @@ int qv_post_debug_ctc(qv_engine *eng, const float *lp, int T, const uint16_t *tg
     QV_HIP(hipMemcpyAsync(loss_host, d_l, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
     QV_HIP(hipStreamSynchronize(stream));
     (void)hipFree(d_t); (void)hipFree(d_o); (void)hipFree(d_l);
+    return QV_OK;
+}
+
+int qv_post_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32_t *offsets_host,
+                          const int32_t *n_words_host, const int32_t *bonus_host, int batch,
+                          qv_track_match *out_host, hipStream_t stream) {
+    QvTrack &tw = eng->track;
+    const int nblk = (eng->tab.n_verses + 255) / 256;
+    if (nblk > QV_TRACK_BLOCKS) { qv_set_error(eng, "verse table larger than the tracker workspace"); return QV_ERR_CAPACITY; }
+    std::vector<int32_t> meta((size_t)QV_TRACK_CAP * 4);
+    for (int b0 = 0; b0 < batch; b0 += QV_TRACK_CAP) {
+        int nb = std::min(QV_TRACK_CAP, batch - b0);
+        for (int i = 0; i < nb; ++i) {
+            int n = offsets_host[b0 + i + 1] - offsets_host[b0 + i];
+            meta[i * 4] = n; meta[i * 4 + 1] = n_words_host[b0 + i]; meta[i * 4 + 2] = bonus_host[b0 + i]; meta[i * 4 + 3] = 0;
+            if (n > 0)
+                QV_HIP(hipMemcpyAsync(tw.q + (size_t)i * QV_MAXQ, codes_host + offsets_host[b0 + i], n, hipMemcpyHostToDevice, stream));
+        }
+        QV_HIP(hipMemcpyAsync(tw.meta, meta.data(), sizeof(int32_t) * 4 * nb, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_track, dim3(nblk, nb), dim3(256), 0, stream, eng->tab, tw);
+        hipLaunchKernelGGL(k_track_final, dim3((nb + 63) / 64), dim3(64), 0, stream, eng->tab, tw, nb, nblk);
+        QV_HIP(hipGetLastError());
+        QV_HIP(hipMemcpyAsync(out_host + b0, tw.out, sizeof(qv_track_match) * nb, hipMemcpyDeviceToHost, stream));
+        QV_HIP(hipStreamSynchronize(stream));   // meta[] and the workspace are reused by the next slice
+    }
     return QV_OK;
 }

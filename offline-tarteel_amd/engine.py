@@ -47,6 +47,12 @@ class QvResult(C.Structure):
     ]
 
 
+class QvTrackMatch(C.Structure):
+    """include/qverse.h: qv_track_match"""
+    _fields_ = [("verse", C.c_int32), ("surah", C.c_int32), ("ayah", C.c_int32), ("variant", C.c_int32),
+                ("n_words", C.c_int32), ("reserved", C.c_int32), ("score", C.c_double)]
+
+
 RESULT_DTYPE = np.dtype([
     ("surah", "<i4"), ("ayah", "<i4"), ("ayah_end", "<i4"), ("source", "<i4"),
     ("score", "<f8"), ("base_score", "<f8"), ("ctc_norm_loss", "<f4"),
@@ -93,6 +99,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_packed_results_ctx.argtypes = [vp, i32, vp]
     lib.qv_packed_results_ctx.restype = vp
     lib.qv_fetch_results_ctx.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.qv_tracker_match.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     lib.qv_debug_retrieve.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.qv_debug_ctc_loss.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     lib.qv_debug_forward_tap.argtypes = [vp, i32, i32, vp, vp]
@@ -359,6 +366,53 @@ class Engine:
                 "flops": fl.value, "launches": iters}
 
     # ---------------------------------------------------------------- debug ------
+    # ---------------------------------------------------------------- streaming row
+    def next_verse(self, surah: int, ayah: int) -> int:
+        """Global index of the verse after (surah, ayah) in mushaf order, -1 if there is none
+        or (surah, ayah) does not exist (QuranDB.get_next_verse, shared/quran_db.py:81-90)."""
+        t = self.tables.s
+        if not (1 <= surah <= 114) or not (1 <= ayah <= int(t["surah_len"][surah - 1])):
+            return -1
+        idx = int(t["surah_start"][surah - 1]) + ayah - 1
+        return idx + 1 if idx + 1 < self.tables.n_verses else -1
+
+    def track_match(self, texts, last_refs=None) -> list[dict | None]:
+        """VerseTracker._find_best_match for a batch of accumulated texts in one launch
+        (qv_tracker_match).  last_refs[b] = (surah, ayah) of the tracker's last emission or None.
+        Returns per text None (no verse scores above 0) or
+        {surah, ayah, n_words, score, verse, variant}; the caller applies its emit gates."""
+        n = len(texts)
+        if n == 0:
+            return []
+        last_refs = last_refs or [None] * n
+        enc = [self.tables.encode(t) for t in texts]
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        codes = np.ascontiguousarray(np.concatenate(enc) if off[-1] else np.zeros(1, np.uint8))
+        nw = np.ascontiguousarray(np.array([len(t.split()) for t in texts], np.int32))
+        bonus = np.ascontiguousarray(np.array([self.next_verse(*r) if r else -1 for r in last_refs], np.int32))
+        out = (QvTrackMatch * n)()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.qv_tracker_match(self.h, p(codes), p(off), p(nw), p(bonus), n, C.cast(out, C.c_void_p),
+                                       self._stream())
+        self._check(rc, "qv_tracker_match")
+        return [None if m.verse < 0 else
+                {"surah": m.surah, "ayah": m.ayah, "n_words": m.n_words, "score": m.score, "verse": m.verse,
+                 "variant": m.variant} for m in out]
+
+    def transcribe_batch(self, audio, lengths) -> list[str]:
+        """Forward + greedy CTC decode of a zero-padded batch (float32 cuda [B, N]); the
+        transcript of each row as c2c-direct/run.py:187-204 returns it."""
+        lp, T = self.forward(audio, lengths)
+        ids = lp.argmax(-1).cpu().numpy()
+        out = []
+        for b, t in enumerate(T):
+            row = ids[b, :t]
+            keep = np.ones(t, bool)
+            keep[1:] = row[1:] != row[:-1]
+            out.append(self.transcript_of(row[keep & (row != 1024)].tolist()))
+        return out
+
     def debug_retrieve(self, transcript: str) -> dict:
         """match_verse + candidate assembly for an already-normalised transcript."""
         codes = np.ascontiguousarray(self.tables.encode(transcript))
