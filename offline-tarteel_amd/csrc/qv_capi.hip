@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <fstream>
 #include <mutex>
 
@@ -194,6 +195,25 @@ static int load_tables(qv_engine *eng, const char *path) {
     QV_TRY(upload(eng, (const uint16_t *)blob.get("alt_nw"), (size_t)N, &t.nw[1]));
     QV_TRY(upload(eng, (const uint16_t *)blob.get("nobsm_nw"), (size_t)N, &t.nw[2]));
     QV_TRY(upload(eng, nrank.data(), (size_t)N, &t.nobsm_rank));
+    {   // word ends of the clean texts (the verse tracker's prefix scores)
+        std::vector<uint32_t> wo(N + 1, 0);
+        std::vector<uint16_t> we;
+        const uint16_t *cnw = (const uint16_t *)blob.get("clean_nw");
+        for (int v = 0; v < N; ++v) {
+            wo[v] = (uint32_t)we.size();
+            for (int i = 0; i < clen[v]; ++i)
+                if (ctxt[coff[v] + i] == 0) we.push_back((uint16_t)i);
+            we.push_back(clen[v]);
+            if ((int)(we.size() - wo[v]) != cnw[v]) { qv_set_error(eng, "tables: clean_nw disagrees with the text"); return QV_ERR_IO; }
+        }
+        wo[N] = (uint32_t)we.size();
+        QV_TRY(upload(eng, wo.data(), wo.size(), &t.wend_off));
+        QV_TRY(upload(eng, we.data(), we.size(), &t.wend));
+        std::vector<int32_t> order(N);
+        for (int v = 0; v < N; ++v) order[v] = v;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return clen[a] > clen[b]; });
+        QV_TRY(upload(eng, order.data(), order.size(), &t.len_order));
+    }
     // per-text match masks
     t.n_text = 2 * N + n_nobsm;
     std::vector<uint32_t> pmo(t.n_text);

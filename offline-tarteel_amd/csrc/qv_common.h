@@ -57,6 +57,10 @@ struct QvTables {
     const uint16_t *alt_len;     // [N]
     const uint16_t *nw[3];       // word counts clean / alt / nobsm
     const int32_t *nobsm_rank;   // [N] index among verses that have a no_bsm text, -1 otherwise
+    // word ends of the clean texts: wend[wend_off[v] + k] = chars of the first k+1 words joined
+    const uint32_t *wend_off;    // [N+1]
+    const uint16_t *wend;
+    const int32_t *len_order;    // [N] verse indices, longest clean text first (lanes of a wave get similar lengths)
     // per-text bit-parallel match masks (pattern = the verse text): text id = variant*N + v for
     // variant 0/1, 2N + nobsm_rank for variant 2.  layout [QV_NSYM][words]
     const uint64_t *pmv;
@@ -139,8 +143,8 @@ struct QvKnobs {
 #define QV_TRACK_CAP 256
 #define QV_TRACK_BLOCKS 32   // >= ceil(n_verses / 256) partial maxima per text
 struct QvTrack {
-    uint8_t *q;          // [CAP][QV_MAXQ] codes
-    int32_t *meta;       // [CAP][4] q_len, n_words, bonus verse, -
+    uint8_t *q;          // [CAP * QV_MAXQ] codes of the slice's texts, back to back
+    int32_t *meta;       // [CAP][4] q_len, n_words, bonus verse, offset in q
     double *part_s;      // [CAP][QV_TRACK_BLOCKS]
     uint64_t *part_k;    // [CAP][QV_TRACK_BLOCKS] verse * 2 + (no_bsm variant matched)
     qv_track_match *out; // [CAP]

@@ -253,8 +253,15 @@ __device__ __forceinline__ int lcs_dispatch(int W, const uint64_t *pm, int strid
 }
 
 // stage the transcript's match masks (both the spaced and the spaceless pattern, 10 KB) in LDS
+// LDS row stride of the match masks (u64 units).  With the global stride QV_MAXW = 16 (128 B) every
+// symbol's word w sat in the same two banks, so the 64 lanes of a wave - each on a different
+// symbol - serialised their mask reads; the padded stride spreads the rows over the banks.
+#ifndef QV_PMS
+#define QV_PMS (QV_MAXW + 2)   // 144 B rows: 16-byte aligned for ds_read_b128, 16 distinct bank offsets
+#endif
 __device__ __forceinline__ void load_pm_lds(uint64_t *spm, const uint64_t *gpm) {
-    for (int i = threadIdx.x; i < 2 * QV_NSYM * QV_MAXW; i += blockDim.x) spm[i] = gpm[i];
+    for (int i = threadIdx.x; i < 2 * QV_NSYM * QV_MAXW; i += blockDim.x)
+        spm[(i / QV_MAXW) * QV_PMS + (i % QV_MAXW)] = gpm[i];
     __syncthreads();
 }
 
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
     const QvUtt &u = wk.utt[b];
     if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
     const int m = u.q_len, W = (m + 63) >> 6, N = tab.n_verses;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_MAXW];
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     const uint64_t *pm = spm;
     const int32_t *cand1 = wk.cand1 + (size_t)b * N;
@@ -701,11 +708,11 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
     const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 2;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < jobs; j += gridDim.x * 256) {
         int v, variant;
-        if (mode == 0) { v = cand1[j / 3]; variant = j % 3; } else { v = j >> 1; variant = j & 1; }
+        if (mode == 0) { v = cand1[j / 3]; variant = j % 3; } else { v = tab.len_order[j >> 1]; variant = j & 1; }  // similar lengths per wave
         double *fs = wk.fs + ((size_t)b * N + v) * 3 + variant;
         if (variant == 2 && tab.nobsm_len[v] == 0) { if (short_q) *fs = -1.0; continue; }
         TextRef t = text_of(tab, v, variant);
-        int l = lcs_dispatch(W, pm, QV_MAXW, t.p, t.n, m);
+        int l = lcs_dispatch(W, pm, QV_PMS, t.p, t.n, m);
         out[v * 3 + variant] = (int16_t)l;
         if (short_q) {
             // fewer than 4 query words: _fragment_score never looks at windows
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_MAXW];
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     if (u.q_len > 0) {
         int m = u.q_len, W = (m + 63) >> 6;
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
             int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
             int mn = m < n ? m : n;
             if (!(ratio_from(mn, m, n) > u.best1_score)) continue;
-            int l = lcs_dispatch(W, pm, QV_MAXW, tab.clean + start, n, m);
+            int l = lcs_dispatch(W, pm, QV_PMS, tab.clean + start, n, m);
             double raw = ratio_from(l, m, n);
             double sc = raw < 1.0 ? raw : 1.0;
             unsigned long long key = (unsigned long long)base + (unsigned long long)(i * per + span - 2);
@@ -907,15 +914,16 @@ __global__ __launch_bounds__(256) void k_pass3(QvTables tab, QvWork wk) {
     int b = wk.fail_list[blockIdx.y];
     const QvUtt &u = wk.utt[b];
     if (u.q_len == 0) return;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_MAXW];
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
-    int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= tab.n_verses) return;
+    int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= tab.n_verses) return;
+    int v = tab.len_order[slot];  // lanes of a wave stream texts of similar length
     int m = u.q_len, ms = u.qs_len;
     const uint8_t *t = tab.clean + tab.clean_off[v];
     int n = tab.clean_len[v], ns = n - (tab.nw[0][v] - 1);
     int l1 = wk.lcsf[((size_t)b * tab.n_verses + v) * 3];  // LCS(t, clean) from k_lcs_full
-    int l2 = lcs_dispatch((ms + 63) >> 6, spm + QV_NSYM * QV_MAXW, QV_MAXW, t, n, ms);
+    int l2 = lcs_dispatch((ms + 63) >> 6, spm + QV_NSYM * QV_PMS, QV_PMS, t, n, ms);
     double a = ratio_from(l1, m, n), c = ratio_from(l2, ms, ns);
     wk.p3[(size_t)b * tab.n_verses + v] = a > c ? a : c;
 }
@@ -1291,21 +1299,24 @@ __global__ void k_init_utts(QvWork wk, const int32_t *__restrict__ t_dev, int ba
 // than the verse - LCS(text, first n_text words of the verse), both by streaming the verse
 // through the text's bit-vector.  Scores are Python double arithmetic, operation by operation.
 __global__ __launch_bounds__(256) void k_track(QvTables tab, QvTrack tw) {
-    __shared__ unsigned long long spm[QV_NSYM * QV_MAXW];
+    __shared__ unsigned long long spm[QV_NSYM * QV_PMS];
     __shared__ double sh_s[8];
     __shared__ unsigned long long sh_k[8];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int m = tw.meta[b * 4], n_text = tw.meta[b * 4 + 1], bonus = tw.meta[b * 4 + 2];
-    const uint8_t *q = tw.q + (size_t)b * QV_MAXQ;
-    for (int i = tid; i < QV_NSYM * QV_MAXW; i += 256) spm[i] = 0ull;
+    const uint8_t *q = tw.q + tw.meta[b * 4 + 3];
+    for (int i = tid; i < QV_NSYM * QV_PMS; i += 256) spm[i] = 0ull;
     __syncthreads();
-    for (int i = tid; i < m; i += 256) { int c = q[i]; if (c < QV_NSYM) atomicOr(&spm[c * QV_MAXW + (i >> 6)], 1ull << (i & 63)); }
+    for (int i = tid; i < m; i += 256) { int c = q[i]; if (c < QV_NSYM) atomicOr(&spm[c * QV_PMS + (i >> 6)], 1ull << (i & 63)); }
     __syncthreads();
     const int W = (m + 63) >> 6;
-    const int v = blockIdx.x * 256 + tid;
+    // lanes walk the verses in order of decreasing length, so the 64 verses of a wave cost about
+    // the same; the first-maximum rule lives in the key (verse index), not in the visiting order
+    const int slot = blockIdx.x * 256 + tid;
+    const int v = slot < tab.n_verses ? tab.len_order[slot] : -1;
     double best = 0.0;
     unsigned long long bkey = ~0ull;
-    if (v < tab.n_verses && m > 0) {
+    if (v >= 0 && m > 0) {
         double score = 0.0;
         int matched_nb = 0;
         const int nl = tab.nobsm_len[v];
@@ -1321,13 +1332,12 @@ __global__ __launch_bounds__(256) void k_track(QvTables tab, QvTrack tw) {
                 int pw = n_text < nwv ? n_text : nwv;     // prefix = first pw words of the verse
                 plen = n;
                 if (pw < nwv) {
-                    int seen = 0;
-                    plen = 0;
-                    for (int i = 0; i < n; ++i)
-                        if (p[i] == 0 && ++seen == pw) { plen = i; break; }
+                    // the no_bsm text is a suffix of the clean text: its words are the clean text's last nwv
+                    int drop = tab.nw[0][v] - nwv, shift = tab.clean_len[v] - n;
+                    plen = pw > 0 ? (int)tab.wend[tab.wend_off[v] + drop + pw - 1] - shift : 0;
                 }
             } else if (plen == n) continue;               // prefix is the whole verse
-            int l = lcs_dispatch(W, (const uint64_t *)spm, QV_MAXW, p, (j & 1) ? plen : n, m);
+            int l = lcs_dispatch(W, (const uint64_t *)spm, QV_PMS, p, (j & 1) ? plen : n, m);
             if ((j & 1) == 0) { lfull = l; if (plen != n) continue; }
             double ps = ratio_from(l, m, plen), fs = ratio_from(lfull, m, n);
             double cov = __ddiv_rn((double)n_text, (double)(nwv > 1 ? nwv : 1));
@@ -1466,12 +1476,15 @@ int qv_post_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32
     std::vector<int32_t> meta((size_t)QV_TRACK_CAP * 4);
     for (int b0 = 0; b0 < batch; b0 += QV_TRACK_CAP) {
         int nb = std::min(QV_TRACK_CAP, batch - b0);
+        const int32_t base = offsets_host[b0];
         for (int i = 0; i < nb; ++i) {
-            int n = offsets_host[b0 + i + 1] - offsets_host[b0 + i];
-            meta[i * 4] = n; meta[i * 4 + 1] = n_words_host[b0 + i]; meta[i * 4 + 2] = bonus_host[b0 + i]; meta[i * 4 + 3] = 0;
-            if (n > 0)
-                QV_HIP(hipMemcpyAsync(tw.q + (size_t)i * QV_MAXQ, codes_host + offsets_host[b0 + i], n, hipMemcpyHostToDevice, stream));
+            meta[i * 4] = offsets_host[b0 + i + 1] - offsets_host[b0 + i];
+            meta[i * 4 + 1] = n_words_host[b0 + i];
+            meta[i * 4 + 2] = bonus_host[b0 + i];
+            meta[i * 4 + 3] = offsets_host[b0 + i] - base;
         }
+        const int32_t total = offsets_host[b0 + nb] - base;   // <= nb * QV_MAXQ (lengths were checked)
+        if (total > 0) QV_HIP(hipMemcpyAsync(tw.q, codes_host + base, (size_t)total, hipMemcpyHostToDevice, stream));
         QV_HIP(hipMemcpyAsync(tw.meta, meta.data(), sizeof(int32_t) * 4 * nb, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_track, dim3(nblk, nb), dim3(256), 0, stream, eng->tab, tw);
         hipLaunchKernelGGL(k_track_final, dim3((nb + 63) / 64), dim3(64), 0, stream, eng->tab, tw, nb, nblk);

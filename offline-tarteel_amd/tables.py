@@ -31,13 +31,18 @@ class Tables:
         self.n_verses = int(self.s["meta"][0])
         self.alphabet = [chr(int(c)) for c in self.s["alphabet"]]
         self._code = {ch: i for i, ch in enumerate(self.alphabet)}
+        top = max(int(c) for c in self.s["alphabet"])
+        self._lut = np.full(top + 2, OTHER, np.uint8)       # last entry: every code point above the alphabet
+        for i, c in enumerate(self.s["alphabet"]):
+            self._lut[int(c)] = i
         po, pu = self.s["piece_u8_off"], self.s["piece_u8"]
         self.piece_surface = [pu[po[i]: po[i + 1]].tobytes().decode("utf-8") for i in range(1025)]
         self.surah = self.s["surah"]
         self.ayah = self.s["ayah"]
 
     def encode(self, text: str) -> np.ndarray:
-        return np.array([self._code.get(ch, OTHER) for ch in text], dtype=np.uint8)
+        cp = np.frombuffer(text.encode("utf-32-le", "surrogatepass"), dtype="<u4")
+        return self._lut[np.minimum(cp, len(self._lut) - 1)]
 
     def ids_to_text(self, ids) -> str:
         """SentencePiece decode_ids over the piece surfaces (leading whitespace markers of the
