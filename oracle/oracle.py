@@ -308,6 +308,44 @@ class Oracle:
             out.extend(losses.tolist())
         return np.asarray(out, dtype=np.float32)
 
+    @staticmethod
+    def ctc_score_f64(lp: np.ndarray, ids) -> float:
+        """float64 restatement of the browser twin of the rerank, web/frontend/src/lib/
+        ctc-rescore.ts:35-102 (scoreCtcSequence): alpha recursion over the 2L+1 blank-interleaved
+        states with logAddExp = hi + log1p(exp(lo - hi)) (:22-28), infeasible (L == 0 or
+        2L+1 > T, :30-33,43-49) -> 1e9, else -log p / L.  A cross-check of the float32 HIP
+        kernel in double precision; vectorised over the states."""
+        lp = np.asarray(lp, dtype=np.float64)
+        T, L = lp.shape[0], len(ids)
+        if L == 0 or 2 * L + 1 > T:
+            return 1e9
+        S = 2 * L + 1
+        states = np.full(S, BLANK, dtype=np.int64)
+        states[1::2] = np.asarray(ids, dtype=np.int64)
+        skip = np.zeros(S, dtype=bool)
+        skip[2:] = (states[2:] != BLANK) & (states[2:] != states[:-2])
+
+        def lae(a, b):
+            hi, lo = np.maximum(a, b), np.minimum(a, b)
+            with np.errstate(invalid="ignore"):
+                r = hi + np.log1p(np.exp(lo - hi))
+            return np.where(np.isneginf(lo), hi, r)
+
+        prev = np.full(S, -np.inf)
+        prev[0] = lp[0, BLANK]
+        prev[1] = lp[0, states[1]]
+        for t in range(1, T):
+            tot = prev.copy()
+            tot[1:] = lae(tot[1:], prev[:-1])
+            cand = np.full(S, -np.inf)
+            cand[2:] = prev[:-2]
+            tot = np.where(skip, lae(tot, cand), tot)
+            prev = np.where(np.isneginf(tot), -np.inf, tot + lp[t, states])
+        fin = float(lae(prev[S - 1], prev[S - 2]))
+        if not np.isfinite(fin):
+            return 1e9
+        return -fin / L
+
     def ctc_rerank(self, lp: np.ndarray, cs, cp, sc):
         lp = np.ascontiguousarray(lp, dtype=np.float32)
         n = len(cs)

@@ -63,3 +63,21 @@ def test_gate_is_stricter_than_feasibility(oracle):
     win, loss, cl, fs = oracle.ctc_rerank(lp, cs, cp, sc)
     assert win == -1 and np.isinf(loss[0])
     assert np.isfinite(oracle.ctc_loss_c(lp, ids))
+
+
+def test_ctc_float64_twin_agrees_with_torch(oracle):
+    """oracle.ctc_score_f64 (restatement of the browser rerank, lib/ctc-rescore.ts:35-102) vs the
+    reference's F.ctc_loss call: normalised losses within 1e-5 relative, incl. repeated tokens."""
+    import torch
+
+    from synth import synth_logits
+
+    rng = np.random.default_rng(1)
+    ids0 = oracle.token_ids(100, 1).tolist()
+    lp = torch.log_softmax(torch.from_numpy(synth_logits(ids0, 126, seed=5, noise=2.0, boost=5.0, rep=2)), -1).numpy()
+    tg = [ids0[:40], rng.integers(0, 1024, size=30).tolist(), [5, 5, 5, 7], [9]]
+    want = oracle.ctc_loss_torch(lp, tg)
+    for t, w in zip(tg, want):
+        f = oracle.ctc_score_f64(lp, t)
+        assert abs(w / len(t) - f) <= 1e-5 * max(1.0, abs(f))
+    assert oracle.ctc_score_f64(lp, list(range(63))) == 1e9      # 2L+1 = 127 > T = 126
