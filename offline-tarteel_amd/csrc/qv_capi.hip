@@ -239,7 +239,38 @@ static int load_tables(qv_engine *eng, const char *path) {
     QV_TRY(upload(eng, (const double *)blob.get("tri_idf"), (size_t)NT, &t.tri_idf));
     const uint32_t *vto = (const uint32_t *)blob.get("vtri_off");
     QV_TRY(upload(eng, vto, (size_t)N + 1, &t.vtri_off));
-    QV_TRY(upload(eng, (const uint16_t *)blob.get("vtri"), (size_t)vto[N], &t.vtri));
+    const uint16_t *vt = (const uint16_t *)blob.get("vtri");
+    QV_TRY(upload(eng, vt, (size_t)vto[N], &t.vtri));
+    {   // inverted trigram index, split in four verse-range slices (one per wave of k_trigram)
+        std::vector<uint32_t> start(NT + 1, 0);
+        for (uint32_t p = 0; p < vto[N]; ++p) {
+            if (vt[p] >= NT) { qv_set_error(eng, "tables: trigram id out of range"); return QV_ERR_IO; }
+            ++start[vt[p] + 1];
+        }
+        for (int i = 0; i < NT; ++i) start[i + 1] += start[i];
+        std::vector<uint16_t> post(vto[N] + 64, 0);
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1), slice((size_t)NT * 5);
+        for (int i = 0; i < NT; ++i) slice[(size_t)i * 5] = start[i];
+        int w = 0;
+        for (int v = 0; v < N; ++v) {
+            while (w < 3 && v >= (int)((long long)(w + 1) * N / 4)) {   // verse v opens slice w + 1
+                ++w;
+                for (int i = 0; i < NT; ++i) slice[(size_t)i * 5 + w] = fill[i];
+            }
+            for (uint32_t p = vto[v]; p < vto[v + 1]; ++p) post[fill[vt[p]]++] = (uint16_t)v;
+        }
+        for (++w; w <= 4; ++w)
+            for (int i = 0; i < NT; ++i) slice[(size_t)i * 5 + w] = fill[i];
+        QV_TRY(upload(eng, post.data(), post.size(), &t.tri_post));
+        std::vector<uint16_t> map((size_t)1 << 18, 0xFFFF);
+        const uint32_t *keys = (const uint32_t *)blob.get("tri_keys");
+        for (int i = 0; i < NT; ++i) {
+            if (keys[i] >= map.size() || NT >= 0xFFFF) { qv_set_error(eng, "tables: trigram key out of range"); return QV_ERR_IO; }
+            map[keys[i]] = (uint16_t)i;
+        }
+        QV_TRY(upload(eng, map.data(), map.size(), &t.tri_map));
+        QV_TRY(upload(eng, slice.data(), slice.size(), &t.tri_slice));
+    }
     const uint32_t *to = (const uint32_t *)blob.get("tok_off");
     QV_TRY(upload(eng, to, (size_t)N * QV_MAX_SPAN + 1, &t.tok_off));
     QV_TRY(upload(eng, (const uint16_t *)blob.get("tok"), (size_t)to[(size_t)N * QV_MAX_SPAN], &t.tok));

@@ -70,6 +70,11 @@ struct QvTables {
     const double *tri_idf;       // [n_tri]
     const uint32_t *vtri_off;    // [N+1]
     const uint16_t *vtri;        // sorted trigram ids per verse
+    // ... and the inverted form: verses of each trigram in ascending order; tri_slice[id*5 + w] is
+    // where the verses of quarter w of the verse range start (w = 4: end of the list)
+    const uint16_t *tri_post;
+    const uint16_t *tri_map;     // [2^18] packed trigram (6 bits per code) -> id, 0xFFFF = not in the index
+    const uint32_t *tri_slice;   // [n_tri * 5]
     // CTC token table: key = v*6 + (span-1)
     const uint32_t *tok_off;     // [N*6+1]
     const uint16_t *tok;

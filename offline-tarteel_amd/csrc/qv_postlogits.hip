@@ -480,49 +480,15 @@ __device__ int pyset_order(const int32_t *vals, int n, int32_t *out, int32_t *ta
 
 #define TRI_WORDS 352  // >= ceil(10243/32), multiple of 32
 
-#define TRI_CHUNKS 48
-
-// IDF-weighted trigram overlap per verse (forward index: the trigram ids of each verse are
-// tested against the transcript's trigram bitmap; sums run in ascending trigram id = the
-// canonical order).  grid (TRI_CHUNKS, B): each block scores one slice of the verses.
-__global__ __launch_bounds__(256) void k_tri_score(QvTables tab, QvWork wk) {
-    __shared__ uint32_t bits[TRI_WORDS];
-    int b = blockIdx.y, tid = threadIdx.x;
-    QvUtt &u = wk.utt[b];
-    int m = u.q_len;
-    if (m < 3) return;  // no trigrams: nothing touched (n_cand1 stays 0 -> full scan)
-    const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
-    for (int i = tid; i < TRI_WORDS; i += 256) bits[i] = 0;
-    __syncthreads();
-    for (int i = tid; i + 2 < m; i += 256) {
-        uint32_t key = ((uint32_t)q[i] << 12) | ((uint32_t)q[i + 1] << 6) | q[i + 2];
-        int lo = 0, hi = tab.n_tri - 1, id = -1;
-        while (lo <= hi) {
-            int mid = (lo + hi) >> 1;
-            uint32_t kv = tab.tri_keys[mid];
-            if (kv == key) { id = mid; break; }
-            if (kv < key) lo = mid + 1; else hi = mid - 1;
-        }
-        if (id >= 0) atomicOr(&bits[id >> 5], 1u << (id & 31));
-    }
-    __syncthreads();
-    int N = tab.n_verses, per = (N + TRI_CHUNKS - 1) / TRI_CHUNKS;
-    int v0 = blockIdx.x * per, v1 = min(N, v0 + per), local = 0;
-    double *score = wk.p3 + (size_t)b * N;  // pass 3 runs later and overwrites this buffer
-    for (int v = v0 + tid; v < v1; v += 256) {
-        double s = 0.0;
-        bool touched = false;
-        for (uint32_t p = tab.vtri_off[v]; p < tab.vtri_off[v + 1]; ++p) {
-            int id = tab.vtri[p];
-            if (bits[id >> 5] >> (id & 31) & 1u) { s = __dadd_rn(s, tab.tri_idf[id]); touched = true; }
-        }
-        score[v] = touched ? s : -1.0;
-        local += touched;
-    }
-    local = wave_sum_i(local);
-    if ((tid & 63) == 0 && local) atomicAdd(&u.n_cand1, local);  // temporary: touched count
-}
-
+// _trigram_candidates (quran_db.py:173-186) + the candidate-set rule of match_verse (:278-288),
+// one block per utterance.  The transcript's distinct trigram ids are collected in a bitmap and
+// compacted in ascending order; then the INVERTED index is walked: for every query trigram, in
+// ascending id (= the canonical summation order), its IDF is added to the fp64 score of every
+// verse of its posting list.  The per-verse scores live in LDS; wave w owns quarter w of the verse
+// range (posting lists are verse-sorted and carry the four slice starts), so no two waves ever
+// touch the same score and the loop needs no block barrier.  Work is sum(df) over the query's
+// trigrams instead of a scan of all 420k forward postings per utterance.  Then: fewer than 20
+// touched verses -> full scan; else the 50 highest sums, iterated in CPython set order.
 __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *score = (double *)smem;                            // [N]
@@ -531,32 +497,98 @@ __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
     int32_t *top = (int32_t *)(sh_k + 8);                      // [64]
     int32_t *tabA = top + 64;                                  // [256]
     int32_t *tabB = tabA + 256;                                // [256]
-    int b = blockIdx.x, tid = threadIdx.x;
+    uint32_t *tri_scratch = (uint32_t *)(tabB + 256);          // [272]
+    double *sel_s = (double *)(tri_scratch + 272);             // [64]
+    double *ord_s = sel_s + 64;                                // [64]
+    int32_t *sel_p = (int32_t *)(ord_s + 64);                  // [64]
+    uint32_t *bits = (uint32_t *)(sel_p + 64);                 // [TRI_WORDS]
+    uint16_t *ids = (uint16_t *)(bits + TRI_WORDS);            // [QV_MAXQ]
+    int32_t *cnt = (int32_t *)(ids + QV_MAXQ);                 // [8]: [0] number of ids, [1..4] touched per wave
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QvUtt &u = wk.utt[b];
-    int m = u.q_len;
+    const int m = u.q_len, N = tab.n_verses;
     if (m == 0) return;
-    int N = tab.n_verses;
-    int touched_total = u.n_cand1;
+    int32_t *cand1 = wk.cand1 + (size_t)b * N;
+    for (int v = tid; v < N; v += 256) score[v] = -1.0;        // -1 = not touched
+    for (int i = tid; i < TRI_WORDS; i += 256) bits[i] = 0;
     __syncthreads();
-    if (touched_total >= 20) {
-        const double *gs = wk.p3 + (size_t)b * N;
-        for (int v = tid; v < N; v += 256) score[v] = gs[v];
+    const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
+    for (int i = tid; i + 2 < m; i += 256) {
+        // codes are < 64 (63 = outside the alphabet, never part of an indexed trigram)
+        uint32_t key = ((uint32_t)q[i] << 12) | ((uint32_t)q[i + 1] << 6) | q[i + 2];
+        int id = tab.tri_map[key];
+        if (id == 0xFFFF) id = -1;
+        if (id >= 0) atomicOr(&bits[id >> 5], 1u << (id & 31));
     }
     __syncthreads();
-    int32_t *cand1 = wk.cand1 + (size_t)b * N;
+    if (wave == 0) {                                            // ascending list of the distinct ids
+        int running = 0;
+        for (int base = 0; base < TRI_WORDS; base += 64) {
+            uint32_t w = base + lane < TRI_WORDS ? bits[base + lane] : 0u;
+            int c = __popc(w), incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+            int pos = running + incl - c;
+            while (w) { int bit = __ffs(w) - 1; w &= w - 1; ids[pos++] = (uint16_t)((base + lane) * 32 + bit); }
+            running += __shfl(incl, 63);
+        }
+        if (lane == 0) cnt[0] = running;
+    }
+    __syncthreads();
+    const int n_ids = cnt[0];
+    for (int k0 = 0; k0 < n_ids; k0 += 64) {
+        // this chunk's list bounds and IDFs: one memory round trip for 64 trigrams
+        uint32_t P0 = 0, P1 = 0;
+        double IDF = 0.0;
+        if (k0 + lane < n_ids) {
+            int id = ids[k0 + lane];
+            P0 = tab.tri_slice[(size_t)id * 5 + wave];
+            P1 = tab.tri_slice[(size_t)id * 5 + wave + 1];
+            IDF = tab.tri_idf[id];
+        }
+        const int nchunk = n_ids - k0 < 64 ? n_ids - k0 : 64;
+        for (int j0 = 0; j0 < nchunk; j0 += 8) {
+            // the first 64 verses of 8 consecutive lists are requested together, then applied in list order
+            int vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                uint32_t p0 = __shfl(P0, (j0 + e) & 63), p1 = __shfl(P1, (j0 + e) & 63);
+                vv[e] = (j0 + e < nchunk && p0 + lane < p1) ? (int)tab.tri_post[p0 + lane] : -1;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (j0 + e >= nchunk) break;
+                const double idf = __shfl(IDF, (j0 + e) & 63);
+                if (vv[e] >= 0) { double sv = score[vv[e]]; score[vv[e]] = sv < 0.0 ? idf : __dadd_rn(sv, idf); }
+                uint32_t p0 = __shfl(P0, (j0 + e) & 63), p1 = __shfl(P1, (j0 + e) & 63);
+                for (uint32_t base = p0 + 64; base < p1; base += 512) {   // long lists (frequent trigrams), 8 loads in flight
+                    int lv[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        uint32_t p = base + x * 64 + lane;
+                        lv[x] = p < p1 ? (int)tab.tri_post[p] : -1;
+                    }
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        if (lv[x] >= 0) { double sv = score[lv[x]]; score[lv[x]] = sv < 0.0 ? idf : __dadd_rn(sv, idf); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int local = 0;
+    for (int v = tid; v < N; v += 256) local += score[v] >= 0.0;
+    local = wave_sum_i(local);
+    if (lane == 0) cnt[1 + wave] = local;
+    __syncthreads();
+    const int touched_total = cnt[1] + cnt[2] + cnt[3] + cnt[4];
     if (touched_total < 20) {  // quran_db.py:285-286
         for (int v = tid; v < N; v += 256) cand1[v] = v;
         if (tid == 0) { u.n_cand1 = N; u.full_scan = 1; }
         return;
     }
     int K = touched_total < 50 ? touched_total : 50;
-    {
-        uint32_t *tri_scratch = (uint32_t *)(tabB + 256);     // [272]
-        double *sel_s = (double *)(tri_scratch + 272);        // [64]
-        double *ord_s = sel_s + 64;                           // [64]
-        int32_t *sel_p = (int32_t *)(ord_s + 64);             // [64]
-        block_topk_select(score, N, K, tri_scratch, sel_p, sel_s, top, ord_s);
-    }
+    block_topk_select(score, N, K, tri_scratch, sel_p, sel_s, top, ord_s);
     if (tid == 0) {
         int n = pyset_order(top, K, cand1, tabA, tabB);
         u.n_cand1 = n;
@@ -1386,8 +1418,8 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
     QvWork &wk = eng->work;
     QvKnobs kn = eng->knobs;
     int N = tab.n_verses;
-    size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + 64;
-    hipLaunchKernelGGL(k_tri_score, dim3(TRI_CHUNKS, batch), dim3(256), 0, stream, tab, wk);
+    size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + TRI_WORDS * 4 +
+                    QV_MAXQ * 2 + 8 * 4 + 64;
     hipLaunchKernelGGL(k_trigram, dim3(batch), dim3(256), sm_tri, stream, tab, wk);
     hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 0);
     hipLaunchKernelGGL(k_frag, dim3(64, batch), dim3(256), 0, stream, tab, wk, 0);

@@ -163,3 +163,64 @@ def test_pipeline_audio_end_to_end():
         assert together == [pipe.run_on_audio_chunked(r) for r in recs]
     finally:
         eng.close()
+
+
+def test_reference_unit_scenarios(engine, oracle):
+    """The scenarios of the reference's own unit tests for this row (tests/test_verse_tracker.py,
+    tests/test_streaming_pipeline.py, tests/test_quran_db.py), with the HIP matching step."""
+    from offline_tarteel_amd.streaming import StreamingPipeline
+    from offline_tarteel_amd.verse_tracker import VerseTracker
+
+    def verse(s, a):
+        return oracle.verse_text(oracle.verse_index(s, a))
+
+    def run_text(text, **kw):
+        tr = VerseTracker(engine, **kw)
+        return tr.process_text(text) + tr.finalize()
+
+    e = run_text(verse(1, 1))
+    assert (e[0]["surah"], e[0]["ayah"]) == (1, 1)
+    e = run_text(verse(112, 1) + " " + verse(112, 2))
+    assert [(x["surah"], x["ayah"]) for x in e[:2]] == [(112, 1), (112, 2)]
+    e = run_text(verse(55, 13), last_emission=(55, 12))            # the refrain: continuation decides
+    assert (e[0]["surah"], e[0]["ayah"]) == (55, 13)
+    e = run_text("الله لا اله الا هو الحي القيوم لا تاخذه سنه ولا نوم")   # enough of 2:255 to beat 3:2
+    assert (e[0]["surah"], e[0]["ayah"]) == (2, 255)
+    assert run_text("") == []
+    tr = VerseTracker(engine, streaming_mode=True)
+    assert tr.process_delta("يا") + tr.finalize() == []             # one word: below MIN_WORDS_FOR_MATCH
+    tr = VerseTracker(engine, streaming_mode=True)
+    assert tr.process_delta("بسم") == []
+    e = tr.process_delta(verse(1, 1)) + tr.finalize()
+    assert e and e[0]["surah"] == 1
+
+    pipe = StreamingPipeline(engine)
+    e = pipe.run_on_text([verse(1, 1)])
+    assert (e[0]["surah"], e[0]["ayah"]) == (1, 1)
+    v1, v2, v3 = verse(103, 1), verse(103, 2), verse(103, 3)
+    e = pipe.run_on_text([v1, v1 + " " + v2, v1 + " " + v2 + " " + v3])
+    assert [(x["surah"], x["ayah"]) for x in e[:3]] == [(103, 1), (103, 2), (103, 3)]
+
+    calls = []
+
+    def low_then_good(path):
+        calls.append(path)
+        if len(calls) == 1:
+            return {"text": "يا المسلمون الكرام", "avg_logprob": -2.0}   # gated: low confidence
+        return {"text": verse(112, 1), "avg_logprob": -0.3}
+
+    e = pipe.run_on_audio_chunked(np.zeros(16000 * 6, np.float32), low_then_good, chunk_seconds=3.0)
+    assert len(calls) == 2 and (e[0]["surah"], e[0]["ayah"]) == (112, 1)
+    e = pipe.run_on_audio_chunked(np.zeros(16000 * 3, np.float32), lambda p: verse(112, 1), chunk_seconds=3.0)
+    assert e and e[0]["surah"] == 112
+    e = pipe.run_on_audio_chunked(np.zeros(16000 * 3, np.float32),
+                                  lambda p: {"text": verse(112, 1), "avg_logprob": -0.3}, chunk_seconds=3.0)
+    assert e and (e[0]["surah"], e[0]["ayah"]) == (112, 1) and e[0]["score"] >= 0.7
+    with pytest.raises(NotImplementedError):
+        pipe.run_on_full_transcript("x.wav", lambda p: verse(112, 1))
+
+    # QuranDB.get_next_verse navigation (tests/test_quran_db.py)
+    assert engine.next_verse(1, 1) == oracle.verse_index(1, 2)
+    assert engine.next_verse(1, 7) == oracle.verse_index(2, 1)
+    assert engine.next_verse(114, 6) == -1
+    assert engine.next_verse(999, 1) == -1
