@@ -192,6 +192,19 @@ int qv_tracker_match(qv_engine *e, const uint8_t *codes_host, const int32_t *off
                      const int32_t *n_words_host, const int32_t *bonus_verse_host, int32_t batch,
                      qv_track_match *out_host, void *stream);
 
+/* QuranDB.match_verse(text, max_span, hint) WITHOUT the trigram restriction (shared/quran_db.py:
+ * 244-371 with use_trigram_index=False), as StreamingPipeline.run_on_full_transcript calls it
+ * (shared/streaming.py:86): pass 1 scores every verse (fragment scores of text_clean /
+ * text_clean_alt / text_clean_no_bsm; for the <= 3 verses of the continuation hint also
+ * _suffix_prefix_score, :188-208, plus their bonus, _continuation_bonuses :121-146), pass 2 every
+ * window of 2..max_span ayat of the surahs of the top 20.  codes_host: the NORMALISED text as
+ * alphabet codes; bonus_verse / bonus_value: n_bonus (0..3) global verse indices and their
+ * bonuses; max_span in [2, 8].  Outputs the winner (first verse index, number of ayat, score);
+ * the caller applies the threshold.  SYNCHRONOUS on `stream`. */
+int qv_match_verse(qv_engine *e, const uint8_t *codes_host, int32_t n_codes, int32_t n_bonus,
+                   const int32_t *bonus_verse, const double *bonus_value, int32_t max_span,
+                   int32_t *start, int32_t *span, double *score, void *stream);
+
 /* Device pointer of the packed (surah, ayah, ayah_end, float-bits(score)) i32[B,4] rows of the
  * last async call -- the payload of the per-batch RCCL all-gather. */
 const int32_t *qv_packed_results_dev(qv_engine *e);

@@ -608,6 +608,26 @@ extern "C" int qv_tracker_match(qv_engine *eng, const uint8_t *codes_host, const
                                  (hipStream_t)stream);
 }
 
+extern "C" int qv_match_verse(qv_engine *eng, const uint8_t *codes_host, int32_t n_codes, int32_t n_bonus,
+                              const int32_t *bonus_verse, const double *bonus_value, int32_t max_span, int32_t *start,
+                              int32_t *span, double *score, void *stream) {
+    if (!eng) return QV_ERR_ARG;
+    if (n_codes < 0 || (n_codes > 0 && !codes_host) || n_bonus < 0 || n_bonus > 3 || (n_bonus > 0 && (!bonus_verse || !bonus_value)) ||
+        max_span < 2 || max_span > 8 || !start || !span || !score) {
+        qv_set_error(eng, "qv_match_verse: bad argument (n_bonus in [0,3], max_span in [2,8])");
+        return QV_ERR_ARG;
+    }
+    for (int i = 0; i < n_bonus; ++i)
+        if (bonus_verse[i] < 0 || bonus_verse[i] >= eng->tab.n_verses) { qv_set_error(eng, "qv_match_verse: bonus verse out of range"); return QV_ERR_ARG; }
+    if (n_codes > QV_MAXQ) { qv_set_error(eng, "qv_match_verse: text longer than QV_MAX_TRANSCRIPT"); return QV_ERR_CAPACITY; }
+    int rc = qv_post_match_verse(eng, codes_host, n_codes, n_bonus, bonus_verse, bonus_value, max_span, (hipStream_t)stream);
+    if (rc) return rc;
+    QvUtt u;
+    QV_HIP(hipMemcpy(&u, eng->work.utt, sizeof(QvUtt), hipMemcpyDeviceToHost));
+    *start = u.base_start; *span = u.base_span; *score = u.base_score;
+    return QV_OK;
+}
+
 extern "C" int qv_debug_ctc_loss(qv_engine *eng, const float *lp, int32_t T, const uint16_t *tg, const int32_t *lens,
                                  int32_t n, float *loss_host, void *stream) {
     if (!eng || n < 1) return QV_ERR_ARG;

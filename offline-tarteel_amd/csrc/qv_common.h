@@ -102,6 +102,13 @@ struct QvUtt {           // one per utterance, device memory (SoA would not buy 
     int32_t n_cand;
     int32_t win;           // winning candidate index or -1
     float win_norm;
+    // match_verse with a continuation hint and without the trigram restriction (qv_match_verse;
+    // the hot path leaves both at 0): up to 3 verses get a bonus and a suffix-prefix score
+    int32_t force_full;
+    int32_t hint_n;
+    int32_t hint_v[3];
+    double hint_bonus[3];
+    double hint_sp[3];
 };
 
 struct QvWork {
@@ -162,6 +169,8 @@ int qv_post_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32
 int qv_post_run(qv_engine *eng, const float *logprobs_dev, int t_max, const int32_t *t_host, int batch,
                 hipStream_t stream);
 int qv_post_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int n, hipStream_t stream);
+int qv_post_match_verse(qv_engine *eng, const uint8_t *codes_host, int n, int n_bonus, const int32_t *bonus_verse,
+                        const double *bonus_value, int max_span, hipStream_t stream);
 int qv_post_debug_ctc(qv_engine *eng, const float *lp, int T, const uint16_t *tg, const int32_t *lens, int n,
                       float *loss_host, hipStream_t stream);
 

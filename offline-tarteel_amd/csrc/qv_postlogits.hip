@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) void k_decode(QvTables tab, QvWork wk) {
         u.flags = flags;
         u.base_start = -1; u.base_span = 0; u.base_score = 0.0;
         u.use_ctc = 0; u.n_cand = 0; u.win = -1; u.win_norm = 0.f;
-        u.n_cand1 = 0; u.full_scan = 0; u.n_runners = 0; u.n_surah20 = 0;
+        u.n_cand1 = 0; u.full_scan = 0; u.n_runners = 0; u.n_surah20 = 0; u.force_full = 0; u.hint_n = 0;
         u.best1_idx = -1; u.best1_score = 0.0;
     }
 }
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(64) void k_prepare_codes(QvWork wk, int n) {
         u.base_start = -1; u.base_span = 0; u.base_score = 0.0;
         u.use_ctc = 0; u.n_cand = 0; u.win = -1; u.win_norm = 0.f;
         u.n_cand1 = 0; u.full_scan = 0; u.n_runners = 0; u.n_surah20 = 0; u.best1_idx = -1; u.best1_score = 0.0;
+        u.force_full = 0; u.hint_n = 0;
     }
 }
 
@@ -509,6 +510,11 @@ __global__ __launch_bounds__(256) void k_trigram(QvTables tab, QvWork wk) {
     const int m = u.q_len, N = tab.n_verses;
     if (m == 0) return;
     int32_t *cand1 = wk.cand1 + (size_t)b * N;
+    if (u.force_full) {  // match_verse(use_trigram_index=False): every verse, in verse order
+        for (int v = tid; v < N; v += 256) cand1[v] = v;
+        if (tid == 0) { u.n_cand1 = N; u.full_scan = 1; }
+        return;
+    }
     for (int v = tid; v < N; v += 256) score[v] = -1.0;        // -1 = not touched
     for (int i = tid; i < TRI_WORDS; i += 256) bits[i] = 0;
     __syncthreads();
@@ -788,6 +794,53 @@ __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode)
     }
 }
 
+// ------------------------------------------------------------------ 4b. hint scores ----
+// _suffix_prefix_score (quran_db.py:188-208) for the <= 3 verses of the continuation hint, both
+// of their texts: the transcript minus its first 1..min(words/2, 4) words against the equally
+// long word prefix of the verse.  One lane per (verse, text, trim); pattern = the verse's
+// precomputed match masks (a word prefix of the pattern is the low bits of the same masks).
+__global__ __launch_bounds__(64) void k_hint_sp(QvTables tab, QvWork wk, int b) {
+    QvUtt &u = wk.utt[b];
+    const int lane = threadIdx.x, m = u.q_len, qw = u.q_words;
+    const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
+    double best = 0.0;
+    const int k = lane >> 3, variant = (lane >> 2) & 1, trim = (lane & 3) + 1;   // 3 x 2 x 4 jobs
+    const int max_trim = (qw >> 1) < 4 ? (qw >> 1) : 4;
+    if (k < u.hint_n && m > 0 && qw >= 2 && trim <= max_trim) {
+        const int v = u.hint_v[k];
+        TextRef t = text_of(tab, v, variant);
+        if (t.nw >= 2) {
+            int start = 0, seen = 0;                         // transcript after its first `trim` words
+            for (int i = 0; i < m; ++i)
+                if (q[i] == 0 && ++seen == trim) { start = i + 1; break; }
+            const int nt = qw - trim, pw = nt < t.nw ? nt : t.nw;
+            int plen = t.n;
+            if (pw < t.nw) {
+                seen = 0;
+                for (int i = 0; i < t.n; ++i)
+                    if (t.p[i] == 0 && ++seen == pw) { plen = i; break; }
+            }
+            const int ls = m - start;
+            const uint64_t *pm = tab.pmv + tab.pmv_off[t.tid];
+            int l = lcs_dispatch((plen + 63) >> 6, pm, qv_tmpl_w((t.n + 63) >> 6), q + start, ls, plen);
+            best = ratio_from(l, ls, plen);
+        }
+    }
+    // max over the 8 lanes of a verse
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { double x = __shfl_xor(best, o); if (x > best) best = x; }
+    if ((lane & 7) == 0 && k < u.hint_n) u.hint_sp[k] = best;
+}
+
+__global__ void k_set_hint(QvWork wk, int b, int n, int v0, int v1, int v2, double b0, double b1, double b2) {
+    QvUtt &u = wk.utt[b];
+    u.force_full = 1;
+    u.hint_n = n;
+    u.hint_v[0] = v0; u.hint_v[1] = v1; u.hint_v[2] = v2;
+    u.hint_bonus[0] = b0; u.hint_bonus[1] = b1; u.hint_bonus[2] = b2;
+    u.hint_sp[0] = u.hint_sp[1] = u.hint_sp[2] = 0.0;
+}
+
 // ------------------------------------------------------------------ 5. pass-1 finalize -
 // stable descending sort of min(raw,1.0) in iteration order (quran_db.py:290-331): only the
 // first max(top_k,5) entries are ever used, selected by repeated block argmax.
@@ -807,7 +860,11 @@ __global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, Qv
         double a = fs[v * 3], c = fs[v * 3 + 1], d = fs[v * 3 + 2];
         double raw = a > c ? a : c;
         if (d > raw) raw = d;
-        sc[p] = raw < 1.0 ? raw : 1.0;
+        double bonus = 0.0;                       // continuation hint (quran_db.py:300-311); none on the hot path
+        for (int k = 0; k < u.hint_n; ++k)
+            if (v == u.hint_v[k]) { if (u.hint_sp[k] > raw) raw = u.hint_sp[k]; bonus = u.hint_bonus[k]; }
+        double tot = __dadd_rn(raw, bonus);
+        sc[p] = tot < 1.0 ? tot : 1.0;
     }
     __syncthreads();
     int K = kn.top_text > 5 ? kn.top_text : 5;
@@ -883,9 +940,13 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
             uint32_t start = tab.clean_off[v0] + (nl ? tab.clean_len[v0] - nl : 0);
             int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
             int mn = m < n ? m : n;
-            if (!(ratio_from(mn, m, n) > u.best1_score)) continue;
+            double bonus = 0.0;                   // of the span's first verse (quran_db.py:352-353)
+            for (int k = 0; k < u.hint_n; ++k)
+                if (v0 == u.hint_v[k]) bonus = u.hint_bonus[k];
+            double ub = __dadd_rn(ratio_from(mn, m, n), bonus);
+            if (!((ub < 1.0 ? ub : 1.0) > u.best1_score)) continue;
             int l = lcs_dispatch(W, pm, QV_PMS, tab.clean + start, n, m);
-            double raw = ratio_from(l, m, n);
+            double raw = __dadd_rn(ratio_from(l, m, n), bonus);
             double sc = raw < 1.0 ? raw : 1.0;
             unsigned long long key = (unsigned long long)base + (unsigned long long)(i * per + span - 2);
             if (better(sc, key, best, bkey)) { best = sc; bkey = key; }
@@ -1524,5 +1585,38 @@ int qv_post_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32
         QV_HIP(hipMemcpyAsync(out_host + b0, tw.out, sizeof(qv_track_match) * nb, hipMemcpyDeviceToHost, stream));
         QV_HIP(hipStreamSynchronize(stream));   // meta[] and the workspace are reused by the next slice
     }
+    return QV_OK;
+}
+
+// match_verse(text, max_span, hint, use_trigram_index=False) (quran_db.py:244-371): full scan,
+// continuation bonuses, span pass; result in utt[0].base_* (SYNCHRONOUS).
+int qv_post_match_verse(qv_engine *eng, const uint8_t *codes_host, int n, int n_bonus, const int32_t *bonus_verse,
+                        const double *bonus_value, int max_span, hipStream_t stream) {
+    QvTables &tab = eng->tab;
+    QvWork &wk = eng->work;
+    QvKnobs kn = eng->knobs;
+    kn.max_span = max_span;
+    const int N = tab.n_verses;
+    int32_t zero = 0;
+    QV_HIP(hipMemcpyAsync(eng->t_dev, &zero, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_init_utts, dim3(1), dim3(64), 0, stream, wk, eng->t_dev, 1);
+    if (n > 0) QV_HIP(hipMemcpyAsync(wk.q, codes_host, n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_prepare_codes, dim3(1), dim3(64), 0, stream, wk, n);
+    int hv[3] = {-1, -1, -1};
+    double hb[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < n_bonus; ++i) { hv[i] = bonus_verse[i]; hb[i] = bonus_value[i]; }
+    hipLaunchKernelGGL(k_set_hint, dim3(1), dim3(1), 0, stream, wk, 0, n_bonus, hv[0], hv[1], hv[2], hb[0], hb[1], hb[2]);
+    size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + TRI_WORDS * 4 +
+                    QV_MAXQ * 2 + 8 * 4 + 64;
+    hipLaunchKernelGGL(k_trigram, dim3(1), dim3(256), sm_tri, stream, tab, wk);
+    hipLaunchKernelGGL(k_lcs_full, dim3(32, 1), dim3(256), 0, stream, tab, wk, 0);
+    hipLaunchKernelGGL(k_frag, dim3(256, 1), dim3(256), 0, stream, tab, wk, 0);
+    if (n_bonus > 0) hipLaunchKernelGGL(k_hint_sp, dim3(1), dim3(64), 0, stream, tab, wk, 0);
+    size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
+    hipLaunchKernelGGL(k_pass1_final, dim3(1), dim3(256), sm_p1, stream, tab, wk, kn);
+    hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, 1), dim3(256), 0, stream, tab, wk, kn);
+    hipLaunchKernelGGL(k_base_final, dim3(1), dim3(64), 0, stream, tab, wk, kn, 1, 0);
+    QV_HIP(hipGetLastError());
+    QV_HIP(hipStreamSynchronize(stream));
     return QV_OK;
 }

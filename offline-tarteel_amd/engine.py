@@ -100,6 +100,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_packed_results_ctx.restype = vp
     lib.qv_fetch_results_ctx.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.qv_tracker_match.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.qv_match_verse.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp]
     lib.qv_debug_retrieve.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.qv_debug_ctc_loss.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     lib.qv_debug_forward_tap.argtypes = [vp, i32, i32, vp, vp]
@@ -399,6 +400,62 @@ class Engine:
         return [None if m.verse < 0 else
                 {"surah": m.surah, "ayah": m.ayah, "n_words": m.n_words, "score": m.score, "verse": m.verse,
                  "variant": m.variant} for m in out]
+
+    def continuation_bonuses(self, hint) -> list[tuple[int, float]]:
+        """QuranDB._continuation_bonuses (shared/quran_db.py:121-146) as (verse index, bonus)
+        pairs: the three ayat after the hint, or - when the hint is the last ayah of its surah -
+        the first three of the next surah."""
+        if not hint:
+            return []
+        s, a = hint
+        t = self.tables.s
+        n_surah = len(t["surah_len"])
+
+        def idx(su, ay):
+            if 1 <= su <= n_surah and 1 <= ay <= int(t["surah_len"][su - 1]):
+                return int(t["surah_start"][su - 1]) + ay - 1
+            return None
+
+        out = []
+        if idx(s, a + 1) is not None:
+            for k, bonus in enumerate((0.22, 0.12, 0.06)):
+                i = idx(s, a + 1 + k)
+                if i is not None:
+                    out.append((i, bonus))
+        elif 1 <= s + 1 <= n_surah:
+            first = int(t["surah_start"][s])
+            for k, bonus in zip(range(min(3, int(t["surah_len"][s]))), (0.22, 0.12, 0.06)):
+                out.append((first + k, bonus))
+        return out
+
+    def match_verse(self, text: str, threshold: float = 0.3, max_span: int = 3, hint=None) -> dict | None:
+        """QuranDB.match_verse without the trigram restriction (qv_match_verse).  Returns None
+        below the threshold, else {surah, ayah, ayah_end (None for one ayah), score, n_words}
+        where n_words counts the words of the matched text_clean (what the caller trims by)."""
+        text = normalize_arabic(text)
+        if not text.strip():
+            return None
+        codes = np.ascontiguousarray(self.tables.encode(text))
+        bon = self.continuation_bonuses(hint)
+        bv = np.ascontiguousarray(np.array([b[0] for b in bon] + [0] * (3 - len(bon)), np.int32))
+        bb = np.ascontiguousarray(np.array([b[1] for b in bon] + [0.0] * (3 - len(bon)), np.float64))
+        st, sp, sc = C.c_int32(), C.c_int32(), C.c_double()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.qv_match_verse(self.h, p(codes), len(codes), len(bon), p(bv), p(bb), int(max_span),
+                                     C.byref(st), C.byref(sp), C.byref(sc), self._stream())
+        self._check(rc, "qv_match_verse")
+        if st.value < 0 or not (sc.value >= threshold):
+            return None
+        v, span = st.value, sp.value
+        t = self.tables.s
+        if span == 1:
+            n_words = int(t["clean_nw"][v])
+        else:
+            first = int(t["nobsm_nw"][v]) or int(t["clean_nw"][v])
+            n_words = first + sum(int(t["clean_nw"][v + k]) for k in range(1, span))
+        s, a = int(self.tables.surah[v]), int(self.tables.ayah[v])
+        return {"surah": s, "ayah": a, "ayah_end": a + span - 1 if span > 1 else None, "score": sc.value,
+                "n_words": n_words, "verse": v, "span": span}
 
     def transcribe_batch(self, audio, lengths) -> list[str]:
         """Forward + greedy CTC decode of a zero-padded batch (float32 cuda [B, N]); the

@@ -6,6 +6,7 @@
                                                     confirmed emissions, VerseTracker in
                                                     streaming mode fed chunk by chunk
     run_on_audio_chunked_batch(paths)      (new)    the same for many recordings at once
+    run_on_full_transcript(path, fn)       :58-105  whole transcript, verses peeled off front to back
 
 The chunk walk never depends on a transcript, so with the engine as the ASR backend
 (``transcribe_fn=None``) ALL chunks of ALL recordings go through the acoustic model as one packed
@@ -13,8 +14,9 @@ ragged batch, and the trackers are then advanced in lock step with one ``qv_trac
 per round (verse_tracker.drive_many).  A caller-supplied ``transcribe_fn(wav_path) -> str | dict``
 is honoured exactly like in the reference (one 16-bit PCM temporary WAV per chunk).
 
-``run_on_full_transcript`` (:58-105) is not part of this row: it needs ``match_verse`` with a
-continuation hint and max_span = 8, outside the span tables (<= 6) of the hot path; it raises.
+``run_on_full_transcript`` (:58-105) peels verses off the front of a whole-file transcript with
+``match_verse(remaining, max_span=8, hint=...)``; that call is ``qv_match_verse`` here (full scan of
+all verses, continuation bonuses and suffix-prefix scores on the device).
 """
 
 from __future__ import annotations
@@ -27,6 +29,7 @@ from pathlib import Path
 import numpy as np
 
 from .audio import load_audio
+from .normalizer import normalize_arabic
 from .verse_tracker import STREAMING_MIN_EMIT_SCORE, VerseTracker, drive_many
 
 SAMPLE_RATE = 16000
@@ -116,9 +119,10 @@ class StreamingPipeline:
     """``db``: an ``Engine`` (or None for the plugin's process-wide engine).  ``matcher`` overrides
     the tracker's matching step (tests)."""
 
-    def __init__(self, db=None, matcher=None):
+    def __init__(self, db=None, matcher=None, match_verse_fn=None):
         self._engine = db
         self._matcher = matcher
+        self._match_verse_fn = match_verse_fn   # (text, max_span, hint) -> dict | None; tests only
 
     def _eng(self):
         if self._engine is None:
@@ -142,10 +146,37 @@ class StreamingPipeline:
         out.extend(tracker.finalize())
         return out
 
-    def run_on_full_transcript(self, audio_path: str, transcribe_fn):
-        raise NotImplementedError(
-            "run_on_full_transcript needs match_verse(max_span=8, hint=...), which is outside this build's "
-            "hot path (span tables stop at 6 ayat, no hint bonus); use run_on_audio_chunked or predict().")
+    def run_on_full_transcript(self, audio_path, transcribe_fn=None) -> list[dict]:
+        """:58-105.  ``transcribe_fn(audio_path) -> str``; None = the engine."""
+        if transcribe_fn is None:
+            import torch
+
+            eng = self._eng()
+            audio = self._load(audio_path)
+            transcript = eng.transcribe_batch(torch.from_numpy(audio[None, :]).cuda(eng.device), [len(audio)])[0]
+        else:
+            transcript = transcribe_fn(audio_path)
+        match = self._match_verse_fn
+        if match is None:
+            eng = self._eng()
+            match = lambda text, max_span, hint: eng.match_verse(text, max_span=max_span, hint=hint)  # noqa: E731
+        remaining = normalize_arabic(transcript)
+        if not remaining.strip():
+            return []
+        out, hint, min_score = [], None, 0.3
+        for _ in range(20):                       # safety bound of the reference
+            if not remaining.strip():
+                break
+            r = match(remaining, 8, hint)
+            if not r or r.get("score", 0) < min_score:
+                break
+            min_score = 0.7                       # after the first match only confident ones continue
+            end = r.get("ayah_end") or r["ayah"]
+            out.extend({"surah": r["surah"], "ayah": a, "score": r["score"]} for a in range(r["ayah"], end + 1))
+            words = remaining.split()
+            remaining = " ".join(words[min(r["n_words"], len(words)):])
+            hint = (r["surah"], end)
+        return out
 
     # ------------------------------------------------------------------ audio -----
     def transcribe_chunks(self, chunk_lists: list[list[np.ndarray]]) -> list[list[str]]:

@@ -117,3 +117,131 @@ class TrackerOracle:
             return None
         return {"surah": int(self.o.surah[v]), "ayah": int(self.o.ayah[v]), "n_words": nw, "score": score,
                 "verse": v, "variant": var}
+
+
+class MatchVerseOracle:
+    """QuranDB.match_verse(text, threshold=0.3, max_span, hint, use_trigram_index=False)
+    (shared/quran_db.py:244-371) as StreamingPipeline.run_on_full_transcript calls it
+    (shared/streaming.py:86), over the oracle's C primitives (Indel ratio, fragment score):
+
+        _continuation_bonuses   :121-146     _suffix_prefix_score   :188-208
+        pass 1 (all verses)     :289-312     pass 2 (spans)         :334-365
+
+    Pinned by tests/golden/fulltx_cases.json.gz (tests/golden/gen_fulltx_golden.py)."""
+
+    def __init__(self, oracle: Oracle | None = None):
+        self.o = oracle or Oracle()
+        t = self.o.t
+        self.n = len(t["surah"])
+        sl = lambda name, v: np.ascontiguousarray(t[name][t[name + "_off"][v]: t[name + "_off"][v + 1]])  # noqa: E731
+        self.clean = [sl("clean", v) for v in range(self.n)]
+        self.alt = [sl("alt", v) for v in range(self.n)]
+        self.nobsm = [sl("nobsm", v) for v in range(self.n)]
+        self.lib = self.o.lib
+
+    def _call(self, fn, a: np.ndarray, b: np.ndarray) -> float:
+        return fn(a.ctypes.data_as(_U8P), len(a), b.ctypes.data_as(_U8P), len(b))
+
+    def ratio(self, a, b) -> float:
+        return self._call(self.lib.qvo_ratio, a, b)
+
+    def frag(self, q, v) -> float:
+        return self._call(self.lib.qvo_fragment_score, q, v)
+
+    def bonuses(self, hint) -> dict[int, float]:
+        if not hint:
+            return {}
+        s, a = hint
+        t = self.o.t
+
+        def idx(su, ay):
+            if 1 <= su <= 114 and 1 <= ay <= int(t["surah_len"][su - 1]):
+                return int(t["surah_start"][su - 1]) + ay - 1
+            return None
+
+        out = {}
+        if idx(s, a + 1) is not None:
+            for k, b in enumerate((0.22, 0.12, 0.06)):
+                i = idx(s, a + 1 + k)
+                if i is not None:
+                    out[i] = b
+        elif 1 <= s + 1 <= 114:
+            first = int(t["surah_start"][s])
+            for k in range(min(3, int(t["surah_len"][s]))):
+                out[first + k] = (0.22, 0.12, 0.06)[k]
+        return out
+
+    @staticmethod
+    def _words(codes: np.ndarray) -> list[np.ndarray]:
+        cuts = [-1] + np.flatnonzero(codes == 0).tolist() + [len(codes)]
+        return [codes[cuts[i] + 1: cuts[i + 1]] for i in range(len(cuts) - 1)]
+
+    @staticmethod
+    def _join(words) -> np.ndarray:
+        out = []
+        for i, w in enumerate(words):
+            if i:
+                out.append(np.zeros(1, np.uint8))
+            out.append(w)
+        return np.ascontiguousarray(np.concatenate(out)) if out else np.zeros(0, np.uint8)
+
+    def suffix_prefix(self, q: np.ndarray, v: np.ndarray) -> float:
+        wt, wv = self._words(q), self._words(v)
+        if len(wt) < 2 or len(wv) < 2:
+            return 0.0
+        best = 0.0
+        for trim in range(1, min(len(wt) // 2, 4) + 1):
+            n = len(wt) - trim
+            best = max(best, self.ratio(self._join(wt[trim:]), self._join(wv[: min(n, len(wv))])))
+        return best
+
+    def match_verse(self, text: str, threshold: float = 0.3, max_span: int = 3, hint=None):
+        text = normalize_arabic(text)
+        if not text.strip():
+            return None
+        q = np.ascontiguousarray(self.o.encode(text))
+        bon = self.bonuses(hint)
+        scored = []
+        for v in range(self.n):
+            raw = max(self.frag(q, self.clean[v]), self.frag(q, self.alt[v]))
+            if len(self.nobsm[v]):
+                raw = max(raw, self.frag(q, self.nobsm[v]))
+            b = bon.get(v, 0.0)
+            if b > 0:
+                raw = max(raw, self.suffix_prefix(q, self.clean[v]), self.suffix_prefix(q, self.alt[v]))
+            scored.append((v, raw, b, min(raw + b, 1.0)))
+        scored.sort(key=lambda x: x[3], reverse=True)          # stable: ties stay in verse order
+        v0, raw0, b0, best_score = scored[0]
+        best = (v0, 1, best_score, raw0, b0)
+        t = self.o.t
+        seen = set()
+        for v, _r, _b, _t in scored[:20]:
+            s = int(self.o.surah[v])
+            if s in seen:
+                continue
+            seen.add(s)
+            first, sl = int(t["surah_start"][s - 1]), int(t["surah_len"][s - 1])
+            for i in range(sl):
+                for span in range(2, max_span + 1):
+                    if i + span > sl:
+                        break
+                    a = first + i
+                    head = self.nobsm[a] if len(self.nobsm[a]) else self.clean[a]
+                    combined = self._join([head] + [self.clean[a + k] for k in range(1, span)])
+                    raw = self.ratio(q, combined)
+                    b = bon.get(a, 0.0)
+                    score = min(raw + b, 1.0)
+                    if score > best_score:
+                        best_score = score
+                        best = (a, span, score, raw, b)
+        if best_score < threshold:
+            return None
+        v, span, score, raw, b = best
+        if span == 1:
+            n_words = len(self._words(self.clean[v]))
+        else:
+            head = self.nobsm[v] if len(self.nobsm[v]) else self.clean[v]
+            n_words = len(self._words(head)) + sum(len(self._words(self.clean[v + k])) for k in range(1, span))
+        a = int(self.o.ayah[v])
+        return {"surah": int(self.o.surah[v]), "ayah": a, "ayah_end": a + span - 1 if span > 1 else None,
+                "score": score, "raw_score": raw, "bonus": b, "n_words": n_words, "verse": v, "span": span}

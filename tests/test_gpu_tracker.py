@@ -216,11 +216,56 @@ def test_reference_unit_scenarios(engine, oracle):
     e = pipe.run_on_audio_chunked(np.zeros(16000 * 3, np.float32),
                                   lambda p: {"text": verse(112, 1), "avg_logprob": -0.3}, chunk_seconds=3.0)
     assert e and (e[0]["surah"], e[0]["ayah"]) == (112, 1) and e[0]["score"] >= 0.7
-    with pytest.raises(NotImplementedError):
-        pipe.run_on_full_transcript("x.wav", lambda p: verse(112, 1))
+    e = pipe.run_on_full_transcript("x.wav", lambda p: verse(112, 1))     # mock transcribe, like the reference's test
+    assert e and (e[0]["surah"], e[0]["ayah"]) == (112, 1)
 
     # QuranDB.get_next_verse navigation (tests/test_quran_db.py)
     assert engine.next_verse(1, 1) == oracle.verse_index(1, 2)
     assert engine.next_verse(1, 7) == oracle.verse_index(2, 1)
     assert engine.next_verse(114, 6) == -1
     assert engine.next_verse(999, 1) == -1
+
+
+def test_match_verse_hint_golden_and_oracle(engine, golden_dir, oracle):
+    """qv_match_verse (full scan + continuation hint + spans up to 8) against the reference-generated
+    fixtures and, on seeded texts, against the oracle: same winner, bit-identical fp64 score."""
+    from oracle.tracker_ref import MatchVerseOracle
+
+    with gzip.open(golden_dir / "fulltx_cases.json.gz", "rt", encoding="utf-8") as f:
+        fx = json.load(f)
+    for c in fx["match"]:
+        r = engine.match_verse(c["text"], max_span=8, hint=tuple(c["hint"]) if c["hint"] else None)
+        w = c["result"]
+        assert (r is None) == (w is None), c["text"]
+        if r:
+            for k in ("surah", "ayah", "ayah_end", "score", "n_words"):
+                assert r[k] == w[k], (c["text"], k, r[k], w[k])
+    mv = MatchVerseOracle(oracle)
+    rng = random.Random(11)
+    for _ in range(12):
+        v = rng.randrange(6236 - 4)
+        k = rng.choice((1, 2, 3))
+        words = " ".join(oracle.verse_text(v + j) for j in range(k)).split()
+        lo = rng.randrange(0, max(1, len(words) // 3))
+        text = " ".join(words[lo: lo + rng.randrange(3, 40)])[:900]
+        s, a = int(oracle.surah[v]), int(oracle.ayah[v])
+        hint = rng.choice([None, (s, a - 1) if a > 1 else None, (s, a), (s - 1, 999) if s > 1 else None])
+        for max_span in (3, 8):
+            r = engine.match_verse(text, threshold=0.0, max_span=max_span, hint=hint)
+            w = mv.match_verse(text, threshold=0.0, max_span=max_span, hint=hint)
+            assert (r["verse"], r["span"], r["score"], r["n_words"]) == (w["verse"], w["span"], w["score"], w["n_words"]), \
+                (text, hint, max_span, r, w)
+    from offline_tarteel_amd.engine import QvError
+
+    with pytest.raises(QvError):
+        engine.match_verse("قل هو الله احد", max_span=9)
+
+
+def test_run_on_full_transcript_golden(engine, golden_dir):
+    from offline_tarteel_amd.streaming import StreamingPipeline
+
+    with gzip.open(golden_dir / "fulltx_cases.json.gz", "rt", encoding="utf-8") as f:
+        fx = json.load(f)
+    pipe = StreamingPipeline(engine)
+    for c in fx["full"]:
+        assert pipe.run_on_full_transcript("x.wav", lambda p, t=c["text"]: t) == c["emissions"], c["text"]

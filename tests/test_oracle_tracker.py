@@ -105,3 +105,37 @@ def test_wav16_roundtrip(tmp_path):
     _write_wav16(str(p), x)
     y = load_audio(str(p))
     assert len(y) == len(x) and np.max(np.abs(y - x)) <= 2.0 / 32768.0   # scale 32767 out, 32768 in, half an LSB of rounding
+
+
+@pytest.fixture(scope="module")
+def fulltx(golden_dir):
+    with gzip.open(golden_dir / "fulltx_cases.json.gz", "rt", encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def mv_oracle(oracle):
+    from oracle.tracker_ref import MatchVerseOracle
+
+    return MatchVerseOracle(oracle)
+
+
+def test_oracle_match_verse_hint_matches_reference(fulltx, mv_oracle):
+    """match_verse(text, max_span=8, hint) without the trigram restriction: winner, fp64 score,
+    raw score, bonus and the matched text's word count equal the reference's."""
+    for c in fulltx["match"]:
+        r = mv_oracle.match_verse(c["text"], max_span=8, hint=tuple(c["hint"]) if c["hint"] else None)
+        w = c["result"]
+        assert (r is None) == (w is None), c["text"]
+        if r:
+            for k in ("surah", "ayah", "ayah_end", "score", "raw_score", "bonus", "n_words"):
+                assert r[k] == w[k], (c["text"], k, r[k], w[k])
+
+
+def test_host_run_on_full_transcript_matches_reference(fulltx, mv_oracle):
+    from offline_tarteel_amd.streaming import StreamingPipeline
+
+    pipe = StreamingPipeline(matcher=lambda *a: [], match_verse_fn=lambda text, max_span, hint:
+                             mv_oracle.match_verse(text, max_span=max_span, hint=hint))
+    for c in fulltx["full"]:
+        assert pipe.run_on_full_transcript("x.wav", lambda p, t=c["text"]: t) == c["emissions"], c["text"]
