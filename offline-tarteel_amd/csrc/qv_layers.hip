@@ -363,38 +363,86 @@ __device__ __forceinline__ void ln_row(const float v[8], const float *__restrict
     for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * g0[i] + b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * g1[i] + b1[i]; }
 }
 
+// LayerNorm parameters of one lane (8 channels), requested before the row statistics so that
+// their latency overlaps the reductions
+struct LnParam { f32x4 g0, g1, b0, b1; };
+__device__ __forceinline__ LnParam ln_param(const float *__restrict__ gam, const float *__restrict__ bet, int lane) {
+    LnParam p;
+    p.g0 = *(const f32x4 *)(gam + lane * 8); p.g1 = *(const f32x4 *)(gam + lane * 8 + 4);
+    p.b0 = *(const f32x4 *)(bet + lane * 8); p.b1 = *(const f32x4 *)(bet + lane * 8 + 4);
+    return p;
+}
+__device__ __forceinline__ void ln_row_p(const float v[8], const LnParam &p, float o[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    float mu = wave_sum(s) * (1.f / QV_D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { float d = v[i] - mu; q += d * d; }
+    float rs = rsqrtf(wave_sum(q) * (1.f / QV_D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * p.g0[i] + p.b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * p.g1[i] + p.b1[i]; }
+}
+
+// One wave normalises LN_ROWS consecutive rows: all their loads (and the parameters) are in flight
+// before the first reduction, and a wave lives for LN_ROWS rows instead of one.
+#define LN_ROWS 2
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ gam,
                                                    const float *__restrict__ bet, half_t *__restrict__ y, int M) {
-    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const float *p = x + (size_t)row * QV_D + lane * 8;
-    f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
-    float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}, o[8];
-    ln_row(v, gam, bet, lane, o);
-    half8 h;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;
+    if (row0 >= M) return;
+    f32x4 a[LN_ROWS], c[LN_ROWS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = (half_t)o[i];
-    *(half8 *)(y + (size_t)row * QV_D + lane * 8) = h;
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const int row = row0 + r < M ? row0 + r : M - 1;
+        const float *p = x + (size_t)row * QV_D + lane * 8;
+        a[r] = *(const f32x4 *)p; c[r] = *(const f32x4 *)(p + 4);
+    }
+    const LnParam pr = ln_param(gam, bet, lane);
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        if (row0 + r >= M) break;
+        float v[8] = {a[r][0], a[r][1], a[r][2], a[r][3], c[r][0], c[r][1], c[r][2], c[r][3]}, o[8];
+        ln_row_p(v, pr, o);
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (half_t)o[i];
+        *(half8 *)(y + (size_t)(row0 + r) * QV_D + lane * 8) = h;
+    }
 }
 
 // x <- LN_out(x) (f32, in place: the next layer's residual stream), y <- LN_next(x) (f16)
 __global__ __launch_bounds__(256) void k_layernorm2(float *__restrict__ x, const float *__restrict__ g1, const float *__restrict__ b1,
                                                     const float *__restrict__ g2, const float *__restrict__ b2,
                                                     half_t *__restrict__ y, int M) {
-    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    float *p = x + (size_t)row * QV_D + lane * 8;
-    f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
-    float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}, o[8], o2[8];
-    ln_row(v, g1, b1, lane, o);
-    *(f32x4 *)p = f32x4{o[0], o[1], o[2], o[3]};
-    *(f32x4 *)(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
-    if (y) {
-        ln_row(o, g2, b2, lane, o2);
-        half8 h;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;
+    if (row0 >= M) return;
+    f32x4 a[LN_ROWS], c[LN_ROWS];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = (half_t)o2[i];
-        *(half8 *)(y + (size_t)row * QV_D + lane * 8) = h;
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const int row = row0 + r < M ? row0 + r : M - 1;
+        const float *p = x + (size_t)row * QV_D + lane * 8;
+        a[r] = *(const f32x4 *)p; c[r] = *(const f32x4 *)(p + 4);
+    }
+    const LnParam p1 = ln_param(g1, b1, lane);
+    LnParam p2 = p1;
+    if (y) p2 = ln_param(g2, b2, lane);
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        if (row0 + r >= M) break;
+        float *p = x + (size_t)(row0 + r) * QV_D + lane * 8;
+        float v[8] = {a[r][0], a[r][1], a[r][2], a[r][3], c[r][0], c[r][1], c[r][2], c[r][3]}, o[8], o2[8];
+        ln_row_p(v, p1, o);
+        *(f32x4 *)p = f32x4{o[0], o[1], o[2], o[3]};
+        *(f32x4 *)(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        if (y) {
+            ln_row_p(o, p2, o2);
+            half8 h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = (half_t)o2[i];
+            *(half8 *)(y + (size_t)(row0 + r) * QV_D + lane * 8) = h;
+        }
     }
 }
 
@@ -873,12 +921,12 @@ void launch_pack_rows(const half_t *x, int t_max, int row_elems, const int32_t *
 }
 
 void launch_layernorm(const float *x, const float *g, const float *b, half_t *y, int M, hipStream_t s) {
-    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, M);
+    hipLaunchKernelGGL(k_layernorm, dim3((M + 4 * LN_ROWS - 1) / (4 * LN_ROWS)), dim3(256), 0, s, x, g, b, y, M);
 }
 
 void launch_layernorm2(float *x, const float *g1, const float *b1, const float *g2, const float *b2, half_t *y, int M,
                        hipStream_t s) {
-    hipLaunchKernelGGL(k_layernorm2, dim3((M + 3) / 4), dim3(256), 0, s, x, g1, b1, g2, b2, y, M);
+    hipLaunchKernelGGL(k_layernorm2, dim3((M + 4 * LN_ROWS - 1) / (4 * LN_ROWS)), dim3(256), 0, s, x, g1, b1, g2, b2, y, M);
 }
 
 void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s) {
