@@ -229,7 +229,9 @@ def main():
         ach = rep["flops"] / (rep["avg_us"] * 1e-6) / 1e12
         traffic = None
         try:
-            pmc = json.loads((ROOT / "profiles" / "r01_i_pmc_traffic.json").read_text())["kernels"]
+            # newest committed PMC summary (tools/pmc_traffic.py; rocprofv3 --pmc passes of tools/gemm_bench)
+            pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
+            pmc = json.loads(pmc_file.read_text())["kernels"]
             traffic = pmc.get(rep["kernel"], {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
