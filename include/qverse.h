@@ -200,7 +200,9 @@ int qv_tracker_match(qv_engine *e, const uint8_t *codes_host, const int32_t *off
  * window of 2..max_span ayat of the surahs of the top 20.  codes_host: the NORMALISED text as
  * alphabet codes; bonus_verse / bonus_value: n_bonus (0..3) global verse indices and their
  * bonuses; max_span in [2, 8].  Outputs the winner (first verse index, number of ayat, score);
- * the caller applies the threshold.  SYNCHRONOUS on `stream`. */
+ * the caller applies the threshold.  SYNCHRONOUS on `stream`.  Uses the workspace of the most
+ * recently used execution context (waits for batches in flight first): fetch the results of an
+ * asynchronous batch before calling it. */
 int qv_match_verse(qv_engine *e, const uint8_t *codes_host, int32_t n_codes, int32_t n_bonus,
                    const int32_t *bonus_verse, const double *bonus_value, int32_t max_span,
                    int32_t *start, int32_t *span, double *score, void *stream);

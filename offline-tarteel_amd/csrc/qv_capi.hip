@@ -608,6 +608,15 @@ extern "C" int qv_tracker_match(qv_engine *eng, const uint8_t *codes_host, const
                                  (hipStream_t)stream);
 }
 
+// Entry points that run a single text through the CURRENT context's workspace on the caller's
+// stream: with batches in flight, wait until no internal stream is still using a workspace.
+static int quiesce_contexts(qv_engine *eng) {
+    if (eng->n_ctx > 1)
+        for (int k = 0; k < eng->n_ctx; ++k)
+            if (eng->ctx[k].busy) QV_HIP(hipEventSynchronize(eng->ctx[k].done));
+    return QV_OK;
+}
+
 extern "C" int qv_match_verse(qv_engine *eng, const uint8_t *codes_host, int32_t n_codes, int32_t n_bonus,
                               const int32_t *bonus_verse, const double *bonus_value, int32_t max_span, int32_t *start,
                               int32_t *span, double *score, void *stream) {
@@ -620,6 +629,7 @@ extern "C" int qv_match_verse(qv_engine *eng, const uint8_t *codes_host, int32_t
     for (int i = 0; i < n_bonus; ++i)
         if (bonus_verse[i] < 0 || bonus_verse[i] >= eng->tab.n_verses) { qv_set_error(eng, "qv_match_verse: bonus verse out of range"); return QV_ERR_ARG; }
     if (n_codes > QV_MAXQ) { qv_set_error(eng, "qv_match_verse: text longer than QV_MAX_TRANSCRIPT"); return QV_ERR_CAPACITY; }
+    QV_TRY(quiesce_contexts(eng));
     int rc = qv_post_match_verse(eng, codes_host, n_codes, n_bonus, bonus_verse, bonus_value, max_span, (hipStream_t)stream);
     if (rc) return rc;
     QvUtt u;
