@@ -138,6 +138,12 @@ def cpu_baseline(audio_np, n_clips: int):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
+    # host / library banner when the first communicator is created), so file descriptor 1 points at
+    # stderr while the benchmark runs and is restored only for the result line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -277,7 +283,10 @@ def main():
                        "batches_in_flight": args.contexts},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     eng.close()
     if use_dist:
         # the last gathered block must hold this rank's own rows
