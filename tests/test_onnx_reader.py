@@ -1,0 +1,209 @@
+"""tools/onnx_reader.py + the --onnx leg of tools/convert_weights.py on synthetic ONNX models.
+
+The models are written by the small protobuf encoder below (independent of the reader: it only
+shares the public onnx.proto field numbers), in the storage forms the reference's
+fastconformer_full_mixed.onnx is described to use: MatMulNBits int4 blocks (with default and with
+packed zero points), int8 tensors behind DequantizeLinear, ConvInteger weights written by dynamic
+quantisation, plain float initializers in raw / typed / fp16 encodings, and an anonymous MatMul
+operand that only the consuming node's scope identifies."""
+
+import importlib.util
+import struct
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, str(ROOT / "tools" / f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ------------------------------------------------------------------ tiny protobuf writer --
+def vint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def key(num, wt):
+    return vint(num << 3 | wt)
+
+
+def ld(num, payload):
+    return key(num, 2) + vint(len(payload)) + payload
+
+
+def tensor(name, arr, how="raw"):
+    code = {np.dtype(np.float32): 1, np.dtype(np.uint8): 2, np.dtype(np.int8): 3, np.dtype(np.float16): 10,
+            np.dtype(np.int64): 7}[arr.dtype]
+    out = b"".join(key(1, 0) + vint(d) for d in arr.shape) + key(2, 0) + vint(code)
+    if how == "raw":
+        out += ld(9, arr.astype(arr.dtype.newbyteorder("<")).tobytes())
+    elif how == "float_data":                       # packed repeated float
+        out += ld(4, arr.astype("<f4").tobytes())
+    elif how == "int32_data":                       # fp16 bit patterns / small ints, packed varints
+        vals = arr.view(np.uint16).ravel() if arr.dtype == np.float16 else arr.ravel()
+        out += ld(5, b"".join(vint(int(v)) for v in vals))
+    return out + ld(8, name.encode())
+
+
+def attr_i(name, v):
+    return ld(1, name.encode()) + key(3, 0) + vint(v) + key(20, 0) + vint(2)
+
+
+def node(op, name, inputs, outputs, attrs=()):
+    out = b"".join(ld(1, i.encode()) for i in inputs) + b"".join(ld(2, o.encode()) for o in outputs)
+    out += ld(3, name.encode()) + ld(4, op.encode())
+    return out + b"".join(ld(5, a) for a in attrs)
+
+
+def model(nodes, inits):
+    graph = b"".join(ld(1, n) for n in nodes) + ld(2, b"g") + b"".join(ld(5, t) for t in inits)
+    return key(1, 0) + vint(8) + ld(2, b"test") + ld(7, graph)
+
+
+def pack_nbits(w, bs, with_zp):
+    """block-wise 4-bit quantisation in MatMulNBits layout; returns (B, scales, zp_packed | None, dequantised)."""
+    N, K = w.shape
+    nb = K // bs
+    blocks = w.reshape(N, nb, bs)
+    if with_zp:
+        lo, hi = blocks.min(-1, keepdims=True), blocks.max(-1, keepdims=True)
+        scale = np.maximum((hi - lo) / 15.0, 1e-8).astype(np.float32)
+        zp = np.clip(np.rint(-lo / scale), 0, 15)
+    else:
+        scale = np.maximum(np.abs(blocks).max(-1, keepdims=True) / 7.0, 1e-8).astype(np.float32)
+        zp = np.full_like(scale, 8.0)
+    q = np.clip(np.rint(blocks / scale + zp), 0, 15).astype(np.uint8)
+    B = (q[:, :, 0::2] | (q[:, :, 1::2] << 4)).astype(np.uint8)
+    deq = ((q.astype(np.float32) - zp) * scale).reshape(N, K)
+    zpp = None
+    if with_zp:
+        z = zp.reshape(N, nb).astype(np.uint8)
+        if nb % 2:
+            z = np.concatenate([z, np.zeros((N, 1), np.uint8)], 1)
+        zpp = (z[:, 0::2] | (z[:, 1::2] << 4)).astype(np.uint8)
+    return B, scale.reshape(-1), zpp, deq
+
+
+def test_wire_primitives_and_tensor_encodings(tmp_path):
+    O = _load("onnx_reader")
+    a = np.arange(12, dtype=np.float32).reshape(3, 4) - 5
+    h = (np.arange(6, dtype=np.float32) / 4 - 1).astype(np.float16).reshape(2, 3)
+    i64 = np.array([-1, 2 ** 40, 7], np.int64)
+    p = tmp_path / "m.onnx"
+    p.write_bytes(model([], [tensor("a_raw", a), tensor("a_typed", a, "float_data"), tensor("h", h, "int32_data"),
+                             key(1, 0) + vint(3) + key(2, 0) + vint(7) +          # int64_data, packed varints
+                             ld(7, b"".join(vint(int(v)) for v in i64)) + ld(8, b"i64")]))
+    nodes, inits = O.read_model(p)
+    assert nodes == []
+    assert np.array_equal(inits["a_raw"], a) and np.array_equal(inits["a_typed"], a)
+    assert inits["h"].dtype == np.float16 and np.array_equal(inits["h"], h)
+    assert inits["i64"].tolist() == i64.tolist()
+
+
+def test_matmul_nbits_known_answer():
+    O = _load("onnx_reader")
+    q = np.arange(16, dtype=np.uint8)                        # element 2i in the low nibble
+    B = (q[0::2] | (q[1::2] << 4)).reshape(1, 1, 8)
+    n = O.Node(op="MatMulNBits", name="/x/MatMul_Q4", inputs=["a", "B", "s"], outputs=["y"],
+               attrs={"K": 16, "N": 1, "bits": 4, "block_size": 16})
+    w = O.dequant_matmul_nbits(n, {"B": B, "s": np.array([0.5], np.float32)})
+    assert np.array_equal(w, ((q.astype(np.float32) - 8) * 0.5).reshape(1, 16))   # default zero point 8
+
+
+def test_convert_weights_from_synthetic_onnx(tmp_path):
+    C = _load("convert_weights")
+    rng = np.random.default_rng(3)
+    D, FF, V = 32, 64, 11
+    L = "encoder.layers.0."
+    shapes = {
+        L + "feed_forward1.linear1.weight": (FF, D), L + "feed_forward1.linear1.bias": (FF,),
+        L + "feed_forward1.linear2.weight": (D, FF),
+        L + "self_attn.linear_pos.weight": (D, D),
+        L + "conv.pointwise_conv1.weight": (2 * D, D, 1),
+        L + "conv.depthwise_conv.weight": (D, 1, 9),
+        L + "conv.batch_norm.weight": (D,), L + "conv.batch_norm.bias": (D,),
+        L + "conv.batch_norm.running_mean": (D,), L + "conv.batch_norm.running_var": (D,),
+        L + "norm_out.weight": (D,), L + "norm_out.bias": (D,),
+        "ctc_decoder.decoder_layers.0.weight": (V, D, 1),
+    }
+    w1 = rng.normal(size=(FF, D)).astype(np.float32)
+    w2 = rng.normal(size=(D, FF)).astype(np.float32)
+    B1, s1, _, deq1 = pack_nbits(w1, 16, with_zp=False)
+    B2, s2, z2, deq2 = pack_nbits(w2, 32, with_zp=True)
+    b1 = rng.normal(size=FF).astype(np.float32)
+    wpos = rng.normal(size=(D, D)).astype(np.float32)                 # [out, in]; stored transposed for MatMul
+    pw1 = rng.normal(size=(2 * D, D, 1)).astype(np.float32)
+    pw_scale = np.float32(np.abs(pw1).max() / 127.0)
+    pw_q = np.clip(np.rint(pw1 / pw_scale) + 128, 0, 255).astype(np.uint8)
+    pw_deq = (pw_q.astype(np.float32) - 128.0) * pw_scale
+    dw = rng.normal(size=(D, 1, 9)).astype(np.float32)
+    g = (1 + 0.1 * rng.normal(size=D)).astype(np.float32)
+    g_scale = np.float32(np.abs(g).max() / 127.0)
+    g_q = np.clip(np.rint(g / g_scale), -127, 127).astype(np.int8)
+    beta = rng.normal(size=D).astype(np.float16)
+    head = rng.normal(size=(V, D, 1)).astype(np.float32)
+    nodes = [
+        node("MatMulNBits", "/encoder/layers.0/feed_forward1/linear1/MatMul_Q4", ["x", "onnx::MatMul_901_Q4", "onnx::MatMul_901_scales"],
+             ["y1"], [attr_i("K", D), attr_i("N", FF), attr_i("bits", 4), attr_i("block_size", 16)]),
+        node("MatMulNBits", "/encoder/layers.0/feed_forward1/linear2/MatMul_Q4",
+             ["y1", "onnx::MatMul_902_Q4", "onnx::MatMul_902_scales", "onnx::MatMul_902_zero_points"], ["y2"],
+             [attr_i("K", FF), attr_i("N", D), attr_i("bits", 4), attr_i("block_size", 32)]),
+        node("MatMul", "/layers.0/self_attn/linear_pos/MatMul", ["pos", "onnx::MatMul_903"], ["p"]),   # scope without "encoder."
+        node("ConvInteger", "/encoder/layers.0/conv/pointwise_conv1/Conv_quant",
+             ["xq", L + "conv.pointwise_conv1.weight_quantized", "x_zp", L + "conv.pointwise_conv1.weight_zero_point"], ["c"]),
+        node("DequantizeLinear", "/encoder/layers.0/norm_out/dq", [L + "norm_out.weight_quantized", "g_scale", "g_zp"],
+             [L + "norm_out.weight_dq"]),
+    ]
+    inits = [
+        tensor("onnx::MatMul_901_Q4", B1), tensor("onnx::MatMul_901_scales", s1),
+        tensor("onnx::MatMul_902_Q4", B2), tensor("onnx::MatMul_902_scales", s2), tensor("onnx::MatMul_902_zero_points", z2),
+        tensor(L + "feed_forward1.linear1.bias", b1, "float_data"),
+        tensor("onnx::MatMul_903", np.ascontiguousarray(wpos.T)),
+        tensor(L + "conv.pointwise_conv1.weight_quantized", pw_q), tensor(L + "conv.pointwise_conv1.weight_scale", np.array(pw_scale)),
+        tensor(L + "conv.pointwise_conv1.weight_zero_point", np.array(128, np.uint8)),
+        tensor(L + "conv.depthwise_conv.weight", dw),
+        tensor(L + "norm_out.weight_quantized", g_q), tensor("g_scale", np.array(g_scale)), tensor("g_zp", np.array(0, np.int8)),
+        tensor(L + "norm_out.bias", beta, "int32_data"),
+        tensor("ctc_decoder.decoder_layers.0.weight", head),
+    ]
+    p = tmp_path / "synthetic.onnx"
+    p.write_bytes(model(nodes, inits))
+    sd = C.onnx_state_dict(str(p), shapes, verbose=False)
+    assert set(sd) == set(shapes)
+    assert np.array_equal(sd[L + "feed_forward1.linear1.weight"], deq1)
+    assert np.array_equal(sd[L + "feed_forward1.linear2.weight"], deq2)
+    assert np.abs(deq2 - w2).max() < 0.25 and np.abs(deq1 - w1).max() < 0.5      # the synthetic quantiser is sane
+    assert np.array_equal(sd[L + "feed_forward1.linear1.bias"], b1)
+    assert np.array_equal(sd[L + "self_attn.linear_pos.weight"], wpos)           # MatMul operand transposed back
+    assert np.array_equal(sd[L + "conv.pointwise_conv1.weight"], pw_deq)
+    assert np.array_equal(sd[L + "conv.depthwise_conv.weight"], dw)
+    assert np.array_equal(sd[L + "norm_out.weight"], g_q.astype(np.float32) * g_scale)
+    assert np.array_equal(sd[L + "norm_out.bias"], beta.astype(np.float32))
+    assert np.array_equal(sd["ctc_decoder.decoder_layers.0.weight"], head)
+    # BatchNorm absent from the graph -> identity: (x - 0) / sqrt(var + 1e-5) * 1 + 0 == x
+    assert np.all(sd[L + "conv.batch_norm.weight"] == 1) and np.all(sd[L + "conv.batch_norm.running_mean"] == 0)
+    assert np.allclose(sd[L + "conv.batch_norm.running_var"] + 1e-5, 1.0)
+    # and the flat file the engine loads
+    out = tmp_path / "w.qvw"
+    C.write_qvw(out, {k: sd[k] for k in shapes})
+    raw = out.read_bytes()
+    assert raw[:8] == b"QVWT0001" and struct.unpack("<I", raw[8:12])[0] == len(shapes)
+    # a tensor the graph does not hold is reported, not guessed
+    import pytest
+
+    with pytest.raises(SystemExit):
+        C.onnx_state_dict(str(p), dict(shapes, **{L + "self_attn.linear_q.weight": (D, D)}), verbose=False)

@@ -11,10 +11,20 @@ ctc_decoder.decoder_layers.0.*), the same the engine's seeded init uses
 (csrc/qv_model.hip::weight_shapes).  A ``.nemo`` file is a tar archive holding
 ``model_weights.ckpt`` (a torch state dict), readable without NeMo.
 
-The mixed int4/int8 ONNX (fastconformer_full_mixed.onnx, MatMulNBits + dynamic-int8 Conv) is
-NOT handled yet: it needs a protobuf reader and block dequantisation (next round; the fp16 path
-then reproduces the *dequantised* weights, while ORT's dynamic activation quantisation for Conv
-stays a documented numerical difference).
+    python tools/convert_weights.py --onnx fastconformer_full_mixed.onnx --list          # what the file holds
+    python tools/convert_weights.py --onnx fastconformer_full_mixed.onnx --out fc.qvw [--map names.json]
+
+``--onnx`` reads the reference's own weight format without onnx/onnxruntime (tools/onnx_reader.py):
+MatMulNBits int4 blocks, DequantizeLinear'ed and ConvInteger/MatMulInteger int8 tensors are
+dequantised to float32 (the engine then stores them as fp16, or re-quantises the Linear layers to
+its own block-128 int4 with ``precision=1``); ORT's dynamic activation quantisation of the Conv
+nodes stays a documented numerical difference.  Tensors are matched to the NeMo state-dict keys by
+initializer name, else by the scope of the node that consumes them
+("/encoder/layers.0/feed_forward1/linear1/MatMul" -> encoder.layers.0.feed_forward1.linear1.weight);
+``--map`` ({"nemo key": "onnx key"}) overrides, ``--list`` prints every candidate with its shape.
+A BatchNorm that the exporter folded into the depthwise convolution is written as the identity.
+The real file is absent from the build container: the reader is tested on synthetic models only
+(tests/test_onnx_reader.py), and the name matching reports anything it cannot place.
 """
 
 from __future__ import annotations
@@ -56,16 +66,97 @@ def load_state_dict(args):
     return torch.load(args.state_dict, map_location="cpu", weights_only=True)
 
 
+def _fit(arr: np.ndarray, shape):
+    """arr as `shape` if it is that tensor up to singleton dimensions, else None."""
+    if tuple(arr.shape) == tuple(shape):
+        return arr
+    squeeze = lambda s: tuple(d for d in s if d != 1)  # noqa: E731
+    if arr.size == int(np.prod(shape)) and squeeze(arr.shape) == squeeze(shape):
+        return arr.reshape(shape)
+    return None
+
+
+def onnx_state_dict(path, shapes: dict, name_map: dict | None = None, verbose: bool = True) -> dict:
+    """NeMo-keyed float32 tensors from an ONNX file (see the module docstring)."""
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import onnx_reader as O
+
+    nodes, inits = O.read_model(path)
+    fw = O.float_weights(nodes, inits)
+    name_map = name_map or {}
+    out, missing = {}, []
+    for name, shape in shapes.items():
+        cands = []
+        if name in name_map:
+            cands.append(name_map[name])
+        cands.append(name)
+        module = name.rsplit(".", 1)[0]
+        if name.endswith(".weight"):
+            cands.append(module)
+            # scopes may lack or carry extra leading components ("layers.0..." / "model.encoder.layers.0...")
+            tail = [k for k in fw if not k.endswith((".weight", ".bias")) and
+                    (k.endswith("." + module) or module.endswith("." + k)) and _fit(fw[k][0], shape) is not None]
+            if len(tail) == 1:
+                cands.append(tail[0])
+        got = None
+        for c in cands:
+            if c in fw:
+                got = _fit(fw[c][0], shape)
+                if got is not None:
+                    break
+        if got is None:
+            missing.append(name)
+        else:
+            out[name] = got
+    # BatchNorm folded into the depthwise convolution by the exporter: identity statistics
+    for name in list(missing):
+        if ".conv.batch_norm." in name:
+            kind = name.rsplit(".", 1)[1]
+            out[name] = np.full(shapes[name], {"weight": 1.0, "bias": 0.0, "running_mean": 0.0,
+                                               "running_var": 1.0 - 1e-5}[kind], np.float32)
+            missing.remove(name)
+            if verbose and kind == "weight":
+                print(f"note: {name.rsplit('.', 1)[0]} not in the graph (folded by the exporter): identity")
+    if missing:
+        raise SystemExit("cannot place these tensors (use --list and --map):\n  " + "\n  ".join(missing[:40]) +
+                         (f"\n  ... and {len(missing) - 40} more" if len(missing) > 40 else ""))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nemo")
     ap.add_argument("--state-dict")
+    ap.add_argument("--onnx")
+    ap.add_argument("--map", help="JSON {nemo key: onnx key} overrides for --onnx")
+    ap.add_argument("--list", action="store_true", help="with --onnx: print the weight candidates and exit")
     ap.add_argument("--random", type=int)
-    ap.add_argument("--out", required=True)
+    ap.add_argument("--out")
     args = ap.parse_args()
     from oracle import fastconformer_ref as R  # shapes + seeded init only (build-time tool)
 
     shapes = R.weight_shapes()
+    if args.onnx and args.list:
+        sys.path.insert(0, str(Path(__file__).resolve().parent))
+        import onnx_reader as O
+
+        nodes, inits = O.read_model(args.onnx)
+        for k, (a, how) in sorted(O.float_weights(nodes, inits).items()):
+            print(f"{k}  {tuple(a.shape)}  [{how}]")
+        ops = {}
+        for n in nodes:
+            ops[n.op] = ops.get(n.op, 0) + 1
+        print("node types:", dict(sorted(ops.items())))
+        return
+    if not args.out:
+        raise SystemExit("--out is required")
+    if args.onnx:
+        import json
+
+        sd_np = onnx_state_dict(args.onnx, shapes, json.loads(Path(args.map).read_text()) if args.map else None)
+        write_qvw(args.out, {k: sd_np[k] for k in shapes})
+        print(f"wrote {args.out}: {len(shapes)} tensors from {args.onnx}")
+        return
     if args.random is not None:
         sd = R.random_weights(args.random)
     else:
