@@ -294,6 +294,18 @@ def test_fused_subsampling_equals_two_kernel_path(setup, monkeypatch):
         eng.close()
 
 
+def test_specialised_attention_equals_one_wave_per_tile_kernel(setup, monkeypatch):
+    """k_attention_ws (loader / consumer waves, K, V^T and the relative-position ring staged in LDS)
+    against the plain one-wave-per-query-tile kernel (QVERSE_ATT_OLD=1): bit-identical log-probs."""
+    monkeypatch.setenv("QVERSE_ATT_OLD", "1")
+    eng = setup["eng"]
+    lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
+    torch.cuda.synchronize()
+    assert t == setup["t"]
+    for i, n in enumerate(t):
+        assert torch.equal(lp[i, :n], setup["lp"][i, :n])
+
+
 def test_tiny_and_long_utterances_share_a_packed_batch(setup):
     """shortest legal clip (400 samples -> 1 encoder frame) next to long ones: packed rows of very
     different lengths, reference parity on every valid frame and exact batch invariance."""
