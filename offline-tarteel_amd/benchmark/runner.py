@@ -12,8 +12,11 @@
 
 ``--batch N`` (not in the reference) sends N files per engine call through the plugin's
 predict_batch; per-sample latency is then the call time divided by N.
-Only predict()-style plugins are supported: the transcribe()+StreamingPipeline fallback and
---mode streaming belong to other experiments and are refused.
+``--mode`` / ``--chunk`` follow the reference (runner.py:250,309-321,350-351,419): an experiment
+that exports predict() is run through it in both modes (streaming only changes the result label
+and records chunk_seconds); a transcribe()-only experiment goes through StreamingPipeline --
+run_on_audio_chunked in streaming mode, run_on_full_transcript otherwise -- with the MI355X
+verse tracker / match_verse underneath (offline-tarteel_amd/streaming.py).
 """
 
 from __future__ import annotations
@@ -87,22 +90,28 @@ def discover_experiments(name: str | None) -> list[dict]:
             for n in names if n in EXPERIMENT_REGISTRY]
 
 
-def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int = 1) -> dict | None:
+def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int = 1, mode: str = "full",
+                   chunk_seconds: float = 3.0, pipeline=None) -> dict | None:
     mod = load_module(exp["name"].replace("/", "_").replace("-", "_"), exp["run_path"])
-    if not hasattr(mod, "predict"):
-        print(f"  Skipping {exp['name']} -- no predict() function")
+    use_predict = hasattr(mod, "predict")
+    if not use_predict and not hasattr(mod, "transcribe"):
+        print(f"  Skipping {exp['name']} -- no predict() or transcribe() function")
         return None
+    if not use_predict and pipeline is None:
+        from ..streaming import StreamingPipeline
+
+        pipeline = StreamingPipeline()
     present = [s for s in samples if (corpus_dir / s["file"]).exists()]
     if present:  # warm-up on the first sample; failure is only reported
         try:
-            mod.predict(str(corpus_dir / present[0]["file"]))
+            (mod.predict if use_predict else mod.transcribe)(str(corpus_dir / present[0]["file"]))
         except Exception as e:
             print(f"  Warmup failed for {exp['name']}: {e}")
     try:
         size = mod.model_size()
     except Exception:
         size = 0
-    use_batch = batch > 1 and hasattr(mod, "predict_batch")
+    use_batch = use_predict and batch > 1 and hasattr(mod, "predict_batch")
     per_sample, latencies = [], []
     tot = {"recall": 0.0, "precision": 0.0, "sequence_accuracy": 0.0}
     for s0 in range(0, len(present), batch if use_batch else 1):
@@ -110,9 +119,14 @@ def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int 
         paths = [str(corpus_dir / s["file"]) for s in group]
         try:
             t0 = time.perf_counter()
-            results = mod.predict_batch(paths) if use_batch else [mod.predict(paths[0])]
+            if use_predict:
+                results = mod.predict_batch(paths) if use_batch else [mod.predict(paths[0])]
+                emissions = [predict_to_emissions(r) for r in results]
+            elif mode == "streaming":
+                emissions = [pipeline.run_on_audio_chunked(paths[0], mod.transcribe, chunk_seconds=chunk_seconds)]
+            else:
+                emissions = [pipeline.run_on_full_transcript(paths[0], mod.transcribe)]
             elapsed = (time.perf_counter() - t0) / len(group)
-            emissions = [predict_to_emissions(r) for r in results]
         except Exception as e:
             print(f"  Error on {[s['id'] for s in group]}: {e}")
             emissions, elapsed = [[] for _ in group], 0.0
@@ -125,7 +139,7 @@ def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int 
             per_sample.append({"id": sample["id"], "expected": expected, "predicted": em, **sc, "latency": elapsed})
     n = len(per_sample)
     return {
-        "name": exp["name"],
+        "name": exp["name"] if mode == "full" else f"{exp['name']} (stream {chunk_seconds:.0f}s)",
         "recall": tot["recall"] / n if n else 0, "precision": tot["precision"] / n if n else 0,
         "sequence_accuracy": tot["sequence_accuracy"] / n if n else 0,
         "total": n, "avg_latency": sum(latencies) / n if n else 0, "model_size": size, "per_sample": per_sample,
@@ -143,7 +157,7 @@ def print_table(results: list[dict]):
 
 
 def save_results(results: list[dict], *, mode: str = "full", category: str | None = None,
-                 results_dir: Path | None = None) -> Path:
+                 results_dir: Path | None = None, chunk_seconds: float = 3.0) -> Path:
     out_dir = Path(results_dir or RESULTS_DIR)
     out_dir.mkdir(parents=True, exist_ok=True)
     stamp = datetime.now().strftime("%Y-%m-%d_%H%M%S")
@@ -156,8 +170,9 @@ def save_results(results: list[dict], *, mode: str = "full", category: str | Non
             latest[(e.get("name"), e.get("mode", "full"), e.get("category"), e.get("total"), e.get("chunk_seconds"))] = e
     for r in results:
         summary = {k: r[k] for k in ("name", "recall", "precision", "sequence_accuracy", "total", "avg_latency", "model_size")}
-        summary.update(timestamp=stamp, mode=mode, category=category, chunk_seconds=None, source_file=path.name)
-        key = (summary["name"], mode, category, summary["total"], None)
+        chunk = chunk_seconds if mode == "streaming" else None
+        summary.update(timestamp=stamp, mode=mode, category=category, chunk_seconds=chunk, source_file=path.name)
+        key = (summary["name"], mode, category, summary["total"], chunk)
         prev = latest.get(key)
         better = prev is None or r["sequence_accuracy"] > prev.get("sequence_accuracy", 0) or (
             r["sequence_accuracy"] == prev.get("sequence_accuracy", 0)
@@ -180,8 +195,6 @@ def main(argv=None):
     ap.add_argument("--corpus", type=str, default=str(DEFAULT_CORPUS), help="directory holding manifest.json + audio")
     ap.add_argument("--batch", type=int, default=1, help="files per engine call (uses predict_batch)")
     args = ap.parse_args(argv)
-    if args.mode != "full":
-        raise SystemExit("--mode streaming drives transcribe()-only experiments; c2c plugins expose predict()")
     corpus = Path(args.corpus)
     samples = load_manifest(corpus)
     if args.category:
@@ -191,17 +204,18 @@ def main(argv=None):
     if not experiments:
         print(f"No experiments found matching '{args.experiment}'")
         return []
-    print(f"Running {len(experiments)} experiment(s) on {len(samples)} sample(s) [full transcript]...")
+    label = "full transcript" if args.mode == "full" else f"streaming {args.chunk:g}s chunks"
+    print(f"Running {len(experiments)} experiment(s) on {len(samples)} sample(s) [{label}]...")
     results = []
     for exp in experiments:
         print(f"\n>>> {exp['name']}")
-        r = run_experiment(exp, samples, corpus, batch=args.batch)
+        r = run_experiment(exp, samples, corpus, batch=args.batch, mode=args.mode, chunk_seconds=args.chunk)
         if r is None:
             continue
         results.append(r)
         print(f"    Recall: {r['recall']:.0%}  Precision: {r['precision']:.0%}  SeqAcc: {r['sequence_accuracy']:.0%}")
     print_table(results)
-    save_results(results, mode=args.mode, category=args.category)
+    save_results(results, mode=args.mode, category=args.category, chunk_seconds=args.chunk)
     return results
 
 

@@ -68,6 +68,40 @@ def test_runner_records_empty_prediction_on_plugin_error(tmp_path, monkeypatch):
     assert latest[0]["name"] == "c2c-direct-mixed" and latest[0]["source_file"] == p.name
 
 
+def test_runner_transcribe_only_experiment_both_modes(tmp_path, oracle):
+    """An experiment without predict() goes through StreamingPipeline, as in the reference's runner
+    (runner.py:309-321): chunked in streaming mode, run_on_full_transcript otherwise; the mode shows
+    in the result name and in latest.json's chunk_seconds.  The matching steps are the CPU oracle's
+    here (host logic only; the HIP steps are checked in tests/test_gpu_tracker.py)."""
+    from offline_tarteel_amd.benchmark import runner
+    from offline_tarteel_amd.streaming import StreamingPipeline
+    from oracle.tracker_ref import MatchVerseOracle, TrackerOracle
+    from test_oracle_tracker import oracle_matcher
+
+    text = oracle.verse_text(oracle.verse_index(112, 1))
+    corpus = tmp_path / "corpus"
+    corpus.mkdir()
+    _write_wav(corpus / "x.wav", np.zeros(48000, np.int16), 16000)
+    (corpus / "manifest.json").write_text(json.dumps({"samples": [
+        {"id": "s", "file": "x.wav", "surah": 112, "ayah": 1, "category": "short"}]}))
+    plug = tmp_path / "run.py"
+    plug.write_text(f"def transcribe(audio_path):\n    return {text!r}\n\ndef model_size():\n    return 7\n", encoding="utf-8")
+    mv = MatchVerseOracle(oracle)
+    pipe = StreamingPipeline(matcher=oracle_matcher(TrackerOracle(oracle)),
+                             match_verse_fn=lambda t, max_span, hint: mv.match_verse(t, max_span=max_span, hint=hint))
+    exp = {"name": "mock-asr", "run_path": plug, "model_name": None}
+    samples = runner.load_manifest(corpus)
+    full = runner.run_experiment(exp, samples, corpus, pipeline=pipe)
+    assert full["name"] == "mock-asr" and full["model_size"] == 7
+    assert [(e["surah"], e["ayah"]) for e in full["per_sample"][0]["predicted"]] == [(112, 1)] and full["recall"] == 1.0
+    st = runner.run_experiment(exp, samples, corpus, mode="streaming", chunk_seconds=3.0, pipeline=pipe)
+    assert st["name"] == "mock-asr (stream 3s)"
+    assert [(e["surah"], e["ayah"]) for e in st["per_sample"][0]["predicted"]] == [(112, 1)]
+    runner.save_results([st], mode="streaming", results_dir=tmp_path / "results", chunk_seconds=3.0)
+    latest = json.loads((tmp_path / "results" / "latest.json").read_text())
+    assert latest[0]["mode"] == "streaming" and latest[0]["chunk_seconds"] == 3.0
+
+
 def _write_wav(path, pcm16, sr, channels=1):
     data = pcm16.astype("<i2").tobytes()
     hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack(
