@@ -253,6 +253,14 @@ int qv_profile_replay_gemm(qv_engine *e, int32_t which, int32_t iters, double *a
  * the parity tests compare it with the oracle's quantiser. */
 int qv_debug_int4_roundtrip(const float *w, int32_t n_rows, int32_t k, float *out);
 
+/* Host-only (no GPU needed): the float32 tensors a weight file must hold, in file order -- names are
+ * the NeMo state-dict keys of the CTC branch -- and tensor `index` of the seeded synthetic
+ * initialisation an engine created with weights_path == NULL uses.  tools/convert_weights.py is
+ * written against these, so the converter and the engine cannot disagree about names or shapes. */
+int32_t qv_weight_count(void);
+int qv_weight_spec(int32_t index, char *name_out, int32_t name_cap, int32_t *dims4_out, int32_t *ndim_out);
+int qv_weight_random(uint64_t seed, int32_t index, float *out, int64_t numel);
+
 /* Library build info: "gfx950;hip-x.y;..." */
 const char *qv_build_info(void);
 

@@ -80,36 +80,41 @@ bool ends_with(const std::string &s, const char *suf) {
 
 // seeded init: integer hash -> Irwin-Hall(4 bytes) -> affine; exact in f32 and mirrored by
 // oracle/fastconformer_ref.py::random_weights
+void random_tensor(const Shape &sh, uint64_t seed, std::vector<float> &v) {
+    size_t n = 1;
+    for (int d : sh.dims) n *= (size_t)d;
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (unsigned char c : sh.name) h = (h ^ c) * 0x100000001B3ull;
+    uint64_t key = h ^ (seed * 0x9E3779B97F4A7C15ull);
+    float off = 0.f, sc = 0.f;
+    bool ab = false;
+    const std::string &nm = sh.name;
+    if (ends_with(nm, "running_var")) { off = 1.f; sc = 0.1f; ab = true; }
+    else if (ends_with(nm, "running_mean")) { off = 0.f; sc = 0.1f; }
+    else if (nm.find(".norm_") != std::string::npos || nm.find("batch_norm") != std::string::npos) {
+        if (ends_with(nm, "weight")) { off = 1.f; sc = 0.1f; } else { off = 0.f; sc = 0.1f; }
+    } else if (ends_with(nm, "bias") || nm.find("pos_bias") != std::string::npos) { off = 0.f; sc = 0.1f; }
+    else { size_t fan_in = n / (size_t)sh.dims[0]; sc = 1.0f / sqrtf((float)fan_in); }
+    v.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t x = (uint64_t)i + key + 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        int s4 = (int)(z & 0xFF) + (int)((z >> 8) & 0xFF) + (int)((z >> 16) & 0xFF) + (int)((z >> 24) & 0xFF) - 510;
+        float zn = (float)s4 * (1.0f / 147.8f);
+        if (ab) zn = fabsf(zn);
+        float prod = sc * zn;
+        v[i] = off + prod;
+    }
+}
+
 void init_random(HostWeights &hw, uint64_t seed) {
     for (const Shape &sh : weight_shapes()) {
-        size_t n = 1;
-        for (int d : sh.dims) n *= (size_t)d;
-        uint64_t h = 0xCBF29CE484222325ull;
-        for (unsigned char c : sh.name) h = (h ^ c) * 0x100000001B3ull;
-        uint64_t key = h ^ (seed * 0x9E3779B97F4A7C15ull);
-        float off = 0.f, sc = 0.f;
-        bool ab = false;
-        const std::string &nm = sh.name;
-        if (ends_with(nm, "running_var")) { off = 1.f; sc = 0.1f; ab = true; }
-        else if (ends_with(nm, "running_mean")) { off = 0.f; sc = 0.1f; }
-        else if (nm.find(".norm_") != std::string::npos || nm.find("batch_norm") != std::string::npos) {
-            if (ends_with(nm, "weight")) { off = 1.f; sc = 0.1f; } else { off = 0.f; sc = 0.1f; }
-        } else if (ends_with(nm, "bias") || nm.find("pos_bias") != std::string::npos) { off = 0.f; sc = 0.1f; }
-        else { size_t fan_in = n / (size_t)sh.dims[0]; sc = 1.0f / sqrtf((float)fan_in); }
-        std::vector<float> v(n);
-        for (size_t i = 0; i < n; ++i) {
-            uint64_t x = (uint64_t)i + key + 0x9E3779B97F4A7C15ull;
-            uint64_t z = x;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-            z = z ^ (z >> 31);
-            int s4 = (int)(z & 0xFF) + (int)((z >> 8) & 0xFF) + (int)((z >> 16) & 0xFF) + (int)((z >> 24) & 0xFF) - 510;
-            float zn = (float)s4 * (1.0f / 147.8f);
-            if (ab) zn = fabsf(zn);
-            float prod = sc * zn;
-            v[i] = off + prod;
-        }
-        hw.t[nm] = std::move(v);
+        std::vector<float> v;
+        random_tensor(sh, seed, v);
+        hw.t[sh.name] = std::move(v);
     }
 }
 
@@ -161,6 +166,30 @@ struct LayerW {
 };
 
 }  // namespace
+
+// ---- host-only C ABI: what the weight file must hold (tools/convert_weights.py) ----------
+extern "C" int32_t qv_weight_count(void) { return (int32_t)weight_shapes().size(); }
+
+extern "C" int qv_weight_spec(int32_t index, char *name_out, int32_t name_cap, int32_t *dims4_out, int32_t *ndim_out) {
+    static const std::vector<Shape> shapes = weight_shapes();
+    if (index < 0 || index >= (int32_t)shapes.size() || !name_out || !dims4_out || !ndim_out) return QV_ERR_ARG;
+    const Shape &sh = shapes[index];
+    if ((int32_t)sh.name.size() + 1 > name_cap || sh.dims.size() > 4) return QV_ERR_CAPACITY;
+    memcpy(name_out, sh.name.c_str(), sh.name.size() + 1);
+    *ndim_out = (int32_t)sh.dims.size();
+    for (int k = 0; k < 4; ++k) dims4_out[k] = k < (int)sh.dims.size() ? sh.dims[k] : 1;
+    return QV_OK;
+}
+
+extern "C" int qv_weight_random(uint64_t seed, int32_t index, float *out, int64_t numel) {
+    static const std::vector<Shape> shapes = weight_shapes();
+    if (index < 0 || index >= (int32_t)shapes.size() || !out) return QV_ERR_ARG;
+    std::vector<float> v;
+    random_tensor(shapes[index], seed, v);
+    if ((int64_t)v.size() != numel) return QV_ERR_ARG;
+    memcpy(out, v.data(), sizeof(float) * v.size());
+    return QV_OK;
+}
 
 // per-context state: the activations of one batch in flight
 struct QvActs {

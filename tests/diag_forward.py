@@ -1,4 +1,5 @@
-"""GPU diagnostic: HIP forward vs the fp32 PyTorch restatement, stage by stage."""
+"""GPU diagnostic (not collected by pytest): HIP forward vs the fp32 PyTorch restatement, stage by
+stage.  Lives under tests/ because it uses the oracle.    python tests/diag_forward.py"""
 import os, sys, time
 os.environ["QVERSE_DEBUG_TAPS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

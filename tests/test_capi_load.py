@@ -81,3 +81,28 @@ def test_product_never_imports_oracle():
         assert not py_import.search(p.read_text(encoding="utf-8", errors="ignore")), p
     for p in list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
         assert not c_use.search(p.read_text(encoding="utf-8", errors="ignore")), p
+
+
+def test_weight_spec_and_seeded_init_match_the_oracle_mirror():
+    """Host-only entry points (no GPU): the tensors a weight file must hold, and the engine's seeded
+    synthetic initialisation, against oracle/fastconformer_ref.py (what the GPU parity tests feed the
+    fp32 reference with).  tools/convert_weights.py is written against these entry points."""
+    import importlib.util
+    from pathlib import Path
+
+    import numpy as np
+
+    from oracle import fastconformer_ref as R
+
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("convert_weights", str(root / "tools" / "convert_weights.py"))
+    cw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cw)
+    lib = cw._lib()
+    shapes = cw.weight_shapes(lib)
+    ref = R.weight_shapes()
+    assert list(shapes) == list(ref)
+    assert all(tuple(shapes[k]) == tuple(ref[k]) for k in ref)
+    mine, theirs = cw.random_weights(lib, shapes, 20260630), R.random_weights(20260630)
+    for k in list(shapes)[:40] + list(shapes)[-8:]:
+        assert np.array_equal(mine[k], theirs[k].numpy()), k

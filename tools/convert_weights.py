@@ -8,7 +8,7 @@
 File format ("QVWT0001"): u32 tensor count, then per tensor {u32 name_len, name, u32 numel,
 float32 data}; names are the NeMo state-dict keys of the CTC branch (encoder.*,
 ctc_decoder.decoder_layers.0.*), the same the engine's seeded init uses
-(csrc/qv_model.hip::weight_shapes).  A ``.nemo`` file is a tar archive holding
+(csrc/qv_model.hip::weight_shapes, read through the library's host-only qv_weight_spec).  A ``.nemo`` file is a tar archive holding
 ``model_weights.ckpt`` (a torch state dict), readable without NeMo.
 
     python tools/convert_weights.py --onnx fastconformer_full_mixed.onnx --list          # what the file holds
@@ -64,6 +64,43 @@ def load_state_dict(args):
             buf = io.BytesIO(tar.extractfile(member).read())
         return torch.load(buf, map_location="cpu", weights_only=True)
     return torch.load(args.state_dict, map_location="cpu", weights_only=True)
+
+
+def _lib():
+    """libqverse.so for its host-only weight-spec entry points (loads without a GPU)."""
+    import ctypes as C
+
+    path = ROOT / "offline-tarteel_amd" / "libqverse.so"
+    if not path.exists():
+        raise SystemExit(f"{path} not found: build it with `python offline-tarteel_amd/build.py`")
+    lib = C.CDLL(str(path))
+    lib.qv_weight_spec.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.qv_weight_random.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.c_int64]
+    return lib
+
+
+def weight_shapes(lib) -> dict:
+    """{NeMo key: shape} in file order, as the engine defines them (qv_weight_spec)."""
+    import ctypes as C
+
+    out = {}
+    for i in range(lib.qv_weight_count()):
+        name = C.create_string_buffer(256)
+        dims, nd = (C.c_int32 * 4)(), C.c_int32()
+        if lib.qv_weight_spec(i, name, 256, dims, C.byref(nd)):
+            raise SystemExit(f"qv_weight_spec({i}) failed")
+        out[name.value.decode()] = tuple(dims[: nd.value])
+    return out
+
+
+def random_weights(lib, shapes: dict, seed: int) -> dict:
+    out = {}
+    for i, (name, shape) in enumerate(shapes.items()):
+        a = np.empty(int(np.prod(shape)), np.float32)
+        if lib.qv_weight_random(seed, i, a.ctypes.data, a.size):
+            raise SystemExit(f"qv_weight_random({name}) failed")
+        out[name] = a.reshape(shape)
+    return out
 
 
 def _fit(arr: np.ndarray, shape):
@@ -133,9 +170,8 @@ def main():
     ap.add_argument("--random", type=int)
     ap.add_argument("--out")
     args = ap.parse_args()
-    from oracle import fastconformer_ref as R  # shapes + seeded init only (build-time tool)
-
-    shapes = R.weight_shapes()
+    lib = _lib()
+    shapes = weight_shapes(lib)
     if args.onnx and args.list:
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         import onnx_reader as O
@@ -158,11 +194,12 @@ def main():
         print(f"wrote {args.out}: {len(shapes)} tensors from {args.onnx}")
         return
     if args.random is not None:
-        sd = R.random_weights(args.random)
-    else:
-        sd = load_state_dict(args)
-        if "state_dict" in sd:
-            sd = sd["state_dict"]
+        write_qvw(args.out, random_weights(lib, shapes, args.random))
+        print(f"wrote {args.out}: {len(shapes)} seeded synthetic tensors (seed {args.random})")
+        return
+    sd = load_state_dict(args)
+    if "state_dict" in sd:
+        sd = sd["state_dict"]
     out = {}
     for name, shape in shapes.items():
         if name not in sd:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Streaming row: cost of the verse tracker's matching step (qv_tracker_match) per accumulated
-text, against the CPU oracle's restatement of the reference loop on the host.
+text.  With --cpu-texts > 0 the CPU oracle's restatement of the reference loop is timed next to it
+on the host (a reported baseline, like bench.py's cpu_baseline leg -- never part of the product path).
 
     python tools/tracker_bench.py [--steps 20] [--cpu-texts 8]
 """
