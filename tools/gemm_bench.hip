@@ -73,6 +73,17 @@ int main(int argc, char **argv) {
                 maxerr = fmax(maxerr, fabs(want - ho[(size_t)r * sh.ldo + c]));
             }
         }
+        if (sh.epi == EPI_F16_SWISH) {
+            std::vector<half_t> ho((size_t)M * sh.ldo);
+            CK(hipMemcpy(ho.data(), dO, ho.size() * 2, hipMemcpyDeviceToHost));
+            for (int t = 0; t < 256; ++t) {
+                int r = (t * 977) % M, c = (t * 131) % sh.N;
+                double acc = 0;
+                for (int k = 0; k < sh.K; ++k) acc += (double)(float)hA[(size_t)r * sh.K + k] * (double)(float)hW[(size_t)c * sh.K + k];
+                double x = acc + hb[c], want = x / (1.0 + exp(-x));
+                maxerr = fmax(maxerr, fabs(want - (double)(float)ho[(size_t)r * sh.ldo + c]));
+            }
+        }
         for (int i = 0; i < 3; ++i) launch_gemm(sh.epi, g, 0);
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; ++i) launch_gemm(sh.epi, g, 0);
