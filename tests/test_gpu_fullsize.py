@@ -70,3 +70,23 @@ def test_verse_round_trip_at_batch_64():
             assert r["source"] == "text" and r["score"] >= 0.8
     finally:
         eng.close()
+
+
+def test_int4_batch_256_is_batch_size_invariant():
+    """BASELINE.json configs[2] (int4 Linear weights, 256 clips per call): the result of an utterance
+    is the same bits whether it travels in a batch of 256 or of 64, and a repeated call is identical."""
+    from offline_tarteel_amd.engine import Engine
+
+    Bq = 256
+    eng = Engine(device=0, with_model=True, seed=20260630, precision=1, max_batch=Bq, max_samples=N)
+    try:
+        base = torch.from_numpy(synth_audio(64, N)).cuda()
+        audio = torch.cat([base * (1.0 - 0.01 * k) for k in range(4)], 0).contiguous()     # 256 distinct clips
+        lens = [N] * Bq
+        big = [key(r) for r in eng.predict_batch(audio, lens, want_text=False)]
+        assert [key(r) for r in eng.predict_batch(audio, lens, want_text=False)] == big
+        for k in (0, 3):
+            part = eng.predict_batch(audio[64 * k: 64 * (k + 1)].contiguous(), [N] * 64, want_text=False)
+            assert [key(r) for r in part] == big[64 * k: 64 * (k + 1)]
+    finally:
+        eng.close()
