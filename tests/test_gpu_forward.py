@@ -273,6 +273,18 @@ def test_batches_in_flight_equal_one_at_a_time(setup):
             assert pk[:, 0].tolist() == [r["surah"] for r in want[4]]
         # the synchronous entry point still works with contexts > 1
         assert eng.predict_batch(audio, LENS, want_text=False) == want[0]
+        # the streaming row's entry points next to batches in flight: the tracker has its own workspace
+        # (no interference either way); match_verse waits for the internal streams and then borrows the
+        # current context's workspace, so it is called after that context's batch has been fetched
+        verse = "قل هو الله احد"
+        alone = setup["eng"].track_match([verse] * 3, [None, (112, 1), None])
+        tickets = [eng.predict_batch_async(a, l) for a, l in batches[:3]]
+        assert eng.track_match([verse] * 3, [None, (112, 1), None]) == alone
+        got = [eng.fetch_results(t, a.shape[0], eng.frames_for(max(l))) for t, (a, l) in zip(tickets, batches[:3])]
+        assert got == want[:3]
+        mv = eng.match_verse(verse, max_span=8)
+        assert mv == setup["eng"].match_verse(verse, max_span=8) and (mv["surah"], mv["ayah"]) == (112, 1)
+        assert eng.predict_batch(audio, LENS, want_text=False) == want[0]
     finally:
         eng.close()
 
