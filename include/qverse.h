@@ -252,6 +252,9 @@ int qv_profile_replay_gemm(qv_engine *e, int32_t which, int32_t iters, double *a
  * (q - 8) * half(scale) the W4A16 GEMM multiplies by under QV_PREC_MIXED_INT4_INT8.  Needs no GPU;
  * the parity tests compare it with the oracle's quantiser. */
 int qv_debug_int4_roundtrip(const float *w, int32_t n_rows, int32_t k, float *out);
+/* Same for the pointwise-convolution weights of that precision mode: per-output-channel symmetric int8
+ * (N % 64 == 0, K % 64 == 0), i.e. the f32 matrix q * scale[n] the W8A16 GEMM multiplies by. */
+int qv_debug_int8_roundtrip(const float *w, int32_t n_rows, int32_t k, float *out);
 
 /* Host-only (no GPU needed): the float32 tensors a weight file must hold, in file order -- names are
  * the NeMo state-dict keys of the CTC branch -- and tensor `index` of the seeded synthetic

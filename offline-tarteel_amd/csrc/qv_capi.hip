@@ -44,6 +44,23 @@ extern "C" int qv_debug_int4_roundtrip(const float *w, int32_t N, int32_t K, flo
     return QV_OK;
 }
 
+extern "C" int qv_debug_int8_roundtrip(const float *w, int32_t N, int32_t K, float *out) {
+    if (!w || !out || N < 64 || N % 64 != 0 || K < 64 || K % 64 != 0) return QV_ERR_ARG;
+    std::vector<uint8_t> q((size_t)N * K, 0);
+    std::vector<float> sc((size_t)N);
+    qv_pack_w8(w, N, K, q.data(), sc.data());
+    // walk the device layout exactly as the kernel does (qv_kernels.h: GemmArgs::W8 / w8scale)
+    const int nk = K / 64;
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            int kt = k >> 6, c = (k & 63) >> 3;
+            const uint8_t *row = q.data() + ((size_t)(n >> 6) * nk + kt) * 4096 + (size_t)(n & 63) * 64;
+            int code = (int)row[((c ^ ((n >> 2) & 7)) << 3) + (k & 7)] - 128;
+            out[(size_t)n * K + k] = (float)code * sc[n];
+        }
+    return QV_OK;
+}
+
 extern "C" const char *qv_build_info(void) {
     static char buf[128];
     snprintf(buf, sizeof buf, "libqverse gfx950 hip-%d.%d", HIP_VERSION_MAJOR, HIP_VERSION_MINOR);

@@ -45,6 +45,22 @@ __device__ __forceinline__ half8 dequant8(uint32_t q, half2_t s2, half2_t off) {
     return r;
 }
 
+// 8 bytes u = q + 128 -> 8 halves q, exactly: a byte next to 0x64 is the half 1024 + u (v_perm_b32 puts
+// it there), and (1024 + u) - 1152 = q needs no rounding.  The per-channel scale is applied in the epilogue.
+__device__ __forceinline__ half8 dequant8_i8(uint2 qv) {
+    const half2_t off = {(_Float16)1152.0f, (_Float16)1152.0f};
+    half8 r;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t src = p < 2 ? qv.x : qv.y;
+        const uint32_t bits = __builtin_amdgcn_perm(0x64646464u, src, (p & 1) ? 0x04030402u : 0x04010400u);
+        const half2_t h = __builtin_bit_cast(half2_t, bits) - off;
+        r[2 * p] = h[0];
+        r[2 * p + 1] = h[1];
+    }
+    return r;
+}
+
 }  // namespace
 
 // Wave specialisation: 512 threads.  Waves 0..3 (one per SIMD) are CONSUMERS: fragment reads from LDS
@@ -52,15 +68,17 @@ __device__ __forceinline__ half8 dequant8(uint32_t q, half2_t s2, half2_t off) {
 // issue the direct global->LDS loads of the stage NST - 1 K-steps ahead.  A wave that does both pays
 // the issue time of its 8 loads (hundreds of cycles per K-step) in front of its 16 MFMAs; split, the
 // loads issue under the partner wave's MFMAs (tools/gemm_exp.hip: 7-17 % per GEMM at these shapes).
-template <int EPI, int BN, bool W4, int NST>
+template <int EPI, int BN, int WQ, int NST>
 __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
+    constexpr bool W4 = WQ == 4, W8 = WQ == 8;
+    static_assert(!W8 || BN == 128, "W8A16 is built for 128-wide tiles only");
     constexpr int BM = 128, BK = 64;
     constexpr int NT = 512;
     constexpr int WN = BN / 2;   // columns per consumer wave
     constexpr int NF = WN / 32;  // 32-wide B fragments per consumer wave
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : BN * BK * 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : W8 ? BN * BK : BN * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int G = W4 ? 5 : 4 + BN / 32;      // direct loads per loader wave per stage
+    constexpr int G = W4 ? 5 : W8 ? 6 : 4 + BN / 32;      // direct loads per loader wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,6 +125,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
             const int p = w4 & (BN / 32 - 1);
             glds16(g.Wq + ((size_t)((n0 >> 6) + (p >> 1)) * nk + kt) * 2048 + (p & 1) * 1024 + lane * 16,
                    (unsigned char *)sB + p * 1024);
+            return;
+        }
+        if (W8) {
+            // 64 x 64 byte tiles, 4 KB contiguous and already swizzled: two 1 KB pieces per loader wave
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = w4 * 2 + q;
+                glds16(g.W8 + ((size_t)((n0 >> 6) + (p >> 2)) * nk + kt) * 4096 + (p & 3) * 1024 + lane * 16,
+                       (unsigned char *)sB + p * 1024);
+            }
             return;
         }
 #pragma unroll
@@ -177,6 +205,11 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                     // ds_read_b32 hit 64 different banks
                     uint32_t qv = *(const uint32_t *)((const unsigned char *)sB + row * 32 + ((c ^ ((row >> 2) & 7)) << 2));
                     b[j] = dequant8(qv, sc[j], zo[j]);
+                } else if (W8) {
+                    // 64-byte rows, 8-byte chunks at c ^ ((row >> 2) & 7); bytes are q + 128
+                    const uint2 qv = *(const uint2 *)((const unsigned char *)sB + (row >> 6) * 4096 + (row & 63) * 64 +
+                                                      ((c ^ ((row >> 2) & 7)) << 3));
+                    b[j] = dequant8_i8(qv);
                 } else {
                     b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
                 }
@@ -241,12 +274,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
 
     // this wave's bias values, requested together (g.bias is never null: one load latency, not
     // one per register quad)
-    f32x4 bia[NF][4];
+    f32x4 bia[NF][4], scl[NF][4];   // scl: per-channel weight scales (W8A16 only)
     if (EPI != EPI_GLU && !loader) {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bia[j][q] = *(const f32x4 *)(g.bias + n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
+            for (int q = 0; q < 4; ++q) {
+                bia[j][q] = *(const f32x4 *)(g.bias + n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
+                if (W8) scl[j][q] = *(const f32x4 *)(g.w8scale + n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
+            }
     }
 
     if (epi_is_f32(EPI)) {
@@ -264,7 +300,11 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                     f32x4 v;
                     const f32x4 bb = bia[j][q];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = g.alpha * (acc[i][j][q * 4 + e] + bb[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][q * 4 + e];
+                        if (W8) x *= scl[j][q][e];
+                        v[e] = g.alpha * (x + bb[e]);
+                    }
                     *(f32x4 *)(sO + rl * LDT + cl) = v;
                 }
         }
@@ -313,10 +353,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                 for (int q = 0; q < 4; ++q) {
                     int nl = 8 * q + 4 * hi;
                     f32x4 ba = *(const f32x4 *)(g.bias + nb + nl), bg = *(const f32x4 *)(g.bias + nb + 32 + nl);
+                    f32x4 sa = {1.f, 1.f, 1.f, 1.f}, sg = sa;
+                    if (W8) { sa = *(const f32x4 *)(g.w8scale + nb + nl); sg = *(const f32x4 *)(g.w8scale + nb + 32 + nl); }
                     half4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float av = acc[i][0][q * 4 + e] + ba[e], gv = acc[i][NF - 1][q * 4 + e] + bg[e];
+                        float av = acc[i][0][q * 4 + e], gv = acc[i][NF - 1][q * 4 + e];
+                        if (W8) { av *= sa[e]; gv *= sg[e]; }
+                        av += ba[e];
+                        gv += bg[e];
                         o[e] = (half_t)(av * sigmoidf_(gv));
                     }
                     *(half4 *)(sO + rl * LDT + wn * (WN / 2) + nl) = o;
@@ -350,34 +395,38 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     }
 }
 
-template <int EPI, int BN, bool W4, int NST>
+template <int EPI, int BN, int WQ, int NST>
 static void launch_one(const GemmArgs &g, hipStream_t s) {
+    constexpr bool W4 = WQ == 4, W8 = WQ == 8;
     dim3 grid(g.N / BN, (g.M + 127) / 128);
     size_t lds = W4 ? NST * ((128 * 64 * 2) + (BN * 32)) + (size_t)BN * (g.K / 128) * 4
-                    : NST * ((128 * 64 * 2) + (BN * 64 * 2));
+                    : W8 ? NST * ((128 * 64 * 2) + (BN * 64)) : NST * ((128 * 64 * 2) + (BN * 64 * 2));
     size_t epi = epi_is_f32(EPI) ? (size_t)128 * (BN + 4) * 4 : (size_t)128 * (BN + 8) * 2;
     if (epi > lds) lds = epi;
     // more than 64 KB of dynamic LDS is opted into, once per instantiation and only where needed
     if (lds > 64 * 1024) {
         static size_t allowed = 0;
         if (lds > allowed) {
-            (void)hipFuncSetAttribute((const void *)k_gemm<EPI, BN, W4, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_gemm<EPI, BN, WQ, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             allowed = lds;
         }
     }
-    hipLaunchKernelGGL((k_gemm<EPI, BN, W4, NST>), grid, dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_gemm<EPI, BN, WQ, NST>), grid, dim3(512), lds, s, g);
 }
 
 // tile width BN in {64, 128} and LDS stage count NST in {2, 3, 4} (see launch_gemm)
-template <int EPI, bool W4>
+template <int EPI, int WQ>
 static void launch_shape(const GemmArgs &g, hipStream_t s, bool narrow, int nst) {
-    if (narrow) {
-        if (nst == 2) launch_one<EPI, 64, W4, 2>(g, s);
-        else launch_one<EPI, 64, W4, 3>(g, s);
+    if constexpr (WQ == 8) {   // the two pointwise-convolution shapes: 128-wide tiles, 2 or 3 stages
+        if (nst == 2) launch_one<EPI, 128, 8, 2>(g, s);
+        else launch_one<EPI, 128, 8, 3>(g, s);
+    } else if (narrow) {
+        if (nst == 2) launch_one<EPI, 64, WQ, 2>(g, s);
+        else launch_one<EPI, 64, WQ, 3>(g, s);
     } else {
-        if (nst == 2) launch_one<EPI, 128, W4, 2>(g, s);
-        else if (nst == 3) launch_one<EPI, 128, W4, 3>(g, s);
-        else launch_one<EPI, 128, W4, 4>(g, s);
+        if (nst == 2) launch_one<EPI, 128, WQ, 2>(g, s);
+        else if (nst == 3) launch_one<EPI, 128, WQ, 3>(g, s);
+        else launch_one<EPI, 128, WQ, 4>(g, s);
     }
 }
 
@@ -409,6 +458,27 @@ void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out)
                 if (nib & 1) q_out[byte] = (uint8_t)((q_out[byte] & 0x0F) | (q << 4));
                 else q_out[byte] = (uint8_t)((q_out[byte] & 0xF0) | q);
             }
+        }
+    }
+}
+
+// Per-row symmetric int8: scale = max|w| / 127 (1 for an all-zero row), q = clamp(floor(w / scale + 0.5), -127, 127),
+// stored as q + 128.  oracle/fastconformer_ref.py:quant_dequant_int8 mirrors this exactly.
+void qv_pack_w8(const float *w, int N, int K, uint8_t *q_out, float *scale_out) {
+    const int nk = K / 64;
+    for (int n = 0; n < N; ++n) {
+        const float *row = w + (size_t)n * K;
+        float amax = 0.f;
+        for (int k = 0; k < K; ++k) amax = fmaxf(amax, fabsf(row[k]));
+        const float scale = amax > 0.f ? amax / 127.0f : 1.0f;
+        scale_out[n] = scale;
+        for (int k = 0; k < K; ++k) {
+            float t = row[k] / scale;
+            int q = (int)floorf(t + 0.5f);
+            q = q < -127 ? -127 : q > 127 ? 127 : q;
+            const int kt = k >> 6, c = (k & 63) >> 3;
+            const size_t byte = ((size_t)(n >> 6) * nk + kt) * 4096 + (size_t)(n & 63) * 64 + ((c ^ ((n >> 2) & 7)) << 3) + (k & 7);
+            q_out[byte] = (uint8_t)(q + 128);
         }
     }
 }
@@ -447,22 +517,32 @@ static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool na
     if (g.Wq) {
         // int4 weights: the Linear layers only (FFN, QKV, attention out, linear_pos)
         switch (epi) {
-            case EPI_F16: launch_shape<EPI_F16, true>(g, s, narrow, nst); break;
-            case EPI_F16_SWISH: launch_shape<EPI_F16_SWISH, true>(g, s, narrow, nst); break;
-            case EPI_RESID: launch_shape<EPI_RESID, true>(g, s, narrow, nst); break;
-            case EPI_QKV: launch_shape<EPI_QKV, true>(g, s, narrow, nst); break;
+            case EPI_F16: launch_shape<EPI_F16, 4>(g, s, narrow, nst); break;
+            case EPI_F16_SWISH: launch_shape<EPI_F16_SWISH, 4>(g, s, narrow, nst); break;
+            case EPI_RESID: launch_shape<EPI_RESID, 4>(g, s, narrow, nst); break;
+            case EPI_QKV: launch_shape<EPI_QKV, 4>(g, s, narrow, nst); break;
+            default: abort();
+        }
+        return;
+    }
+    if (g.W8) {
+        // int8 weights: the pointwise convolutions of the conv module (GLU and residual epilogues)
+        if (narrow || g.N % 128 != 0) abort();
+        switch (epi) {
+            case EPI_GLU: launch_shape<EPI_GLU, 8>(g, s, false, nst > 3 ? 3 : nst); break;
+            case EPI_RESID: launch_shape<EPI_RESID, 8>(g, s, false, nst > 3 ? 3 : nst); break;
             default: abort();
         }
         return;
     }
     switch (epi) {
-        case EPI_F16: launch_shape<EPI_F16, false>(g, s, narrow, nst); break;
-        case EPI_F16_SWISH: launch_shape<EPI_F16_SWISH, false>(g, s, narrow, nst); break;
-        case EPI_F16_RELU: launch_shape<EPI_F16_RELU, false>(g, s, narrow, nst); break;
-        case EPI_RESID: launch_shape<EPI_RESID, false>(g, s, narrow, nst); break;
-        case EPI_F32: launch_shape<EPI_F32, false>(g, s, narrow, nst); break;
-        case EPI_QKV: launch_shape<EPI_QKV, false>(g, s, narrow, nst); break;
-        case EPI_GLU: launch_shape<EPI_GLU, false>(g, s, false, nst); break;
+        case EPI_F16: launch_shape<EPI_F16, 0>(g, s, narrow, nst); break;
+        case EPI_F16_SWISH: launch_shape<EPI_F16_SWISH, 0>(g, s, narrow, nst); break;
+        case EPI_F16_RELU: launch_shape<EPI_F16_RELU, 0>(g, s, narrow, nst); break;
+        case EPI_RESID: launch_shape<EPI_RESID, 0>(g, s, narrow, nst); break;
+        case EPI_F32: launch_shape<EPI_F32, 0>(g, s, narrow, nst); break;
+        case EPI_QKV: launch_shape<EPI_QKV, 0>(g, s, narrow, nst); break;
+        case EPI_GLU: launch_shape<EPI_GLU, 0>(g, s, false, nst); break;
         default: abort();
     }
 }

@@ -56,13 +56,23 @@ struct GemmArgs {
     //   wscale  f16 [K/128][N][2] = {scale, 1024 + zero_point}
     const uint8_t *Wq;
     const half_t *wscale;
+    // W8A16 variant (W8 != nullptr; the pointwise convolutions under QV_PREC_MIXED_INT4_INT8): per-
+    // output-channel symmetric int8, w = q * w8scale[n].
+    //   W8      [N/64][K/64][64 rows][64 B]: one 64 x 64 tile is 4 KB contiguous; a byte holds q + 128;
+    //           inside a row the 8-byte chunk c (k = 8c .. 8c+7) sits at position c ^ ((n >> 2) & 7)
+    //   w8scale f32 [N], applied in the epilogue (the MFMA runs on the exact integers)
+    const uint8_t *W8;
+    const float *w8scale;
 };
 
-template <int EPI, int BN, bool W4, int NST>
+// WQ: 0 = f16 weights, 4 = W4A16, 8 = W8A16
+template <int EPI, int BN, int WQ, int NST>
 __global__ void k_gemm(GemmArgs g);
 
 // host-side packer for the W4A16 layout above (w: [N][K] f32 row-major; N % 64 == 0, K % 128 == 0)
 void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out);
+// ... and for the W8A16 layout (N % 64 == 0, K % 64 == 0): scale = max|w| / 127 per row, q = round(w / scale)
+void qv_pack_w8(const float *w, int N, int K, uint8_t *q_out, float *scale_out);
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);
 

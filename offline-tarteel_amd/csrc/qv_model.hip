@@ -156,6 +156,8 @@ struct WMat {
     const half_t *w = nullptr;
     const uint8_t *q = nullptr;
     const half_t *sc = nullptr;
+    const uint8_t *q8 = nullptr;   // int8 mode (pointwise convolutions): packed q + 128 ...
+    const float *sc8 = nullptr;    // ... and the per-output-channel scales
 };
 
 struct LayerW {
@@ -273,6 +275,16 @@ int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K
     qv_pack_w4(w.data(), N, K, q.data(), sc.data());
     TRY(up(eng, m, q, &out->q));
     return up(eng, m, sc, &out->sc);
+}
+
+// upload a pointwise-convolution weight [N][K]: f16, or per-channel int8 when the model runs mixed
+int up_mat8(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K, WMat *out) {
+    if (!m->w4) return up(eng, m, to_half(w), &out->w);
+    std::vector<uint8_t> q((size_t)N * K, 0);
+    std::vector<float> sc((size_t)N);
+    qv_pack_w8(w.data(), N, K, q.data(), sc.data());
+    TRY(up(eng, m, q, &out->q8));
+    return up(eng, m, sc, &out->sc8);
 }
 
 int build_frontend(qv_engine *eng, QvModel *m) {
@@ -393,20 +405,20 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
             // GLU pairing: 64-column groups = [32 value channels | their 32 gate channels]
             const auto &w = hw.get(p + "conv.pointwise_conv1.weight");
             const auto &b = hw.get(p + "conv.pointwise_conv1.bias");
-            std::vector<half_t> pwm((size_t)2 * QV_D * QV_D);
+            std::vector<float> pwm((size_t)2 * QV_D * QV_D);
             std::vector<float> pb(2 * QV_D);
             for (int g = 0; g < QV_D / 32; ++g)
                 for (int j = 0; j < 32; ++j) {
                     int ra = g * 32 + j, rg = QV_D + g * 32 + j;
                     int da = g * 64 + j, dg = g * 64 + 32 + j;
                     for (int k = 0; k < QV_D; ++k) {
-                        pwm[(size_t)da * QV_D + k] = (half_t)w[(size_t)ra * QV_D + k];
-                        pwm[(size_t)dg * QV_D + k] = (half_t)w[(size_t)rg * QV_D + k];
+                        pwm[(size_t)da * QV_D + k] = w[(size_t)ra * QV_D + k];
+                        pwm[(size_t)dg * QV_D + k] = w[(size_t)rg * QV_D + k];
                     }
                     pb[da] = b[ra];
                     pb[dg] = b[rg];
                 }
-            TRY(up(eng, m, pwm, &L.pw1_w.w));
+            TRY(up_mat8(eng, m, pwm, 2 * QV_D, QV_D, &L.pw1_w));
             TRY(up(eng, m, pb, &L.pw1_b));
         }
         {
@@ -426,7 +438,7 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
             TRY(up(eng, m, tap_major(fw, QV_D), &L.dw_w));
             TRY(up(eng, m, fb, &L.dw_b));
         }
-        TRY(up(eng, m, to_half(hw.get(p + "conv.pointwise_conv2.weight")), &L.pw2_w.w));
+        TRY(up_mat8(eng, m, hw.get(p + "conv.pointwise_conv2.weight"), QV_D, QV_D, &L.pw2_w));
         TRY(up(eng, m, hw.get(p + "conv.pointwise_conv2.bias"), &L.pw2_b));
     }
     TRY(up_mat(eng, m, posw, N_LAYERS * QV_D, QV_D, &m->pos_w));
@@ -611,7 +623,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         auto gemm = [&](int epi, const half_t *A, int K, const WMat &W, const float *bias, void *out, int N, int ldo,
                         float alpha) {
             GemmArgs a = {};
-            a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.bias = bias; a.out = out; a.out2 = m->vt;
+            a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.W8 = W.q8; a.w8scale = W.sc8; a.bias = bias; a.out = out; a.out2 = m->vt;
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
             a.row_map = m->row_map;
             launch_gemm(epi, a, s);
@@ -678,7 +690,7 @@ int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, doubl
         case 4: epi = EPI_GLU; a.A = m->ln; W = &L.pw1_w; a.bias = L.pw1_b; a.out = m->glu; a.N = 2 * QV_D; a.K = QV_D; a.ldo = QV_D; break;
         default: return QV_ERR_ARG;
     }
-    a.W = W->w; a.Wq = W->q; a.wscale = W->sc;
+    a.W = W->w; a.Wq = W->q; a.wscale = W->sc; a.W8 = W->q8; a.w8scale = W->sc8;
     a.lda = a.K; a.ldw = a.K;
     hipEvent_t e0, e1;
     QV_HIP(hipEventCreate(&e0));

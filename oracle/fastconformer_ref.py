@@ -172,6 +172,20 @@ def quant_dequant_int4(w2d: np.ndarray, block: int = 128) -> np.ndarray:
     return ((q - np.float32(8.0)) * sh[..., None]).astype(np.float32).reshape(N, K)
 
 
+def quant_dequant_int8(w2d: np.ndarray) -> np.ndarray:
+    """[N][K] f32 -> the f32 matrix the W8A16 GEMM effectively multiplies by: per-row symmetric int8,
+    scale = max|w| / 127 (1 for an all-zero row), q = clip(floor(w / scale + 0.5), -127, 127)
+    (csrc/qv_gemm.hip::qv_pack_w8)."""
+    w2d = np.ascontiguousarray(w2d, dtype=np.float32)
+    amax = np.abs(w2d).max(axis=1, keepdims=True).astype(np.float32)
+    scale = np.where(amax > 0, amax / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+    t = (w2d / scale).astype(np.float32)
+    q = np.clip(np.floor(t + np.float32(0.5)), -127, 127).astype(np.float32)
+    return (q * scale).astype(np.float32)
+
+
+INT8_CONV_SUFFIXES = ("conv.pointwise_conv1.weight", "conv.pointwise_conv2.weight")
+
 INT4_LINEAR_SUFFIXES = (
     "feed_forward1.linear1.weight", "feed_forward1.linear2.weight",
     "feed_forward2.linear1.weight", "feed_forward2.linear2.weight",
@@ -182,11 +196,15 @@ INT4_LINEAR_SUFFIXES = (
 
 def quantize_linear_weights(w: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
     """weights as the QV_PREC_MIXED_INT4_INT8 engine sees them: Linear layers of the 17 Conformer
-    blocks through int4 quantise -> dequantise, everything else untouched."""
+    blocks through int4 quantise -> dequantise, the two pointwise convolutions of each conv module
+    through per-channel int8, everything else untouched."""
     out = dict(w)
     for name, t in w.items():
         if name.startswith("encoder.layers.") and name.endswith(INT4_LINEAR_SUFFIXES):
             out[name] = torch.from_numpy(quant_dequant_int4(t.numpy()))
+        elif name.startswith("encoder.layers.") and name.endswith(INT8_CONV_SUFFIXES):
+            a = t.numpy()
+            out[name] = torch.from_numpy(quant_dequant_int8(a.reshape(a.shape[0], -1)).reshape(a.shape))
     return out
 
 

@@ -58,6 +58,32 @@ def test_int4_packing_roundtrip_equals_oracle_quantiser():
     assert lib.qv_debug_int4_roundtrip(w.ctypes.data, 60, 128, out.ctypes.data) != 0
 
 
+def test_int8_packing_roundtrip_equals_oracle_quantiser():
+    """qv_pack_w8 + the inverse of the device tile layout (host-only) against the oracle's per-channel
+    int8 quantiser: bit-identical dequantised matrices."""
+    from pathlib import Path
+
+    import numpy as np
+
+    from oracle.fastconformer_ref import quant_dequant_int8
+
+    lib = ctypes.CDLL(str(Path(__file__).resolve().parent.parent / "offline-tarteel_amd" / "libqverse.so"))
+    lib.qv_debug_int8_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    rng = np.random.default_rng(6)
+    for N, K in ((64, 64), (128, 512), (1024, 512)):
+        w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        w[0] = 0.0                          # all-zero row: scale 1
+        w[1] = 0.25
+        w[2, 5] = 3.0
+        w[3, 7] = -3.0
+        out = np.empty_like(w)
+        assert lib.qv_debug_int8_roundtrip(w.ctypes.data, N, K, out.ctypes.data) == 0
+        ref = quant_dequant_int8(w)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (N, K)
+        assert np.abs(out - w).max() <= np.abs(w).max(axis=1).max() / 127 * 0.51 + 1e-7
+    assert lib.qv_debug_int8_roundtrip(w.ctypes.data, 60, 64, out.ctypes.data) != 0
+
+
 def test_engine_refuses_to_run_without_gpu():
     import torch
 
