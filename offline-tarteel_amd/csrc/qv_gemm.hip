@@ -558,6 +558,10 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     static const int env_nst = [] { const char *e = getenv("QVERSE_GEMM_NST"); return e ? atoi(e) : 0; }();
     static const int env_narrow = [] { const char *e = getenv("QVERSE_GEMM_NARROW"); return e ? atoi(e) : -1; }();
     bool narrow = g.N % 128 != 0;
+    // int4 weights with too few 128-wide tiles for two blocks per CU (FFN-down, out-projection: N = 512): the
+    // consumer wave of a lone block pays its dequantisation VALU in front of its own MFMAs; 64-wide tiles give
+    // every SIMD a second consumer wave to interleave with
+    if (g.Wq && !narrow && (g.N / 128) * ((g.M + 127) / 128) < 400) narrow = true;
     if (env_narrow >= 0 && g.N % 128 == 0 && epi != EPI_GLU) narrow = env_narrow != 0;
     const int tiles = (g.N / (narrow ? 64 : 128)) * ((g.M + 127) / 128);
     int nst = tiles >= 400 ? 2 : (g.K / 64 >= 16 ? 4 : 3);
