@@ -10,9 +10,10 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"k_gemm<1, 128, false, 2>": "k_gemm<f16_swish,128>", "k_gemm<4, 128, false, 4>": "k_gemm<resid,128,4-stage>",
-         "k_gemm<4, 128, false, 3>": "k_gemm<resid,128,3-stage>", "k_gemm<6, 128, false, 2>": "k_gemm<qkv,128>",
-         "k_gemm<3, 128, false, 2>": "k_gemm<glu,128>"}
+NAMES = {"k_gemm<1, 128, 0, 2>": "k_gemm<f16_swish,128>", "k_gemm<4, 128, 0, 4>": "k_gemm<resid,128,4-stage>",
+         "k_gemm<4, 128, 0, 3>": "k_gemm<resid,128,3-stage>", "k_gemm<6, 128, 0, 2>": "k_gemm<qkv,128>",
+         "k_gemm<3, 128, 0, 2>": "k_gemm<glu,128>"}
+NAMES.update({k.replace(", 0, ", ", false, "): v for k, v in list(NAMES.items())})   # binaries built before the WQ parameter
 
 
 def mean_by_kernel(path, counter):
