@@ -59,6 +59,10 @@ def tensor(name, arr, how="raw"):
     return out + ld(8, name.encode())
 
 
+def attr_t(name, tensor_bytes):
+    return ld(1, name.encode()) + ld(5, tensor_bytes) + key(20, 0) + vint(4)
+
+
 def attr_i(name, v):
     return ld(1, name.encode()) + key(3, 0) + vint(v) + key(20, 0) + vint(2)
 
@@ -207,3 +211,31 @@ def test_convert_weights_from_synthetic_onnx(tmp_path):
 
     with pytest.raises(SystemExit):
         C.onnx_state_dict(str(p), dict(shapes, **{L + "self_attn.linear_q.weight": (D, D)}), verbose=False)
+
+
+def test_constant_nodes_gemm_and_anonymous_conv_operands(tmp_path):
+    """Weights that are not plainly named initializers: a Constant node, a Gemm with transB = 1 under
+    a prefixed scope, and a Conv whose weight and bias lost their names to BatchNorm folding."""
+    C = _load("convert_weights")
+    rng = np.random.default_rng(4)
+    D = 16
+    L = "encoder.layers.0."
+    shapes = {L + "self_attn.linear_q.weight": (D, D), L + "self_attn.linear_q.bias": (D,),
+              L + "conv.depthwise_conv.weight": (D, 1, 9), L + "conv.depthwise_conv.bias": (D,),
+              L + "norm_conv.weight": (D,)}
+    wq, bq = rng.normal(size=(D, D)).astype(np.float32), rng.normal(size=D).astype(np.float32)
+    dw, db = rng.normal(size=(D, 1, 9)).astype(np.float32), rng.normal(size=D).astype(np.float32)
+    g = rng.normal(size=D).astype(np.float32)
+    nodes = [
+        node("Constant", "/c0", [], [L + "norm_conv.weight"], [attr_t("value", tensor("", g))]),
+        node("Gemm", "/model/encoder/layers.0/self_attn/linear_q/Gemm", ["x", "onnx::Gemm_11", "onnx::Gemm_12"], ["q"],
+             [attr_i("transB", 1)]),
+        node("Conv", "/model/encoder/layers.0/conv/depthwise_conv/Conv", ["y", "onnx::Conv_21", "onnx::Conv_22"], ["z"]),
+    ]
+    inits = [tensor("onnx::Gemm_11", wq), tensor("onnx::Gemm_12", bq), tensor("onnx::Conv_21", dw), tensor("onnx::Conv_22", db)]
+    p = tmp_path / "m.onnx"
+    p.write_bytes(model(nodes, inits))
+    sd = C.onnx_state_dict(str(p), shapes, verbose=False)
+    assert np.array_equal(sd[L + "self_attn.linear_q.weight"], wq) and np.array_equal(sd[L + "self_attn.linear_q.bias"], bq)
+    assert np.array_equal(sd[L + "conv.depthwise_conv.weight"], dw) and np.array_equal(sd[L + "conv.depthwise_conv.bias"], db)
+    assert np.array_equal(sd[L + "norm_conv.weight"], g)

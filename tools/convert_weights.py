@@ -128,6 +128,11 @@ def onnx_state_dict(path, shapes: dict, name_map: dict | None = None, verbose: b
             cands.append(name_map[name])
         cands.append(name)
         module = name.rsplit(".", 1)[0]
+        if name.endswith((".weight", ".bias")):   # operands named by node scope, possibly with a different prefix
+            tail = [k for k in fw if k.endswith(name.rsplit(".", 1)[1]) and k != name and
+                    (k.endswith("." + name) or name.endswith("." + k)) and _fit(fw[k][0], shape) is not None]
+            if len(tail) == 1:
+                cands.append(tail[0])
         if name.endswith(".weight"):
             cands.append(module)
             # scopes may lack or carry extra leading components ("layers.0..." / "model.encoder.layers.0...")

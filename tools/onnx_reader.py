@@ -227,11 +227,26 @@ def float_weights(nodes, inits):
     consuming node ("/encoder/layers.0/feed_forward1/linear1/MatMul" -> "encoder.layers.0.
     feed_forward1.linear1") for anonymous MatMul operands."""
     out = {}
+    inits = dict(inits)
+    for n in nodes:                      # weights emitted as Constant nodes count as initializers
+        if n.op == "Constant" and isinstance(n.attrs.get("value"), np.ndarray) and n.outputs:
+            inits.setdefault(n.outputs[0], n.attrs["value"])
     for name, a in inits.items():
         if a.dtype in (np.float32, np.float16, np.float64):
             out[name] = (a.astype(np.float32), "float initializer")
+    named = _named(out)
     for n in nodes:
         scope = n.name.strip("/").rsplit("/", 1)[0].replace("/", ".") if "/" in n.name.strip("/") else ""
+        if n.op in ("Conv", "Gemm") and scope and len(n.inputs) > 1:
+            # anonymous operands (e.g. "onnx::Conv_1234" after BatchNorm folding): name them by the module scope
+            w = out.get(n.inputs[1])
+            if w is not None and n.inputs[1] not in named:
+                a = w[0]
+                if n.op == "Gemm" and not int(n.attrs.get("transB", 0)):
+                    a = a.T                                   # Gemm without transB holds [in, out]
+                out[scope + ".weight"] = (a, f"{n.op} operand named by its node scope")
+            if len(n.inputs) > 2 and n.inputs[2] in out and n.inputs[2] not in named:
+                out[scope + ".bias"] = (out[n.inputs[2]][0], f"{n.op} bias named by its node scope")
         if n.op == "MatMulNBits":
             w = dequant_matmul_nbits(n, inits)
             for key in {scope, _strip(n.inputs[1])} - {""}:
