@@ -26,6 +26,14 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+#ifdef QV_GEMM_TRACE
+#define QV_ABL(bit) (g.abl & (bit))
+#define QV_TRACE(slot) do { if (g.trace && lane == 0 && (wave & 3) == 0) g.trace[(((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 64 + kt_) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QV_ABL(bit) false
+#define QV_TRACE(slot) do { } while (0)
+#endif
+
 constexpr bool epi_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; }
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -68,7 +76,19 @@ __device__ __forceinline__ half8 dequant8_i8(uint2 qv) {
 // issue the direct global->LDS loads of the stage NST - 1 K-steps ahead.  A wave that does both pays
 // the issue time of its 8 loads (hundreds of cycles per K-step) in front of its 16 MFMAs; split, the
 // loads issue under the partner wave's MFMAs (tools/gemm_exp.hip: 7-17 % per GEMM at these shapes).
-template <int EPI, int BN, int WQ, int NST>
+//
+// LD selects how the loader waves move a K-step's operands into LDS:
+//   LD = 0  direct global->LDS loads (global_load_lds_dwordx4), NST LDS stages, counted vmcnt
+//   LD = 1  REGISTER staging through MUBUF: buffer_load_dwordx4 into VGPRs (a loader wave holds no
+//           accumulators, so it has ~100 VGPRs to spare) and ds_write_b128 into a 2-stage LDS ring; the
+//           prefetch depth (two K-steps) lives in registers, not in LDS.  Why (tools/stage_bench.hip, 4 loader
+//           + 4 MFMA waves per CU): while a SIMD's matrix pipe runs back-to-back MFMAs, the FLAT-encoded
+//           loads of its other waves (global_load_lds_dwordx4 AND global_load_dwordx4 -- their 64-bit
+//           address goes through the VALU) hardly issue at all: 2 MB per CU took 86 / 74 us under 61 us of
+//           dense MFMAs against 27 / 17 us alone, i.e. the loads ran AFTER the MFMAs.  Buffer loads (SGPR
+//           descriptor + 32-bit offset, no VALU pass) are not blocked: 18.8 us under the same MFMA load
+//           (53 B/clk/CU), and the MFMA waves lose < 2 %.
+template <int EPI, int BN, int WQ, int NST, int LD>
 __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     constexpr bool W4 = WQ == 4, W8 = WQ == 8;
     static_assert(!W8 || BN == 128, "W8A16 is built for 128-wide tiles only");
@@ -162,7 +182,100 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     // the stage visible to the consumers and tells the loaders that the consumers are done with
     // stage kt - 1, whose buffer the next prefetch overwrites.  (__syncthreads() would drain the
     // whole queue and serialise the load latency with the MFMAs.)
-    if (loader) {
+    if (loader && LD == 1) {
+        static_assert(LD == 0 || NST == 2, "register staging uses a 2-stage LDS ring");
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NB = W4 ? 1 : W8 ? 2 : BN / 32;   // B pieces (1 KB each) per loader wave per K-step
+        constexpr int GR = 4 + NB;
+        // MUBUF addressing: SGPR descriptor + per-lane 32-bit byte offset (fixed for the tile) + a scalar
+        // byte offset that advances with the K-step -- no VALU instruction per load (see the header comment)
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
+        const void *bbase = W4 ? (const void *)g.Wq : W8 ? (const void *)g.W8 : (const void *)g.W;
+        const size_t bbytes = W4 ? (size_t)g.N * g.K / 2 : W8 ? (size_t)g.N * g.K : (size_t)g.N * g.ldw * 2;
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, (int)bbytes, 0x00020000);
+        unsigned offA[4], offB[NB];
+        int dstA[4], dstB[NB];
+        int stepB;   // bytes between consecutive K-steps of a B piece
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int chunk = w4 * 4 + q, row = chunk * 8 + (lane >> 3), c = lane & 7;
+            int grow = m0 + row;
+            grow = grow < g.M ? grow : g.M - 1;
+            offA[q] = (unsigned)(((size_t)grow * g.lda + c * 8) * 2);
+            dstA[q] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        }
+        if (W4) {
+            const int p = w4 & (BN / 32 - 1);
+            offB[0] = (unsigned)(((size_t)((n0 >> 6) + (p >> 1)) * nk) * 2048 + (p & 1) * 1024 + lane * 16);
+            dstB[0] = A_BYTES + p * 1024 + lane * 16;
+            stepB = 2048;
+        } else if (W8) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int p = w4 * 2 + q;
+                offB[q] = (unsigned)(((size_t)((n0 >> 6) + (p >> 2)) * nk) * 4096 + (p & 3) * 1024 + lane * 16);
+                dstB[q] = A_BYTES + p * 1024 + lane * 16;
+            }
+            stepB = 4096;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int chunk = w4 * NB + q, row = chunk * 8 + (lane >> 3), c = lane & 7;
+                offB[q] = (unsigned)(((size_t)(n0 + row) * g.ldw + c * 8) * 2);
+                dstB[q] = A_BYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+            }
+            stepB = BK * 2;
+        }
+        u32x4 r0[GR], r1[GR];
+        // The loads are inline asm: hipcc's own vmcnt bookkeeping merges the two register batches at the loop
+        // head and drains BOTH before the first ds_write (prefetch depth 1); here the wait is counted by hand
+        // -- loads return in order, so "at most GR outstanding" means the older batch has landed.
+        auto fetch = [&](int kt, u32x4 (&r)[GR]) {
+            if (QV_ABL(8)) return;
+            const int sa = kt * (BK * 2), sb = kt * stepB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[q]) : "v"(offA[q]), "s"(rsA), "s"(sa) : "memory");
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[4 + q]) : "v"(offB[q]), "s"(rsB), "s"(sb) : "memory");
+        };
+        auto put = [&](int kt, const u32x4 (&r)[GR], bool newer_in_flight) {
+            if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned char *st = smem + (kt % NST) * STAGE_BYTES;
+            if (QV_ABL(4)) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(u32x4 *)(st + dstA[q]) = r[q];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) *(u32x4 *)(st + dstB[q]) = r[4 + q];
+        };
+        // Barrier kt: stage kt is written (loaders) and stage kt - 1 is read (consumers).  Between barriers
+        // kt - 1 and kt a loader writes stage kt -- the buffer the consumers left before barrier kt - 1 --
+        // out of registers that were requested two K-steps ago, then requests K-step kt + 2 into them.
+        fetch(0, r0);
+        if (nk > 1) fetch(1, r1);
+        for (int kt = 0; kt < nk; kt += 2) {
+            int kt_ = kt;
+            QV_TRACE(0);                       // barrier kt - 1 released
+            put(kt, r0, kt + 1 < nk);
+            QV_TRACE(1);                       // (s_memtime waits lgkmcnt: loads landed + writes done)
+            if (kt + 2 < nk) fetch(kt + 2, r0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            QV_TRACE(2);                       // arriving at barrier kt
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) {
+                kt_ = kt + 1;
+                QV_TRACE(0);
+                put(kt + 1, r1, kt + 2 < nk);
+                QV_TRACE(1);
+                if (kt + 3 < nk) fetch(kt + 3, r1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                QV_TRACE(2);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else if (loader) {
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
             if (s < nk) stage(s);
@@ -176,7 +289,11 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         }
     }
     for (int kt = 0; kt < (loader ? 0 : nk); ++kt) {
+        const int kt_ = kt;
+        QV_TRACE(2);                           // arriving at barrier kt (K-step kt - 1 computed)
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        QV_TRACE(0);                           // barrier kt released
         const half_t *sA = (const half_t *)(smem + (kt % NST) * STAGE_BYTES);
         const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
         half2_t sc[NF], zo[NF];
@@ -188,47 +305,96 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                 zo[j] = half2_t{sz[1], sz[1]};
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8 a[2], b[NF];
-            int c = ks * 2 + (lane >> 5);
+        // Fragment reads are software-pipelined over the four 16-deep sub-steps: the reads of sub-step ks + 1
+        // are in flight while the MFMAs of sub-step ks run (two register sets).  With one set the next reads
+        // could only issue behind the last MFMA of a sub-step and every sub-step exposed one LDS latency
+        // (~90 of ~220 cycles, tools/gemm_trace.hip: 964 cycles per K-step for 512 cycles of MFMA).
+        struct Raw { half8 a[2]; half8 b[NF]; uint32_t q4[NF]; uint2 q8[NF]; };
+        auto rd = [&](int ks, Raw &f) {
+            if (QV_ABL(2)) return;
+            const int c = ks * 2 + (lane >> 5);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                int row = wm * 64 + i * 32 + (lane & 31);
-                a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                const int row = wm * 64 + i * 32 + (lane & 31);
+                f.a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
             }
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                int row = wn * WN + j * 32 + (lane & 31);
+                const int row = wn * WN + j * 32 + (lane & 31);
                 if (W4) {
                     // 32-byte rows, 4-byte chunks at c ^ ((row >> 2) & 7): the 64 lanes of the
                     // ds_read_b32 hit 64 different banks
-                    uint32_t qv = *(const uint32_t *)((const unsigned char *)sB + row * 32 + ((c ^ ((row >> 2) & 7)) << 2));
-                    b[j] = dequant8(qv, sc[j], zo[j]);
+                    f.q4[j] = *(const uint32_t *)((const unsigned char *)sB + row * 32 + ((c ^ ((row >> 2) & 7)) << 2));
                 } else if (W8) {
                     // 64-byte rows, 8-byte chunks at c ^ ((row >> 2) & 7); bytes are q + 128
-                    const uint2 qv = *(const uint2 *)((const unsigned char *)sB + (row >> 6) * 4096 + (row & 63) * 64 +
-                                                      ((c ^ ((row >> 2) & 7)) << 3));
-                    b[j] = dequant8_i8(qv);
+                    f.q8[j] = *(const uint2 *)((const unsigned char *)sB + (row >> 6) * 4096 + (row & 63) * 64 +
+                                               ((c ^ ((row >> 2) & 7)) << 3));
                 } else {
-                    b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+                    f.b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
                 }
             }
+        };
+        auto mma = [&](const Raw &f) {
+            if (QV_ABL(1)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(f.a[i]));
+#pragma unroll
+                for (int j = 0; j < NF; ++j) { asm volatile("" ::"v"(f.b[j])); asm volatile("" ::"v"(f.q4[j])); asm volatile("" ::"v"(f.q8[j])); }
+                return;
+            }
+            half8 b[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) b[j] = W4 ? dequant8(f.q4[j], sc[j], zo[j]) : W8 ? dequant8_i8(f.q8[j]) : f.b[j];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per
                     // register quad -> 8/16-byte LDS writes in the epilogue
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
+        };
+        // (sched_barrier: left alone, the scheduler sinks every read group back behind the previous MFMAs
+        // to save the 16 registers)
+        Raw f0 = {}, f1 = {};
+        rd(0, f0);
+        rd(1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(2, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(3, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
     }
     __syncthreads();  // every wave is done with the operand stages before the epilogue reuses them
+#if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+    if (QV_ABL(32)) {   // no epilogue at all (accumulators kept live)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+#endif
 
     // ------------------------------------------------------------------ epilogue ----------
     // accumulator (i, j), register r: tile row  = wm*64 + i*32 + (lane & 31),
     //   tile column = wn*WN + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
     const int l31 = lane & 31, hi = lane >> 5;
+    // Every global access of the epilogue goes through MUBUF (SGPR descriptor + 32-bit byte offset): while the
+    // co-resident block's consumer waves keep the SIMDs' matrix pipes busy, FLAT-encoded loads and stores of
+    // this block would wait for a gap in their MFMA stream (see the LD = 1 note above).
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, g.N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_scl = __builtin_amdgcn_make_buffer_rsrc((void *)(W8 ? g.w8scale : g.bias), 0, g.N * 4, 0x00020000);
+    auto ldf4 = [&](const __amdgpu_buffer_rsrc_t &rs, int elem) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 0));
+    };
 
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
         // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  The tile goes through LDS as [d][frame] so
@@ -243,7 +409,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
-                    const f32x4 bb = *(const f32x4 *)(g.bias + n0 + cl);
+                    const f32x4 bb = ldf4(rs_bias, n0 + cl);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int rl = wm * 64 + i * 32 + l31;
@@ -280,8 +446,8 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         for (int j = 0; j < NF; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bia[j][q] = *(const f32x4 *)(g.bias + n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
-                if (W8) scl[j][q] = *(const f32x4 *)(g.w8scale + n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
+                bia[j][q] = ldf4(rs_bias, n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
+                if (W8) scl[j][q] = ldf4(rs_scl, n0 + wn * WN + j * 32 + 8 * q + 4 * hi);
             }
     }
 
@@ -314,12 +480,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         // residual: all of a thread's old values are requested before the first store (a store
         // followed by the next load of the same array would serialise one latency per chunk)
         f32x4 old[IT];
+        // (the descriptor's size bounds the rows: loads past row M return 0, stores past it are dropped)
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 4), 0x00020000);
         if (EPI == EPI_RESID) {
 #pragma unroll
             for (int k = 0; k < IT; ++k) {
                 int idx = tid + k * NT, r = idx / CPR, c = (idx % CPR) * 4;
-                const f32x4 *o = (const f32x4 *)((const float *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c);
-                if (m0 + r < g.M) old[k] = *o;
+                if (m0 + r < g.M && !QV_ABL(16)) old[k] = ldf4(rs_out, (m0 + r) * g.ldo + n0 + c);
             }
         }
 #pragma unroll
@@ -327,12 +494,12 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
             int idx = tid + k * NT, r = idx / CPR, c = (idx % CPR) * 4;
             if (m0 + r >= g.M) continue;
             f32x4 v = *(const f32x4 *)(sO + r * LDT + c);
-            f32x4 *o = (f32x4 *)((float *)g.out + (size_t)(m0 + r) * g.ldo + n0 + c);
             if (EPI == EPI_RESID) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += old[k][e];
             }
-            *o = v;
+            if (QV_ABL(16)) { asm volatile("" ::"v"(v)); continue; }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, ((m0 + r) * g.ldo + n0 + c) * 4, 0, 0);
         }
         return;
     }
@@ -352,9 +519,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     int nl = 8 * q + 4 * hi;
-                    f32x4 ba = *(const f32x4 *)(g.bias + nb + nl), bg = *(const f32x4 *)(g.bias + nb + 32 + nl);
+                    f32x4 ba = ldf4(rs_bias, nb + nl), bg = ldf4(rs_bias, nb + 32 + nl);
                     f32x4 sa = {1.f, 1.f, 1.f, 1.f}, sg = sa;
-                    if (W8) { sa = *(const f32x4 *)(g.w8scale + nb + nl); sg = *(const f32x4 *)(g.w8scale + nb + 32 + nl); }
+                    if (W8) { sa = ldf4(rs_scl, nb + nl); sg = ldf4(rs_scl, nb + 32 + nl); }
                     half4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -387,15 +554,17 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         }
         __syncthreads();
         constexpr int CPR = BNO / 8;  // 16-byte chunks per row
+        const __amdgpu_buffer_rsrc_t rs_out16 = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 2), 0x00020000);
         for (int idx = tid; idx < BM * CPR; idx += NT) {
             int r = idx / CPR, c = (idx % CPR) * 8;
             if (m0 + r >= g.M) continue;
-            *(half8 *)((half_t *)g.out + (size_t)(m0 + r) * g.ldo + n0o + c) = *(const half8 *)(sO + r * LDT + c);
+            if (QV_ABL(16)) { asm volatile("" ::"v"(*(const half8 *)(sO + r * LDT + c))); continue; }
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(sO + r * LDT + c), rs_out16, ((m0 + r) * g.ldo + n0o + c) * 2, 0, 0);
         }
     }
 }
 
-template <int EPI, int BN, int WQ, int NST>
+template <int EPI, int BN, int WQ, int NST, int LD = 0>
 static void launch_one(const GemmArgs &g, hipStream_t s) {
     constexpr bool W4 = WQ == 4, W8 = WQ == 8;
     dim3 grid(g.N / BN, (g.M + 127) / 128);
@@ -407,16 +576,22 @@ static void launch_one(const GemmArgs &g, hipStream_t s) {
     if (lds > 64 * 1024) {
         static size_t allowed = 0;
         if (lds > allowed) {
-            (void)hipFuncSetAttribute((const void *)k_gemm<EPI, BN, WQ, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_gemm<EPI, BN, WQ, NST, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             allowed = lds;
         }
     }
-    hipLaunchKernelGGL((k_gemm<EPI, BN, WQ, NST>), grid, dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_gemm<EPI, BN, WQ, NST, LD>), grid, dim3(512), lds, s, g);
 }
 
 // tile width BN in {64, 128} and LDS stage count NST in {2, 3, 4} (see launch_gemm)
 template <int EPI, int WQ>
 static void launch_shape(const GemmArgs &g, hipStream_t s, bool narrow, int nst) {
+    if (nst == 0) {   // register-staged loaders (2-stage LDS ring)
+        if constexpr (WQ == 8) launch_one<EPI, 128, 8, 2, 1>(g, s);
+        else if (narrow) launch_one<EPI, 64, WQ, 2, 1>(g, s);
+        else launch_one<EPI, 128, WQ, 2, 1>(g, s);
+        return;
+    }
     if constexpr (WQ == 8) {   // the two pointwise-convolution shapes: 128-wide tiles, 2 or 3 stages
         if (nst == 2) launch_one<EPI, 128, 8, 2>(g, s);
         else launch_one<EPI, 128, 8, 3>(g, s);
@@ -567,6 +742,9 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     int nst = tiles >= 400 ? 2 : (g.K / 64 >= 16 ? 4 : 3);
     if (narrow && nst > 3) nst = 3;
     if (env_nst >= 2 && env_nst <= (narrow ? 3 : 4)) nst = env_nst;
+    // loader waves: MUBUF register staging by default (QVERSE_GEMM_LD=0 selects the direct global->LDS loads)
+    static const int env_ld = [] { const char *e = getenv("QVERSE_GEMM_LD"); return e ? atoi(e) : 1; }();
+    if (env_ld == 1) nst = 0;
     if (!g_prof.on) { launch_gemm_inner(epi, g, s, narrow, nst); return; }
     size_t i = g_prof.cls.size();
     while (g_prof.ev.size() < 2 * (i + 1)) {

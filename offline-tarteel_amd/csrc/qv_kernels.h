@@ -63,10 +63,16 @@ struct GemmArgs {
     //   w8scale f32 [N], applied in the epilogue (the MFMA runs on the exact integers)
     const uint8_t *W8;
     const float *w8scale;
+#ifdef QV_GEMM_TRACE
+    // dev tool only (tools/gemm_trace.hip): [block][wave][K-step][4] s_memtime stamps
+    unsigned long long *trace;
+    int abl;   // ablation mask: 1 no MFMA, 2 no fragment reads, 4 no ds_write (LD = 1), 8 no loads (LD = 1)
+#endif
 };
 
 // WQ: 0 = f16 weights, 4 = W4A16, 8 = W8A16
-template <int EPI, int BN, int WQ, int NST>
+// LD: 0 = direct global->LDS loads with NST LDS stages, 1 = register-staged loader waves (NST = 2)
+template <int EPI, int BN, int WQ, int NST, int LD>
 __global__ void k_gemm(GemmArgs g);
 
 // host-side packer for the W4A16 layout above (w: [N][K] f32 row-major; N % 64 == 0, K % 128 == 0)
