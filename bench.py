@@ -4,11 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole hot path (FastConformer-CTC forward -> greedy decode ->
-verse retrieval -> CTC rerank) over one batch of synthetic 10 s / 16 kHz clips that is already
-resident in HBM: BASELINE.json configs[1] ("Single MI355X, batch=64 synthetic 10 s/16 kHz
-clips, fp16 forward + CTC rerank").  For N > 1 every rank processes its own batch of 64
-(utterances are independent: pure data parallel, weak scaling) and the packed
-(surah, ayah, ayah_end, score) rows of every batch are all-gathered over RCCL.
+verse retrieval -> CTC rerank) over one batch of synthetic 16 kHz clips that is already resident
+in HBM.  Workloads (BASELINE.json configs):
+  default, N < 8   64 clips x 10 s per GPU, fp16 weights          configs[1] (the headline line)
+  --precision mixed --batch 256   int4 Linear + int8 pointwise-conv weights   configs[2]
+  default, N = 8   256 clips x 10 s per GPU = 2048 per step       configs[3]
+  --workload tta30 64 clips x 30 s per GPU through the TTA wrapper (anchor pass, 0.5 gate, GPU
+                   0.9x / 1.1x copies of the gated clips, majority / best-score pick)   configs[4]
+For N > 1 every rank processes its own batch (utterances are independent: pure data parallel,
+weak scaling) and the packed (surah, ayah, ayah_end, score) rows of every batch are all-gathered
+over RCCL.
 
 The engine keeps --contexts (default 3) batches in flight on internal streams: each step still
 runs the whole path on its own batch of 64, but the latency-bound post-logits kernels of one
@@ -20,6 +25,9 @@ Prints ONE JSON line on rank 0 (contract in the task description) including
   roofline      dominant kernel (the FFN-up GEMM class) measured with HIP events on its stream
   cpu_baseline  the CPU oracle (fp32 PyTorch forward + C restatement of the post-logits
                 stages) timed on this node's host cores on a bounded sample of the same clips
+  post_logits   the post-logits stages alone on verse-shaped log-probs (the random-weight clips
+                decode to near-empty transcripts and never exercise retrieval): ms per batch
+                with every transcript passing the 0.80 text gate and with every one failing it
 """
 
 from __future__ import annotations
@@ -44,8 +52,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
-    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="utterances per GPU per step (default 64; 256 with --gpus 8 = BASELINE configs[3])")
+    ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default 10; 30 for --workload tta30)")
+    ap.add_argument("--workload", choices=("clips", "tta30"), default="clips",
+                    help="clips: the plain hot path; tta30: c2c-direct-mixed-tta on 30 s clips (configs[4])")
+    ap.add_argument("--no-post-logits", action="store_true", help="skip the verse-shaped post-logits replay legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24, help="clips timed on the host for cpu_baseline")
     ap.add_argument("--literal", action="store_true", help="run search()/pass-3 even when the gate passes")
@@ -53,10 +65,53 @@ def parse():
                     help="batches in flight per GPU (execution contexts of the engine, 1..4)")
     ap.add_argument("--precision", choices=("fp16", "mixed"), default="fp16",
                     help="fp16 = BASELINE configs[1] (the headline line); mixed = int4 Linear weights (W4A16)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.batch <= 0:
+        a.batch = 256 if (a.gpus >= 8 and a.workload == "clips") else 64
+    if a.seconds <= 0:
+        a.seconds = 30.0 if a.workload == "tta30" else 10.0
+    return a
 
 
-def cpu_baseline(audio_np, n_clips: int):
+def post_logits_legs(eng, B: int, T: int, steps: int = 10):
+    """SURVEY.md 8(d) replay workload: log-probs synthesised from the token ids of seeded verses (the
+    tests' recipe), once clean enough that every transcript passes the 0.80 text gate (0 % use_ctc) and
+    once corrupted so that every one fails it (100 %: search over all verses, pass 3, candidate spans,
+    CTC rerank).  Returns ms per batch of B for both, timed like the main loop."""
+    import numpy as np
+    import torch
+
+    from synth import synth_logits
+
+    rng = np.random.default_rng(20260630)
+    n_verses = len(eng.tables.s["tok_off"]) // 6
+    out = {"batch": B, "frames": T}
+    for key, noise, boost in (("gate_pass", 1.0, 8.0), ("gate_fail", 3.5, 4.0)):
+        lps, used = [], 0
+        while len(lps) < B:
+            v = int(rng.integers(0, n_verses))
+            ids = eng.tables.token_ids(v, 1).tolist()
+            if not (4 <= len(ids) and 2 * len(ids) + 1 <= T):
+                continue
+            lg = torch.from_numpy(synth_logits(ids, T, seed=1000 + used, noise=noise, boost=boost, rep=2))
+            lps.append(torch.log_softmax(lg, -1))
+            used += 1
+        lp = torch.stack(lps).cuda(eng.device).contiguous()
+        res = eng.decode_retrieve_rerank(lp, [T] * B, want_text=False)
+        for _ in range(2):
+            eng.decode_retrieve_rerank(lp, [T] * B, want_text=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.decode_retrieve_rerank(lp, [T] * B, want_text=False)
+        torch.cuda.synchronize()
+        out[key] = {"ms_per_batch": round((time.perf_counter() - t0) / steps * 1e3, 3),
+                    "use_ctc_fraction": round(sum(r["use_ctc"] for r in res) / B, 3),
+                    "mean_candidates": round(sum(r["n_candidates"] for r in res) / B, 1)}
+    return out
+
+
+def cpu_baseline(audio_np, n_clips: int, what: str = "10 s clips"):
     """oracle ("port"): fp32 PyTorch-CPU forward + C post-logits, per-file like the reference."""
     import numpy as np
     import torch
@@ -98,7 +153,7 @@ def cpu_baseline(audio_np, n_clips: int):
         return {
             "value": round(done / (t_fwd + t_post), 4), "unit": "utterances/s", "cores": os.cpu_count(),
             "kind": "reference",
-            "sample": f"{done} of the benchmark's 10 s clips, batch 1: onnxruntime CPUExecutionProvider on "
+            "sample": f"{done} of the benchmark's {what}, batch 1: onnxruntime CPUExecutionProvider on "
                       f"{os.path.basename(ref_onnx)} with default session options ({t_fwd / done:.2f} s per clip) + C "
                       f"post-logits ({t_post / done:.2f} s per clip)",
         }
@@ -130,7 +185,7 @@ def cpu_baseline(audio_np, n_clips: int):
     return {
         "value": round(n_clips / tot, 4), "unit": "utterances/s", "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n_clips} of the benchmark's 10 s clips, batch 1 like the reference "
+        "sample": f"{n_clips} of the benchmark's {what}, batch 1 like the reference "
                   f"(fp32 PyTorch forward {t_fwd / n_clips:.2f} s + C post-logits {t_post / n_clips:.2f} s per clip); "
                   "reference ORT/ONNX path unavailable on this node (no onnxruntime, no weight file)",
     }
@@ -172,20 +227,24 @@ def main():
 
     n = int(args.seconds * 16000)
     B = args.batch
+    tta = args.workload == "tta30"
     audio_np = synth_audio(B, n, seed=20260630 + 1000 * rank)
     audio = torch.from_numpy(audio_np).cuda(local_rank).contiguous()
     lengths = [n] * B
-    eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=n,
+    # TTA: the 1.1x-slowed copies are 10 % longer than the clips
+    cap = int(n * 1.1) + 1600 if tta else n
+    eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=cap,
                  precision=1 if args.precision == "mixed" else 0, skip_unused_passes=not args.literal,
-                 contexts=args.contexts)
+                 contexts=1 if tta else args.contexts)
     gathered = torch.empty((world * B, 4), dtype=torch.int32, device=f"cuda:{local_rank}") if use_dist else None
     pending = []   # contexts whose packed rows have not been all-gathered yet
+    tta_stats = {"gated": 0, "clips": 0}
 
     def gather(ctx):
         # the path's only exchange: 16 B per utterance, latency-bound
         dist.all_gather_into_tensor(gathered, eng.packed_results(B, ctx))
 
-    def step():
+    def step_clips():
         # every step runs the WHOLE hot path on one batch; with contexts > 1 up to that many batches
         # are in flight, so the all-gather of a batch is issued (contexts - 1) steps later
         ctx = eng.predict_batch_async(audio, lengths)
@@ -193,6 +252,22 @@ def main():
             pending.append(ctx)
             if len(pending) >= args.contexts:
                 gather(pending.pop(0))
+
+    def step_tta():
+        # c2c-direct-mixed-tta/run.py:117-149 per batch: anchor pass, 0.5 gate (host decision on the
+        # fetched scores, as in the reference), 0.9x / 1.1x copies of the gated clips resampled on the GPU
+        # and run as further batches, majority / best-score pick; the combined rows are what is gathered
+        from offline_tarteel_amd import dist as qdist
+        from offline_tarteel_amd.plugin import tta_device_batch
+
+        res = tta_device_batch(eng, audio, lengths, want_text=False)
+        tta_stats["clips"] += B
+        tta_stats["gated"] += sum(1 for r in res if "tta" in r)
+        if use_dist:
+            rows = torch.from_numpy(qdist.pack_results(res)).cuda(local_rank)
+            dist.all_gather_into_tensor(gathered, rows)
+
+    step = step_tta if tta else step_clips
 
     def sync_all():
         while pending:
@@ -221,6 +296,7 @@ def main():
     res = eng.predict_batch(audio, lengths, want_text=False)
     assert len(res) == B and all(r["t_frames"] == eng.frames_for(n) for r in res)
     used_ctc = sum(r["use_ctc"] for r in res)
+    rows_per_launch = B * eng.frames_for(n)   # M of the encoder GEMMs
 
     # ---- roofline of the dominant kernel -----------------------------------------------------
     # Dominant kernel by time (profiles/*_kernel_stats.csv): the GEMM family; its single-shape
@@ -233,12 +309,18 @@ def main():
     if rank == 0:
         rep = eng.replay_gemm(0, iters=100)
         ach = rep["flops"] / (rep["avg_us"] * 1e-6) / 1e12
-        traffic = None
+        # HBM traffic of that kernel is NOT measured in this run (PMC counters need rocprofv3): it is quoted
+        # from the newest committed counter summary, and only for the shape that summary was taken at
+        traffic, traffic_source = None, None
         try:
-            # newest committed PMC summary (tools/pmc_traffic.py; rocprofv3 --pmc passes of tools/gemm_bench)
             pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
-            pmc = json.loads(pmc_file.read_text())["kernels"]
-            traffic = pmc.get(rep["kernel"], {}).get("hbm_bytes_per_launch")
+            doc = json.loads(pmc_file.read_text())
+            if int(doc.get("rows", 8064)) == rows_per_launch and args.precision == "fp16":
+                traffic = doc["kernels"].get(rep["kernel"], {}).get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/{pmc_file.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                  f"tools/gemm_bench, same kernel and shape (M = {rows_per_launch}), not collected in this run")
+            else:
+                traffic_source = f"no committed counter summary for M = {rows_per_launch}, weights {args.precision}"
         except Exception:
             pass
         eng.profile_gemm(True)
@@ -251,38 +333,68 @@ def main():
         gemm_ms = sum(c["ms"] for c in classes)
         roof = {
             "bound": "mfma", "kernel": rep["kernel"], "shape": rep["shape"], "achieved": round(ach, 2),
-            "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+            "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "flops_per_launch": rep["flops"], "avg_launch_us": round(rep["avg_us"], 2), "launches": rep["launches"],
             "other_gemms": {eng.REPLAY_SHAPES[w]: round((lambda r: r["flops"] / (r["avg_us"] * 1e-6) / 1e12)(eng.replay_gemm(w, 50)), 1)
                             for w in (1, 2, 3, 4)},
             "all_gemm_in_situ_tflops": round(sum(c["flops"] for c in classes) / (gemm_ms * 1e-3) / 1e12, 2),
             "all_gemm_in_situ_ms_per_step": round(gemm_ms / nprof, 3),
-            "end_to_end_frac": round(value / world * FLOP_PER_UTT_10S * (args.seconds / 10.0) / 1e12 / PEAK_F16_TFLOPS, 5),
+            "end_to_end_frac": round(value / world * FLOP_PER_UTT_10S * (args.seconds / 10.0) * (3.0 if tta else 1.0) / 1e12 / PEAK_F16_TFLOPS, 5),
         }
+
+    post = None
+    if rank == 0 and not args.no_post_logits:
+        try:
+            post = post_logits_legs(eng, min(B, 64), min(126, eng.frames_for(cap)))
+        except Exception as e:
+            post = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(audio_np, args.cpu_sample)
+            cpu = cpu_baseline(audio_np, args.cpu_sample,
+                               f"{args.seconds:g} s clips" + (" (anchor pass only, no TTA copies)" if tta else ""))
         except Exception as e:  # the baseline leg must never take the GPU number down with it
             cpu = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"failed: {type(e).__name__}: {e}"}
 
     if rank == 0:
+        mixed = args.precision == "mixed"
+        wdesc = ("fp16 weights" if not mixed else
+                 "int4 (block-128) Linear + int8 (per-channel) pointwise-conv weights dequantised in the MFMA operand fetch, f16 activations")
+        if tta:
+            cfg_name = "BASELINE.json configs[4]" + ("" if world == 8 else f" workload on {world} GPU(s)")
+            workload = (f"c2c-direct-mixed-tta hot path, batch={B}/GPU synthetic {args.seconds:g} s/16 kHz clips: anchor pass, "
+                        "0.5 confidence gate, GPU 0.9x/1.1x speed-perturbed copies of the gated clips, majority / best-score "
+                        f"pick, {wdesc} ({cfg_name}); seeded random weights (real ONNX absent) gate every clip")
+        else:
+            if not mixed and B == 64 and args.seconds == 10.0 and world < 8:
+                cfg_name = "BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU, {world} GPUs")
+            elif mixed and B == 256 and world == 1:
+                cfg_name = "BASELINE.json configs[2]"
+            elif B == 256 and world == 8 and args.seconds == 10.0:
+                cfg_name = "BASELINE.json configs[3]: global batch 2048"
+            else:
+                cfg_name = "not a BASELINE.json configuration"
+            workload = (f"c2c-direct-mixed hot path, batch={B}/GPU synthetic {args.seconds:g} s/16 kHz clips, "
+                        f"FastConformer-CTC forward ({wdesc}) + greedy decode + verse retrieval + CTC rerank "
+                        f"({cfg_name}); seeded random weights (real ONNX absent)")
         out = {
-            "metric": "utterances/sec (10 s @16 kHz)", "value": round(value, 2), "unit": "utterances/s",
+            "metric": f"utterances/sec ({args.seconds:g} s @16 kHz{', TTA 0.9x/1.0x/1.1x' if tta else ''})",
+            "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if not mixed else "f16 (int4/int8 weights)",
             "data": "synthetic",
-            "config": {"workload": f"c2c-direct-mixed hot path, batch={B}/GPU synthetic {args.seconds:g} s/16 kHz clips, "
-                                   "fp16 FastConformer-CTC forward + greedy decode + verse retrieval + CTC rerank "
-                                   "(BASELINE.json configs[1]); seeded random weights (real ONNX absent)",
+            "config": {"workload": workload,
                        "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
                        "skip_unused_passes": not args.literal, "weights": args.precision,
-                       "batches_in_flight": args.contexts},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "batches_in_flight": 1 if tta else args.contexts},
+            "roofline": roof, "cpu_baseline": cpu, "post_logits": post,
         }
+        if tta:
+            out["config"]["tta_gated_fraction"] = round(tta_stats["gated"] / max(1, tta_stats["clips"]), 3)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

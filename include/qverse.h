@@ -73,7 +73,8 @@ typedef struct {
     int32_t with_model;         /* 0: post-logits stages only */
     int32_t precision;          /* QV_PREC_* */
     int32_t max_batch;          /* capacity: utterances per call */
-    int32_t max_samples;        /* capacity: samples per utterance (480000 = 30 s) */
+    int32_t max_samples;        /* capacity: samples per utterance (480000 = 30 s); at most 976,000 (61 s):
+                                   the CTC rerank holds 2L+1 <= T <= 768 states per candidate */
     /* CTC_DIRECT_* knobs, experiments/c2c-direct/run.py:62-74 (same defaults) */
     int32_t top_text;           /* CTC_DIRECT_TOP_TEXT        100 */
     int32_t top_span_refs;      /* CTC_DIRECT_TOP_SPAN_REFS    80 */
@@ -246,6 +247,15 @@ int qv_profile_gemm_read(qv_engine *e, double *ms14, double *flops14, int32_t *l
  * Returns the average launch duration in microseconds and the algorithmic FLOPs (2*M*N*K). */
 int qv_profile_replay_gemm(qv_engine *e, int32_t which, int32_t iters, double *avg_us, double *flops_per_launch,
                            void *stream);
+
+/* Stage timers -- the device-side counterpart of C2C_DIRECT_MIXED_PROFILE (experiments/c2c-direct-mixed/
+ * run.py:34,76-81,117-124: forward= decode= build= rerank= per file).  While enabled, every batch brackets
+ * its four stages with HIP events on the stream it runs on: forward (acoustic model), decode (argmax +
+ * greedy collapse + normalisation), build (match_verse / search / pass 3 / candidate assembly), rerank
+ * (CTC losses + decision).  qv_stage_times() waits for context `ctx`'s last batch (SYNCHRONOUS) and
+ * returns the four durations in milliseconds; a stage that did not run reports 0. */
+int qv_profile_stages(qv_engine *e, int32_t enable);
+int qv_stage_times(qv_engine *e, int32_t ctx, float *ms4_host);
 
 /* Host-only: block-128 symmetric int4 quantisation of one Linear weight w[N][K] (f32 row-major,
  * N % 64 == 0, K % 128 == 0) followed by the inverse of the device packing, i.e. the f32 matrix

@@ -349,7 +349,7 @@ static int alloc_work(qv_engine *eng, int k) {
     QV_TRY(dalloc(eng, Bz, &w.fail_list));
     QV_TRY(dalloc(eng, (size_t)1, &w.n_fail));
     QV_TRY(dalloc(eng, Bz, &eng->t_dev));
-    QV_HIP(hipHostMalloc((void **)&eng->t_host_scratch, sizeof(int32_t) * Bz, hipHostMallocDefault));
+    QV_HIP(hipHostMalloc((void **)&eng->t_host_scratch, sizeof(int32_t) * Bz * QV_STAGE_SLOTS, hipHostMallocDefault));
     eng->ctx[k].t_host_scratch = eng->t_host_scratch;  // owned by the context from here on
     eng->logprobs_ws = nullptr;
     if (eng->cfg.with_model) QV_TRY(dalloc(eng, Bz * w.t_cap * QV_VOCAB, &eng->logprobs_ws));
@@ -360,6 +360,11 @@ static int alloc_work(qv_engine *eng, int k) {
     c.t_dev = eng->t_dev;
     c.busy = false;
     c.last_batch = c.last_tmax = 0;
+    for (int i = 0; i < QV_STAGE_SLOTS; ++i) {
+        QV_HIP(hipEventCreateWithFlags(&c.t_copied[i], hipEventDisableTiming));
+        c.t_pending[i] = false;
+    }
+    c.t_slot = 0;
     if (eng->n_ctx > 1) {
         QV_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         QV_HIP(hipEventCreateWithFlags(&c.in_ready, hipEventDisableTiming));
@@ -380,11 +385,15 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     eng->last_batch = eng->last_tmax = 0;
     eng->n_ctx = cfg->n_contexts < 1 ? 1 : cfg->n_contexts;
     eng->cur_ctx = eng->next_ctx = 0;
+    eng->profile_stages = false;
     for (QvCtx &c : eng->ctx) {
         c = QvCtx();
         c.t_host_scratch = nullptr;
         c.stream = nullptr;
         c.in_ready = c.done = nullptr;
+        for (hipEvent_t &e : c.t_copied) e = nullptr;
+        for (hipEvent_t &e : c.stage_ev) e = nullptr;
+        c.stage_valid = false;
     }
     auto fail = [&](int rc) {
         g_create_error = eng->last_error;
@@ -396,6 +405,13 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     if (cfg->top_text < 1 || cfg->top_text > QV_RUNNER_CAP - 1) { qv_set_error(eng, "CTC_DIRECT_TOP_TEXT must be in [1,127]"); return fail(QV_ERR_ARG); }
     if (cfg->top_span_refs < 0 || cfg->top_span_refs > 128) { qv_set_error(eng, "CTC_DIRECT_TOP_SPAN_REFS must be in [0,128]"); return fail(QV_ERR_ARG); }
     if (cfg->max_batch < 1 || cfg->max_samples < 400) { qv_set_error(eng, "bad capacity"); return fail(QV_ERR_ARG); }
+    // the CTC rerank keeps a candidate's 2L+1 <= T states in one wave's registers: T <= 768 frames.  The
+    // reference has no such limit (c2c-direct/run.py:332 only asks 2L+1 <= T); refuse the capacity instead
+    // of silently dropping long candidates.
+    if (qv_frames_for_samples(cfg->max_samples) + 2 > 768) {
+        qv_set_error(eng, "max_samples above 976,000 (61 s) is not supported: the CTC rerank handles at most 768 encoder frames");
+        return fail(QV_ERR_CAPACITY);
+    }
     if (cfg->n_contexts > QV_MAX_CTX) { qv_set_error(eng, "n_contexts must be in [1,4]"); return fail(QV_ERR_ARG); }
     eng->knobs = {cfg->top_text, cfg->top_span_refs, cfg->max_span, cfg->threshold, cfg->text_weight,
                   cfg->span_penalty, cfg->skip_unused_passes};
@@ -439,6 +455,8 @@ extern "C" void qv_destroy(qv_engine *e) {
         if (c.stream) (void)hipStreamDestroy(c.stream);
         if (c.in_ready) (void)hipEventDestroy(c.in_ready);
         if (c.done) (void)hipEventDestroy(c.done);
+        for (hipEvent_t e2 : c.t_copied) if (e2) (void)hipEventDestroy(e2);
+        for (hipEvent_t e2 : c.stage_ev) if (e2) (void)hipEventDestroy(e2);
     }
     delete e;
 }
@@ -454,7 +472,36 @@ extern "C" int qv_forward(qv_engine *eng, const float *audio_dev, const int64_t 
 extern "C" int qv_decode_retrieve_rerank_async(qv_engine *eng, const float *lp, const int32_t *t_host, int32_t batch,
                                                int32_t t_max, void *stream) {
     if (!eng || !lp || !t_host || batch < 1) return QV_ERR_ARG;
+    qv_stage_mark(eng, 0, (hipStream_t)stream);   // no forward in this call: forward = 0
+    qv_stage_mark(eng, 1, (hipStream_t)stream);
     return qv_post_run(eng, lp, t_max, t_host, batch, (hipStream_t)stream);
+}
+
+void qv_stage_mark(qv_engine *eng, int i, hipStream_t s) {
+    if (!eng->profile_stages) return;
+    QvCtx &c = eng->ctx[eng->cur_ctx];
+    if (!c.stage_ev[i]) return;
+    if (i == 0) c.stage_valid = false;
+    if (hipEventRecord(c.stage_ev[i], s) == hipSuccess && i == 4) c.stage_valid = true;
+}
+
+extern "C" int qv_profile_stages(qv_engine *eng, int32_t enable) {
+    if (!eng) return QV_ERR_ARG;
+    if (enable)
+        for (int k = 0; k < eng->n_ctx; ++k)
+            for (hipEvent_t &e : eng->ctx[k].stage_ev)
+                if (!e) QV_HIP(hipEventCreate(&e));
+    eng->profile_stages = enable != 0;
+    return QV_OK;
+}
+
+extern "C" int qv_stage_times(qv_engine *eng, int32_t k, float *ms4) {
+    if (!eng || !ms4 || k < 0 || k >= eng->n_ctx) return QV_ERR_ARG;
+    QvCtx &c = eng->ctx[k];
+    if (!c.stage_valid) { qv_set_error(eng, "qv_stage_times: no profiled batch on this context (qv_profile_stages first)"); return QV_ERR_ARG; }
+    QV_HIP(hipEventSynchronize(c.stage_ev[4]));
+    for (int i = 0; i < 4; ++i) QV_HIP(hipEventElapsedTime(&ms4[i], c.stage_ev[i], c.stage_ev[i + 1]));
+    return QV_OK;
 }
 
 extern "C" int qv_fetch_results(qv_engine *eng, int32_t batch, int32_t t_max, qv_result *res, int32_t *greedy_host,
@@ -508,9 +555,11 @@ extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, co
         QV_HIP(hipStreamWaitEvent(c.stream, c.in_ready, 0));
         run = c.stream;
     }
+    qv_stage_mark(eng, 0, run);
     int rc = qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, eng->logprobs_ws, t_max,
                               t_out.data(), run);
     if (rc) return rc;
+    qv_stage_mark(eng, 1, run);
     rc = qv_post_run(eng, eng->logprobs_ws, t_max, t_out.data(), batch, run);
     if (rc) return rc;
     if (eng->n_ctx > 1) {

@@ -184,20 +184,33 @@ int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out_dev
 int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s);
 
 void qv_model_select_ctx(QvModel *m, int k);
+// records stage event `i` of the current context on `s` when stage profiling is on (qv_capi.hip)
+void qv_stage_mark(qv_engine *eng, int i, hipStream_t s);
 
 // One execution context = everything a batch in flight owns (activations live in QvModel).
 // With n_ctx > 1, qv_predict_batch_async() round-robins the contexts, each on its own internal
 // stream, so the latency-bound post-logits kernels of one batch run under the forward of the next.
 #define QV_MAX_CTX 4
+// Pinned staging buffers (frame counts here, the model's length table in QvActs) are written by the host
+// and then read by an asynchronous H2D copy: each has QV_STAGE_SLOTS slots used in turn, and a slot is
+// reused only after the event recorded behind its copy has completed -- back-to-back asynchronous calls
+// on one context (n_contexts = 1 included) never overwrite lengths a queued copy has yet to read.
+#define QV_STAGE_SLOTS 2
 struct QvCtx {
     QvWork work;
     float *logprobs_ws;
-    int32_t *t_host_scratch;
+    int32_t *t_host_scratch;   // [QV_STAGE_SLOTS][max_batch] pinned
     int32_t *t_dev;
     hipStream_t stream;
     hipEvent_t in_ready, done;
     bool busy;
     int last_batch, last_tmax;
+    hipEvent_t t_copied[QV_STAGE_SLOTS];
+    bool t_pending[QV_STAGE_SLOTS];
+    int t_slot;
+    // stage timers (qv_profile_stages): start, forward done, decode done, build done, rerank done
+    hipEvent_t stage_ev[5];
+    bool stage_valid;
 };
 
 struct qv_engine {
@@ -220,6 +233,7 @@ struct qv_engine {
     struct Fir { int up; std::vector<float> taps; float *hflip_dev; int P; };
     std::vector<Fir> firs;
     QvTrack track;
+    bool profile_stages;
     // host copies of small table parts used by debug/entry code
     std::vector<uint8_t> h_surah;
     std::vector<uint16_t> h_ayah;

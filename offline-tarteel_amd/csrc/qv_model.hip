@@ -200,7 +200,10 @@ struct QvActs {
     half_t *c0, *c1, *c1p, *c2, *c2p, *c2k, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
     int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3; then [max_batch + 1] packed row offsets
     int32_t *row_map;    // [M] utterance << 16 | frame of every packed row (written by k_pack_rows)
-    int32_t *lens_host;  // pinned
+    int32_t *lens_host;  // pinned, QV_STAGE_SLOTS slots of [6 * max_batch + 1] (see QvCtx)
+    hipEvent_t lens_copied[QV_STAGE_SLOTS];
+    bool lens_pending[QV_STAGE_SLOTS];
+    int lens_slot, lens_last;   // next slot to fill; slot of the last forward (qv_model_tap reads its offsets)
     float *tap_x;        // [N_LAYERS+1][M][512] when save_taps
     int last_batch, last_tmax, last_tm_max, last_rows;
 };
@@ -506,8 +509,15 @@ int alloc_context(qv_engine *eng, QvModel *m, int k, bool sub_unfused) {
     TRY(dal(eng, m, M * HEAD_N, &m->logits));
     TRY(dal(eng, m, Bz * 6 + 1, &m->lens_dev));
     TRY(dal(eng, m, M, &m->row_map));
-    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * (Bz * 6 + 1), hipHostMallocDefault));
+    QV_HIP(hipHostMalloc((void **)&m->lens_host, sizeof(int32_t) * (Bz * 6 + 1) * QV_STAGE_SLOTS, hipHostMallocDefault));
     m->ctx_acts[k].lens_host = m->lens_host;  // owned by the context from here on
+    for (int i = 0; i < QV_STAGE_SLOTS; ++i) {
+        m->lens_copied[i] = nullptr;
+        QV_HIP(hipEventCreateWithFlags(&m->lens_copied[i], hipEventDisableTiming));
+        m->ctx_acts[k].lens_copied[i] = m->lens_copied[i];
+        m->lens_pending[i] = false;
+    }
+    m->lens_slot = m->lens_last = 0;
     m->tap_x = nullptr;
     if (m->save_taps) TRY(dal(eng, m, (size_t)(N_LAYERS + 1) * M * QV_D, &m->tap_x));
     m->last_batch = m->last_tmax = m->last_tm_max = m->last_rows = 0;
@@ -546,7 +556,11 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     m->cur_ctx = 0;
     const char *su = getenv("QVERSE_SUB_UNFUSED");
     const bool sub_unfused = su && su[0] == '1';
-    for (QvActs &a : m->ctx_acts) { a = QvActs(); a.lens_host = nullptr; }
+    for (QvActs &a : m->ctx_acts) {
+        a = QvActs();
+        a.lens_host = nullptr;
+        for (hipEvent_t &e : a.lens_copied) e = nullptr;
+    }
     // contexts are allocated last to first so that the flat fields end up being context 0
     for (int k = m->n_ctx - 1; k >= 0; --k) TRY(alloc_context(eng, m, k, sub_unfused));
     return QV_OK;
@@ -555,8 +569,10 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
 void qv_model_destroy(QvModel *m) {
     if (!m) return;
     for (void *p : m->allocs) (void)hipFree(p);
-    for (QvActs &a : m->ctx_acts)
+    for (QvActs &a : m->ctx_acts) {
         if (a.lens_host) (void)hipHostFree(a.lens_host);
+        for (hipEvent_t e : a.lens_copied) if (e) (void)hipEventDestroy(e);
+    }
     delete m;
 }
 
@@ -565,7 +581,9 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     if (batch < 1 || batch > m->max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
     int B = batch, MB = m->max_batch;
     int tm_max = 0, t1m = 0, t2m = 0, t3m = 0, rows = 0;
-    int32_t *lh = m->lens_host;
+    const int slot = m->lens_slot;
+    if (m->lens_pending[slot]) { QV_HIP(hipEventSynchronize(m->lens_copied[slot])); m->lens_pending[slot] = false; }
+    int32_t *lh = m->lens_host + (size_t)slot * (MB * 6 + 1);
     for (int b = 0; b < B; ++b) {
         int64_t n = len_host[b];
         if (n < 400 || n > n_max || n / 160 + 1 > m->tm_cap) {
@@ -589,6 +607,10 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     const int M = rows;
     const int t_pad = (T + 31) / 32 * 32;
     QV_HIP(hipMemcpyAsync(m->lens_dev, lh, sizeof(int32_t) * (MB * 6 + 1), hipMemcpyHostToDevice, s));
+    QV_HIP(hipEventRecord(m->lens_copied[slot], s));
+    m->lens_pending[slot] = true;
+    m->lens_last = slot;
+    m->lens_slot = (slot + 1) % QV_STAGE_SLOTS;
     const int32_t *d_n = m->lens_dev, *d_tm = d_n + MB, *d_l1 = d_n + 2 * MB, *d_l2 = d_n + 3 * MB, *d_l3 = d_n + 4 * MB,
                   *d_off = d_n + 5 * MB;
     const half_t *posp = nullptr;
@@ -722,7 +744,7 @@ int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hi
         const int T = m->last_tmax;
         QV_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)m->last_batch * T * QV_D, s));
         for (int b = 0; b < m->last_batch; ++b) {
-            const int32_t *off = m->lens_host + 5 * m->max_batch;   // offsets of this context's last forward
+            const int32_t *off = m->lens_host + (size_t)m->lens_last * (m->max_batch * 6 + 1) + 5 * m->max_batch;   // this context's last forward
             int r0 = off[b], n = off[b + 1] - r0;
             QV_HIP(hipMemcpyAsync(out + (size_t)b * T * QV_D, m->tap_x + ((size_t)idx * M + r0) * QV_D,
                                   sizeof(float) * (size_t)n * QV_D, hipMemcpyDeviceToDevice, s));

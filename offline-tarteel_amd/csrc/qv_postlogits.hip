@@ -1504,19 +1504,31 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
         qv_set_error(eng, "batch or frame count exceeds engine capacity");
         return QV_ERR_CAPACITY;
     }
-    for (int b = 0; b < batch; ++b) {
+    for (int b = 0; b < batch; ++b)
         if (t_host[b] < 0 || t_host[b] > t_max) { qv_set_error(eng, "t_host[b] out of range"); return QV_ERR_ARG; }
-        eng->t_host_scratch[b] = t_host[b];
+    {
+        // pinned staging slot: wait for the copy that last read it (two calls ago), never for the stream
+        QvCtx &c = eng->ctx[eng->cur_ctx];
+        const int slot = c.t_slot;
+        c.t_slot = (slot + 1) % QV_STAGE_SLOTS;
+        if (c.t_pending[slot]) { QV_HIP(hipEventSynchronize(c.t_copied[slot])); c.t_pending[slot] = false; }
+        int32_t *th = eng->t_host_scratch + (size_t)slot * wk.max_batch;
+        for (int b = 0; b < batch; ++b) th[b] = t_host[b];
+        QV_HIP(hipMemcpyAsync(eng->t_dev, th, sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
+        QV_HIP(hipEventRecord(c.t_copied[slot], stream));
+        c.t_pending[slot] = true;
     }
-    QV_HIP(hipMemcpyAsync(eng->t_dev, eng->t_host_scratch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);
     hipLaunchKernelGGL(k_argmax, dim3(t_max, batch), dim3(64), 0, stream, lp, t_max, wk.utt, wk.frame_ids, wk.t_cap);
     hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);
+    qv_stage_mark(eng, 2, stream);
     int rc = launch_retrieval(eng, batch, 0, stream);
     if (rc) return rc;
+    qv_stage_mark(eng, 3, stream);
     if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
     else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
     hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
+    qv_stage_mark(eng, 4, stream);
     QV_HIP(hipGetLastError());
     eng->last_batch = batch;
     eng->last_tmax = t_max;

@@ -107,6 +107,8 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_gemm.argtypes = [vp, i32]
     lib.qv_profile_gemm_read.argtypes = [vp, vp, vp, vp]
     lib.qv_profile_replay_gemm.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.qv_profile_stages.argtypes = [vp, i32]
+    lib.qv_stage_times.argtypes = [vp, i32, vp]
     _lib = lib
     return lib
 
@@ -352,6 +354,19 @@ class Engine:
                 out.append({"kernel": f"k_gemm<{self.GEMM_EPILOGUES[c // 2]},{128 if c % 2 else 64}>",
                             "ms": float(ms[c]), "flops": float(fl[c]), "launches": int(n[c])})
         return out
+
+    def profile_stages(self, enable: bool):
+        """device-side stage timers (the reference's C2C_DIRECT_MIXED_PROFILE split, mixed/run.py:117-124)"""
+        self._check(self.lib.qv_profile_stages(self.h, int(enable)), "qv_profile_stages")
+
+    def stage_times(self, ctx: int | None = None) -> dict:
+        """seconds spent in forward / decode / build / rerank by the last batch of context `ctx`
+        (default: the most recent call's); waits for that batch."""
+        if ctx is None:
+            ctx = int(self.lib.qv_last_context(self.h))
+        ms = np.zeros(4, np.float32)
+        self._check(self.lib.qv_stage_times(self.h, ctx, ms.ctypes.data_as(C.c_void_p)), "qv_stage_times")
+        return {k: float(v) * 1e-3 for k, v in zip(("forward", "decode", "build", "rerank"), ms)}
 
     REPLAY_KERNELS = ["k_gemm<f16_swish,128>", "k_gemm<resid,64>", "k_gemm<qkv,128>", "k_gemm<resid,64>", "k_gemm<glu,128>"]
     REPLAY_SHAPES = ["FFN-up [M,512]x[512,2048]+Swish", "FFN-down [M,2048]x[2048,512]+residual", "QKV [M,512]x[512,1536]",

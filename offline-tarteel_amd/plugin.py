@@ -30,6 +30,7 @@ MAX_SAMPLES = int(os.getenv("QVERSE_MAX_SAMPLES", str(16000 * 60)))
 MAX_BATCH = int(os.getenv("QVERSE_MAX_BATCH", "16"))
 
 _engine = None
+_last_raw: list[dict] = []   # engine-level dicts of the most recent predict_arrays() call (profile line)
 
 
 def weights_path() -> Path | None:
@@ -55,6 +56,8 @@ def _ensure_engine():
     print(f"[c2c-direct-mixed/qverse] loading {'synthetic weights' if wp is None else wp.name} on cuda:{device}...")
     _engine = Engine(device=device, with_model=True, weights_path=str(wp) if wp else None,
                      max_batch=MAX_BATCH, max_samples=MAX_SAMPLES)
+    if _PROFILE:
+        _engine.profile_stages(True)
     return _engine
 
 
@@ -86,7 +89,9 @@ def predict_arrays(arrays, round_score: bool = True) -> list[dict]:
         for i, a in enumerate(chunk):
             buf[i, : len(a)] = a
         dev = torch.from_numpy(buf).cuda(eng.device)
-        out.extend(_to_dict(r, round_score) for r in eng.predict_batch(dev, lens))
+        raw = eng.predict_batch(dev, lens)
+        _last_raw[:] = raw
+        out.extend(_to_dict(r, round_score) for r in raw)
     return out
 
 
@@ -100,9 +105,24 @@ def predict(audio_path: str) -> dict:
     t1 = time.perf_counter()
     res = predict_arrays([audio])[0]
     if _PROFILE:
+        # the reference's line (mixed/run.py:76-81,117-124): forward= decode= build= rerank= total=
+        # candidates= use_ctc= source= -- stage times from HIP events around the device stages of this
+        # file's batch of one; `forward` includes the audio load like the reference's _ctc_logprobs does
         t2 = time.perf_counter()
-        print(f"[c2c-direct-mixed profile] audio={Path(audio_path).name} load={t1 - t0:.3f}s "
-              f"device={t2 - t1:.3f}s total={t2 - t0:.3f}s source={res.get('source')}")
+        st = _ensure_engine().stage_times()
+        raw = _last_raw[0] if _last_raw else {}
+        head = f"[c2c-direct-mixed profile] audio={Path(audio_path).name} "
+        fwd = (t1 - t0) + st["forward"]
+        if not res.get("transcript", "").strip():
+            print(head + f"forward={fwd:.3f}s decode={st['decode']:.3f}s total={t2 - t0:.3f}s empty=1")
+        elif not res["surah"]:
+            print(head + f"forward={fwd:.3f}s decode={st['decode']:.3f}s build={st['build']:.3f}s "
+                         f"total={t2 - t0:.3f}s no_candidates=1")
+        else:
+            use_ctc = int(bool(raw.get("use_ctc")))
+            print(head + f"forward={fwd:.3f}s decode={st['decode']:.3f}s build={st['build']:.3f}s "
+                         f"rerank={st['rerank'] if use_ctc else 0.0:.3f}s total={t2 - t0:.3f}s "
+                         f"candidates={raw.get('n_candidates', 0)} use_ctc={use_ctc} source={res.get('source')}")
     return res
 
 
@@ -147,31 +167,46 @@ def _tta_combine(p09: dict, anchor: dict, p11: dict) -> dict:
     return best
 
 
-def predict_tta_arrays(arrays) -> list[dict]:
-    """c2c-direct-mixed-tta/run.py:117-149 for a list of clips: one anchor pass over all of them,
-    gate 0.5, then the 0.9x / 1.1x copies of the gated clips -- made on the GPU (qv_upfirdn,
-    bit-identical to the reference's scipy.signal.resample_poly call) -- as further engine batches
-    (the reference runs them as two threads on one session)."""
-    import torch
-
-    eng = _ensure_engine()
-    anchors = predict_arrays(arrays, round_score=False)
+def tta_device_batch(eng, audio, lengths, want_text: bool = True) -> list[dict]:
+    """c2c-direct-mixed-tta/run.py:117-149 for one batch already in HBM (float32 cuda [B, N], zero
+    padded): anchor pass over every clip, gate 0.5 on the UNROUNDED score, then the 0.9x / 1.1x copies of
+    the gated clips -- made on the GPU (qv_upfirdn, bit-identical to the reference's
+    scipy.signal.resample_poly call) -- as further engine batches (the reference runs them as two
+    threads on one session), and the majority / best-score rule."""
+    torch = eng.torch
+    anchors = [_to_dict(r, False) for r in eng.predict_batch(audio, lengths, want_text=want_text)]
     hard = [i for i, a in enumerate(anchors) if a["score"] < CONFIDENCE_SKIP_THRESHOLD]
     out = list(anchors)
     per_call = max(1, eng.max_batch // 2)
-    for s in range(0, len(hard), per_call):
-        idx = hard[s: s + per_call]
+    for s0 in range(0, len(hard), per_call):
+        idx = hard[s0: s0 + per_call]
         variants = []
         for i in idx:
-            dev = torch.from_numpy(np.ascontiguousarray(arrays[i], dtype=np.float32)).cuda(eng.device)
-            variants += [eng.speed_perturb(dev, 0.9), eng.speed_perturb(dev, 1.1)]
+            clip = audio[i, : lengths[i]].contiguous()
+            variants += [eng.speed_perturb(clip, 0.9), eng.speed_perturb(clip, 1.1)]
         lens = [int(v.numel()) for v in variants]
-        rows = torch.zeros((len(variants), max(lens)), dtype=torch.float32, device=variants[0].device)
+        rows = torch.zeros((len(variants), max(lens)), dtype=torch.float32, device=audio.device)
         for r, v in enumerate(variants):
             rows[r, : v.numel()] = v
-        res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens)]
+        res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens, want_text=want_text)]
         for k, i in enumerate(idx):
             out[i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
+    return out
+
+
+def predict_tta_arrays(arrays) -> list[dict]:
+    """tta_device_batch for a list of host clips (one engine batch per <= MAX_BATCH clips)."""
+    import torch
+
+    eng = _ensure_engine()
+    out = []
+    for s0 in range(0, len(arrays), eng.max_batch):
+        chunk = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays[s0: s0 + eng.max_batch]]
+        lens = [len(a) for a in chunk]
+        buf = np.zeros((len(chunk), max(lens)), dtype=np.float32)
+        for i, a in enumerate(chunk):
+            buf[i, : len(a)] = a
+        out.extend(tta_device_batch(eng, torch.from_numpy(buf).cuda(eng.device), lens))
     return out
 
 

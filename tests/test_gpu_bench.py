@@ -31,6 +31,25 @@ def test_bench_single_process_contract():
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["roofline"]["bound"] == "mfma"
     assert 0 < d["roofline"]["frac"] < 1
+    # HBM traffic is quoted from a committed counter summary only for the shape it was taken at (M = 8064)
+    assert d["roofline"]["traffic"] is None and "no committed counter summary" in d["roofline"]["traffic_source"]
+    assert d["dtype"] == "f16" and "not a BASELINE.json configuration" in d["config"]["workload"]
+    # the verse-shaped replay legs: every transcript passes the text gate / every one fails it
+    pl = d["post_logits"]
+    assert pl["gate_pass"]["use_ctc_fraction"] == 0.0 and pl["gate_fail"]["use_ctc_fraction"] == 1.0
+    assert pl["gate_fail"]["ms_per_batch"] > pl["gate_pass"]["ms_per_batch"] > 0
+
+
+def test_bench_tta30_workload_small():
+    """--workload tta30 (BASELINE configs[4]) at a reduced size: anchor pass, gate, GPU-resampled copies,
+    decision rule; seeded random weights gate every clip."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tta30", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--seconds", "6", "--no-cpu-baseline", "--no-post-logits"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert "TTA" in d["metric"] and d["config"]["tta_gated_fraction"] == 1.0 and d["value"] > 0
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["batches_in_flight"] == 1
 
 
 def test_bench_under_torchrun_with_collective_path():

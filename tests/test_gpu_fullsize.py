@@ -90,3 +90,49 @@ def test_int4_batch_256_is_batch_size_invariant():
             assert [key(r) for r in part] == big[64 * k: 64 * (k + 1)]
     finally:
         eng.close()
+
+
+def test_configs3_rank_slices_256x10s_through_shard_plan():
+    """BASELINE configs[3] (8 GPUs, global batch 2048): the slices two of the eight ranks would process --
+    256 clips each, taken from a ragged 2048-clip batch by dist.shard_plan -- run at full size on this GPU;
+    every clip's packed row must equal the row the clip gets in a small batch of its own (the path is
+    batch-invariant), and un-permuting the slices through the all-gather's bookkeeping puts each row at its
+    original position."""
+    from offline_tarteel_amd import dist as qdist
+    from offline_tarteel_amd.engine import Engine
+
+    world, G, per = 8, 2048, 256
+    rng = np.random.default_rng(2048)
+    lengths = (160000 - 1280 * rng.integers(0, 40, size=G)).astype(np.int64)     # 6.8 .. 10 s
+    order, slices = qdist.shard_plan(lengths, world)
+    assert len(order) == G and all(s.stop - s.start == per for s in slices)
+    base = synth_audio(64, N)
+
+    def clip(i):   # utterance i of the global batch: one of 64 base clips, scaled, cut to its length
+        a = base[i % 64] * np.float32(1.0 - 0.004 * (i // 64))
+        a[lengths[i]:] = 0
+        return a
+
+    eng = Engine(device=0, with_model=True, seed=20260630, max_batch=per, max_samples=N)
+    try:
+        gathered = np.zeros((G, 4), np.int32)
+        have = np.zeros(G, bool)
+        for r in (0, 5):
+            idx = order[slices[r]].tolist()
+            lens = [int(lengths[i]) for i in idx]
+            assert lens == sorted(lens, reverse=True)           # length-sorted inside the shard
+            audio = torch.from_numpy(np.stack([clip(i) for i in idx])).cuda()
+            res = eng.predict_batch(audio, lens, want_text=False)
+            packed = qdist.pack_results(res)
+            for k, i in enumerate(idx):
+                gathered[i] = packed[k]
+                have[i] = True
+            # spot check: 6 clips of this slice on their own
+            sub = [0, 31, 100, 177, 254, 255]
+            alone = eng.predict_batch(audio[sub].contiguous(), [lens[k] for k in sub], want_text=False)
+            assert qdist.pack_results(alone).tolist() == packed[sub].tolist(), r
+        assert have.sum() == 2 * per
+        un = qdist.unpack_results(gathered[have])
+        assert all(u["surah"] >= 0 for u in un)
+    finally:
+        eng.close()

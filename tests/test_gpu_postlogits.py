@@ -141,6 +141,44 @@ def test_end_to_end_fixtures_batched(engine, oracle, e2e_cases):
                 assert r["n_candidates"] == c["n_candidates"], c["name"]
 
 
+def test_per_candidate_ctc_losses_of_the_fixtures(engine, e2e_cases):
+    """The reference's whole per-candidate `ctc_loss` vector (F.ctc_loss, float32) and its ranking, for every
+    e2e fixture: the candidates' token ids (table lookups of the fixture's (surah, ayah, ayah_end) keys) go
+    through the rerank kernel's recursion (qv_debug_ctc_loss) on the fixture's log-probs.  Infeasible
+    candidates (2L+1 > T) are the ones the fixture records as null."""
+    tb = engine.tables
+    checked = 0
+    for c in e2e_cases:
+        if "cand_keys" not in c or not c["cand_keys"]:
+            continue
+        lp = lp_of(c["recipe"])
+        T = lp.shape[0]
+        starts = [tb.verse_index(s, a) for s, a, _ in c["cand_keys"]]
+        spans = [e - a + 1 for _, a, e in c["cand_keys"]]
+        ids = [tb.token_ids(st, sp) for st, sp in zip(starts, spans)]
+        feas = [i for i, x in enumerate(ids) if len(x) > 0 and 2 * len(x) + 1 <= T]
+        assert feas == [i for i, w in enumerate(c["ctc_loss"]) if w is not None], c["name"]
+        # the reference records the target length of the candidates it scored (0 for the gated-out ones)
+        assert [len(ids[i]) if i in set(feas) else 0 for i in range(len(ids))] == c["ctc_len"], c["name"]
+        if not feas:
+            continue
+        got = engine.debug_ctc_loss(lp.cuda().contiguous(), [ids[i] for i in feas])
+        want = np.array([c["ctc_loss"][i] for i in feas], np.float64)
+        assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max() / 100), (c["name"], np.abs(got - want).max())
+        # ranking: final = -loss / len - 0.5 * (span - 1), stable in candidate order (c2c-direct/run.py:366-379)
+        final = [-(float(g) / len(ids[i])) - 0.5 * (spans[i] - 1) for g, i in zip(got, feas)]
+        order = sorted(range(len(feas)), key=lambda k: -final[k])
+        top = [c["cand_keys"][feas[k]] for k in order[:20]]
+        gaps_ok = all(abs(a - b) > 2e-3 for a, b in zip(c["ranked_final"][:-1], c["ranked_final"][1:]))
+        if gaps_ok:
+            assert top == c["ranked_keys"], c["name"]
+        else:
+            assert top[0] == c["ranked_keys"][0] and sorted(map(tuple, top)) == sorted(map(tuple, c["ranked_keys"])), c["name"]
+        assert np.allclose([final[k] for k in order[:20]], c["ranked_final"], atol=2e-3), c["name"]
+        checked += 1
+    assert checked >= 6
+
+
 def test_long_transcripts_T376_vs_oracle(oracle):
     """30 s worth of frames: long verse prefixes (transcripts of several hundred characters ->
     multi-word bit-vectors, windows on both sides, CTC targets with > 256 states)."""
