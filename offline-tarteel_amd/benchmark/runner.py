@@ -130,7 +130,23 @@ def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int 
         except Exception as e:
             print(f"  Error on {[s['id'] for s in group]}: {e}")
             emissions, elapsed = [[] for _ in group], 0.0
-        for sample, em in zip(group, emissions):
+            if use_batch and len(group) > 1:
+                # one undecodable / over-long file must not empty the whole group: the reference isolates
+                # failures per sample (runner.py:297-325), so the group is retried file by file
+                emissions, per_file = [], []
+                for path in paths:
+                    try:
+                        t0 = time.perf_counter()
+                        emissions.append(predict_to_emissions(mod.predict(path)))
+                        per_file.append(time.perf_counter() - t0)
+                    except Exception as e1:
+                        print(f"  Error on {Path(path).name}: {e1}")
+                        emissions.append([])
+                        per_file.append(0.0)
+                elapsed = per_file
+        if not isinstance(elapsed, list):
+            elapsed = [elapsed] * len(group)
+        for (sample, em), elapsed in zip(zip(group, emissions), elapsed):
             expected = sample.get("expected_verses", [{"surah": sample["surah"], "ayah": sample["ayah"]}])
             sc = score_sequence(expected, em)
             for k in tot:

@@ -68,6 +68,34 @@ def test_runner_records_empty_prediction_on_plugin_error(tmp_path, monkeypatch):
     assert latest[0]["name"] == "c2c-direct-mixed" and latest[0]["source_file"] == p.name
 
 
+def test_runner_batch_group_failure_falls_back_to_per_file(tmp_path):
+    """--batch N: one bad file makes predict_batch raise for the whole group; the runner then retries
+    file by file so that only the offending sample is recorded as empty (the reference isolates failures
+    per sample, runner.py:297-325)."""
+    from offline_tarteel_amd.benchmark import runner
+
+    corpus = tmp_path / "corpus"
+    corpus.mkdir()
+    samples = [{"id": f"s{i}", "file": f"s{i}.wav", "surah": 1, "ayah": i + 1, "category": "short"} for i in range(3)]
+    for s in samples:
+        (corpus / s["file"]).write_bytes(b"RIFF")
+    (corpus / "manifest.json").write_text(json.dumps({"samples": samples}))
+    plug = tmp_path / "run.py"
+    plug.write_text(
+        "def predict(p):\n"
+        "    if p.endswith('s1.wav'): raise ValueError('undecodable')\n"
+        "    a = int(p[-5]) + 1\n"
+        "    return {'surah': 1, 'ayah': a, 'ayah_end': a, 'score': 1.0}\n"
+        "def predict_batch(ps):\n"
+        "    return [predict(p) for p in ps]\n"
+        "def model_size():\n    return 0\n")
+    res = runner.run_experiment({"name": "grp", "run_path": plug, "model_name": None}, samples, corpus, batch=3)
+    got = {r["id"]: r for r in res["per_sample"]}
+    assert got["s0"]["recall"] == 1.0 and got["s2"]["recall"] == 1.0
+    assert got["s1"]["predicted"] == [] and got["s1"]["latency"] == 0.0
+    assert abs(res["recall"] - 2 / 3) < 1e-12
+
+
 def test_runner_transcribe_only_experiment_both_modes(tmp_path, oracle):
     """An experiment without predict() goes through StreamingPipeline, as in the reference's runner
     (runner.py:309-321): chunked in streaming mode, run_on_full_transcript otherwise; the mode shows

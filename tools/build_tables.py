@@ -79,6 +79,15 @@ def main():
     ap.add_argument("--quran", default="/root/reference/data/quran.json")
     ap.add_argument("--tokenizer", default="/root/reference/web/frontend/public/tokenizer.model")
     ap.add_argument("--out", default=str(offline_tarteel_amd.TABLES_PATH))
+    ap.add_argument("--emit-json", default="",
+                    help='also write the upstream token-table artefact quran_ctc_tokens.json: "surah:ayah:ayah_end" -> ids')
+    ap.add_argument("--json-max-span", type=int, default=6,
+                    help="ayat per span in the JSON.  6 reproduces the upstream counts exactly (35,717 keys, 29,481 "
+                         "multi-ayah spans, PLAN.md:102) and equals CTC_DIRECT_MAX_SPAN; PLAN.md:121-124's prose says "
+                         "'max span length 5', which would give 30,043 keys")
+    ap.add_argument("--json-span-text", choices=("plan", "hot-path"), default="plan",
+                    help='plan: spans are " ".join(text_clean) as PLAN.md:102 specifies the upstream file; '
+                         "hot-path: the first ayah loses its bismillah like c2c-direct/run.py:235-248 (= the binary table)")
     args = ap.parse_args()
 
     import sentencepiece as spm
@@ -152,6 +161,30 @@ def main():
             total += len(ids)
             tok_off[i * MAX_SPAN + k] = total
     tok = np.array(toks, dtype=np.uint16)
+
+    if args.emit_json:
+        # The browser runtime's precomputed table (web/frontend/src/worker/quran-text-adapter.ts:16-31,
+        # lib/quran-db.ts:718-719; upstream file quran_ctc_tokens.json, a missing blob in the reference tree):
+        # key "surah:ayah:ayah_end" (single verses: ayah_end = ayah) -> SentencePiece ids of the text tokenised
+        # ONCE as joined text, spans of at most --json-max-span ayat inside one surah (PLAN.md:102-103,121-124).
+        table = {}
+        for i in range(N):
+            s_no, a_no = int(surah[i]), int(ayah[i])
+            last = surah_start[s_no - 1] + surah_len[s_no - 1] - 1
+            for k in range(1, args.json_max_span + 1):
+                if i + k - 1 > last:
+                    break
+                if k == 1:
+                    text = clean[i]
+                elif args.json_span_text == "plan":
+                    text = " ".join(clean[j] for j in range(i, i + k))
+                else:
+                    text = " ".join([nobsm[i] or clean[i]] + [clean[j] for j in range(i + 1, i + k)])
+                table[f"{s_no}:{a_no}:{a_no + k - 1}"] = [int(t) for t in sp.encode_as_ids(text)]
+        n_multi = sum(1 for key in table if key.split(":")[1] != key.split(":")[2])
+        Path(args.emit_json).write_text(json.dumps(table, separators=(",", ":")), encoding="utf-8")
+        print(f"wrote {args.emit_json}: {len(table)} keys ({n_multi} multi-ayah spans, max span {args.json_max_span}, "
+              f"span text: {args.json_span_text}), {Path(args.emit_json).stat().st_size} B")
 
     # ---- vocabulary pieces -------------------------------------------------------
     V = sp.get_piece_size()

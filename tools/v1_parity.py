@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""v1-corpus parity of the drop-in plugins against the reference's published per-sample outputs.
+
+    QVERSE_WEIGHTS=/path/to/weights.qvwt python tools/v1_parity.py --corpus /path/to/benchmark/test_corpus \
+        [--experiment c2c-direct-mixed | c2c-direct-mixed-tta] [--batch 1] [--score-slack 1e-2] [--out report.json]
+
+Runs this repo's runner (offline-tarteel_amd/benchmark/runner.py, the reference's CLI and scoring) on the
+53-sample v1 manifest and compares every row with tests/golden/v1_expected.json (the reference's
+benchmark/results/2026-06-28_135450.json / ..._135603.json): the predicted (surah, ayah) emission list must
+be identical and the score within --score-slack (the reference rounds to 4 dp; north_star allows 1e-2 on
+the CTC log-probs behind it).  Exit status 0 = every comparable row agrees, 1 = a row differs, 77 = nothing
+could be compared (no weight file or no corpus): the acoustic model's parity stays UNPINNED until this
+command has been run green on a machine that holds the reference's weight file, converted with
+tools/convert_weights.py, and the corpus audio (mp3 / m4a rows need a decoder this repo does not ship and
+are reported as skipped).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+GOLDEN = ROOT / "tests" / "golden" / "v1_expected.json"
+SKIP = 77
+
+
+def compare_rows(expected_doc: dict, experiment: str, result: dict, score_slack: float) -> dict:
+    """result = one entry of the runner's result list.  Returns the report (no I/O)."""
+    key = "mixed" if experiment == "c2c-direct-mixed" else "tta"
+    got = {s["id"]: s for s in result["per_sample"]}
+    rows, bad, skipped = [], 0, 0
+    for s in expected_doc["samples"]:
+        want = s[key]["predicted"]
+        if s["id"] not in got:
+            rows.append({"id": s["id"], "status": "skipped (audio file not in the corpus directory)"})
+            skipped += 1
+            continue
+        g = got[s["id"]]
+        if g.get("latency", 0.0) == 0.0 and not g["predicted"] and want:
+            # the runner's error convention (empty prediction, latency 0.0): undecodable file or engine error
+            rows.append({"id": s["id"], "status": "skipped (predict raised: undecodable audio or capacity)"})
+            skipped += 1
+            continue
+        same_keys = [(p["surah"], p["ayah"]) for p in g["predicted"]] == [(p["surah"], p["ayah"]) for p in want]
+        dscore = max((abs(a["score"] - b["score"]) for a, b in zip(g["predicted"], want)), default=0.0) if same_keys else None
+        ok = same_keys and dscore <= score_slack
+        bad += 0 if ok else 1
+        rows.append({"id": s["id"], "status": "ok" if ok else "DIFFERS", "predicted": g["predicted"], "reference": want,
+                     "max_score_delta": dscore})
+    compared = len(rows) - skipped
+    return {"experiment": experiment, "compared": compared, "skipped": skipped, "differing": bad,
+            "recall": result["recall"], "reference_recall": expected_doc["summary"][experiment]["recall"],
+            "score_slack": score_slack, "rows": rows}
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--corpus", default=os.getenv("QVERSE_CORPUS_DIR", ""))
+    ap.add_argument("--experiment", default="c2c-direct-mixed", choices=("c2c-direct-mixed", "c2c-direct-mixed-tta"))
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--score-slack", type=float, default=1e-2)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args(argv)
+    expected = json.loads(GOLDEN.read_text(encoding="utf-8"))
+    wp = os.getenv("QVERSE_WEIGHTS", "")
+    if not wp or not Path(wp).exists():
+        print("v1_parity: SKIPPED -- QVERSE_WEIGHTS does not name a weight file (convert the reference's "
+              "fastconformer_full_mixed.onnx or the .nemo checkpoint with tools/convert_weights.py)")
+        return SKIP
+    corpus = Path(args.corpus) if args.corpus else None
+    if corpus is None or not (corpus / "manifest.json").exists():
+        print("v1_parity: SKIPPED -- --corpus / QVERSE_CORPUS_DIR must point at the reference's benchmark/test_corpus")
+        return SKIP
+    import offline_tarteel_amd  # noqa: F401
+    from offline_tarteel_amd.benchmark import runner
+
+    samples = runner.load_manifest(corpus)
+    (exp,) = runner.discover_experiments(args.experiment)
+    result = runner.run_experiment(exp, samples, corpus, batch=args.batch)
+    report = compare_rows(expected, args.experiment, result, args.score_slack)
+    for r in report["rows"]:
+        if r["status"] != "ok":
+            print(f"  {r['id']:<24} {r['status']}" + (f"  got {r['predicted']}  want {r['reference']}" if r["status"] == "DIFFERS" else ""))
+    print(f"v1_parity {args.experiment}: {report['compared'] - report['differing']}/{report['compared']} rows agree, "
+          f"{report['skipped']} skipped; recall {report['recall']:.4f} (reference {report['reference_recall']:.4f})")
+    if args.out:
+        Path(args.out).write_text(json.dumps(report, indent=1, ensure_ascii=False) + "\n")
+    if report["compared"] == 0:
+        return SKIP
+    return 0 if report["differing"] == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
