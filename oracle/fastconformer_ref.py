@@ -208,6 +208,102 @@ def quantize_linear_weights(w: dict[str, torch.Tensor]) -> dict[str, torch.Tenso
     return out
 
 
+# ------------------------------------------------------------------- onnxruntime semantics ----
+# What the reference's model file actually computes (experiments/c2c-direct-mixed/run.py:1-9: "step 1
+# MatMulNBitsQuantizer int4 on the MatMul weights, step 2 quantize_dynamic QInt8 on what remains", run by
+# onnxruntime's CPU provider with fp32 activations).  [EXT / UNPINNED like everything in this file: the model
+# file and onnxruntime are absent; the rules below restate onnxruntime's published operator definitions.]
+#   com.microsoft.MatMulNBits (bits 4, block 128, symmetric, zero point 8): y = x @ ((q - 8) * scale)^T with
+#       FLOAT32 scales and fp32 accumulation -- the device path keeps the scale in fp16 (5e-4 relative).
+#   DynamicQuantizeLinear + ConvInteger (what quantize_dynamic makes of a Conv): the ACTIVATION tensor of the
+#       call is quantised to uint8 with one scale / zero point (range widened to include 0, round half to
+#       even, saturate), the weight is int8 with one per-tensor symmetric scale, the convolution accumulates
+#       in int32 and the result is scaled back by scale_x * scale_w and biased in fp32.
+# `OrtMixed` carries the choice of which tensors get which treatment; forward(..., ort=OrtMixed()) routes
+# every Linear / Conv of the model through it.  This is the yardstick for "how far is the HIP mixed path
+# (W4A16 / W8A16: weights dequantised, fp16 activations, no activation quantisation) from the arithmetic the
+# reference ran" -- tests/test_gpu_forward.py reports the max |delta log-prob|.
+ORT_INT4_SUFFIXES = INT4_LINEAR_SUFFIXES + ("encoder.pre_encode.out.weight",)
+
+
+def quant_dequant_int4_f32scale(w2d: np.ndarray, block: int = 128) -> np.ndarray:
+    """as quant_dequant_int4 but with the block scale kept in float32 (MatMulNBits on an fp32 model)."""
+    w2d = np.ascontiguousarray(w2d, dtype=np.float32)
+    N, K = w2d.shape
+    assert K % block == 0
+    wb = w2d.reshape(N, K // block, block)
+    idx = np.abs(wb).argmax(-1)
+    vmax = np.take_along_axis(wb, idx[..., None], -1)[..., 0]
+    scale = (vmax / np.float32(-8.0)).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        rs = np.where(scale != 0, np.float32(1.0) / scale, np.float32(0.0)).astype(np.float32)
+    q = np.clip(np.floor((wb * rs[..., None]).astype(np.float32) + np.float32(8.5)), 0, 15).astype(np.float32)
+    return ((q - np.float32(8.0)) * scale[..., None]).astype(np.float32).reshape(N, K)
+
+
+def dynamic_quantize_linear(x: torch.Tensor):
+    """onnx DynamicQuantizeLinear: (x_q as integer-valued float64, scale, zero_point) of one tensor."""
+    xmin = min(0.0, float(x.min()))
+    xmax = max(0.0, float(x.max()))
+    scale = np.float32((xmax - xmin) / 255.0)
+    if scale == 0:
+        return torch.zeros_like(x, dtype=torch.float64), np.float32(1.0), 0.0
+    zp = float(np.clip(np.round(np.float32(0.0 - xmin) / scale), 0, 255))           # np.round: half to even
+    xq = torch.clamp(torch.round(x / float(scale)) + zp, 0, 255).to(torch.float64)   # torch.round: half to even
+    return xq, scale, zp
+
+
+class OrtMixed:
+    """Routing of the model's Linear / Conv calls through the onnxruntime arithmetic above."""
+
+    def __init__(self, int4_linears: bool = True, int8_convs="all"):
+        self.int4_linears = int4_linears
+        self.int8_convs = int8_convs          # "all", or a tuple of weight-name suffixes, or ()
+        self._w4 = {}
+        self._w8 = {}
+
+    def _is_conv8(self, name: str) -> bool:
+        return self.int8_convs == "all" or (bool(self.int8_convs) and name.endswith(tuple(self.int8_convs)))
+
+    def linear(self, w, name: str, x: torch.Tensor, bias_name: str | None):
+        wt = w[name]
+        if self.int4_linears and name.endswith(ORT_INT4_SUFFIXES):
+            if name not in self._w4:
+                self._w4[name] = torch.from_numpy(quant_dequant_int4_f32scale(wt.numpy()))
+            wt = self._w4[name]
+        return F.linear(x, wt, w[bias_name] if bias_name else None)
+
+    def conv(self, w, name: str, x: torch.Tensor, bias_name: str | None, fn, **kw):
+        """fn = F.conv1d / F.conv2d.  Quantisation is per CALL of the reference, i.e. per utterance (it
+        feeds batch 1): every batch item gets its own activation scale."""
+        wt = w[name]
+        bias = w[bias_name] if bias_name else None
+        if not self._is_conv8(name):
+            return fn(x, wt, bias, **kw)
+        if name not in self._w8:
+            amax = float(wt.abs().max())
+            sw = np.float32(amax / 127.0) if amax > 0 else np.float32(1.0)
+            self._w8[name] = (torch.clamp(torch.round(wt / float(sw)), -127, 127).to(torch.float64), sw)
+        wq, sw = self._w8[name]
+        outs = []
+        for b in range(x.shape[0]):
+            xq, sx, zp = dynamic_quantize_linear(x[b: b + 1])
+            acc = fn(xq - zp, wq, None, **kw)                       # exact: integer-valued float64
+            y = (acc * float(np.float32(sx) * np.float32(sw))).to(torch.float32)
+            outs.append(y + bias.view(1, -1, *([1] * (y.dim() - 2))) if bias is not None else y)
+        return torch.cat(outs, 0)
+
+
+class _Plain:
+    """fp32 routing (the default): plain F.linear / conv."""
+
+    def linear(self, w, name, x, bias_name):
+        return F.linear(x, w[name], w[bias_name] if bias_name else None)
+
+    def conv(self, w, name, x, bias_name, fn, **kw):
+        return fn(x, w[name], w[bias_name] if bias_name else None, **kw)
+
+
 # ------------------------------------------------------------------- front-end --------
 def mel_filterbank() -> np.ndarray:
     """librosa.filters.mel(sr=16000, n_fft=512, n_mels=80, fmin=0, fmax=8000, htk=False,
@@ -296,7 +392,7 @@ def rel_shift(x: torch.Tensor) -> torch.Tensor:
     return x[:, :, 1:].view(b, h, qlen, pos_len)
 
 
-def subsampling(w, feats: torch.Tensor, tm: torch.Tensor):
+def subsampling(w, feats: torch.Tensor, tm: torch.Tensor, ops=None):
     """feats [B,80,Tm] -> [B,T,512]; activations past each stage's valid length are zeroed so a
     padded batch equals the per-utterance (unpadded) result."""
     x = feats.transpose(1, 2).unsqueeze(1)  # [B,1,Tm,80]
@@ -307,43 +403,45 @@ def subsampling(w, feats: torch.Tensor, tm: torch.Tensor):
         m = (torch.arange(T)[None, :] < lens[:, None]).to(x.dtype)
         return x * m[:, None, :, None]
 
+    ops = ops or _Plain()
+    pe = "encoder.pre_encode."
     x = mask_t(x, lens)
-    x = F.relu(F.conv2d(x, w["encoder.pre_encode.conv.0.weight"], w["encoder.pre_encode.conv.0.bias"], stride=2, padding=1))
+    x = F.relu(ops.conv(w, pe + "conv.0.weight", x, pe + "conv.0.bias", F.conv2d, stride=2, padding=1))
     lens = (lens + 2 - 3) // 2 + 1
     x = mask_t(x, lens)
     for dw, pw in ((2, 3), (5, 6)):
-        x = F.conv2d(x, w[f"encoder.pre_encode.conv.{dw}.weight"], w[f"encoder.pre_encode.conv.{dw}.bias"], stride=2,
-                     padding=1, groups=SUB_CH)
-        x = F.relu(F.conv2d(x, w[f"encoder.pre_encode.conv.{pw}.weight"], w[f"encoder.pre_encode.conv.{pw}.bias"]))
+        x = ops.conv(w, f"{pe}conv.{dw}.weight", x, f"{pe}conv.{dw}.bias", F.conv2d, stride=2, padding=1, groups=SUB_CH)
+        x = F.relu(ops.conv(w, f"{pe}conv.{pw}.weight", x, f"{pe}conv.{pw}.bias", F.conv2d))
         lens = (lens + 2 - 3) // 2 + 1
         x = mask_t(x, lens)
     b, c, t, f = x.shape
     x = x.transpose(1, 2).reshape(b, t, c * f)
-    x = F.linear(x, w["encoder.pre_encode.out.weight"], w["encoder.pre_encode.out.bias"])
+    x = ops.linear(w, pe + "out.weight", x, pe + "out.bias")
     return x, lens
 
 
-def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torch.Tensor):
+def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torch.Tensor, ops=None):
     """x [B,T,512]; pad [B,T] True where padded."""
     B, T, _ = x.shape
+    ops = ops or _Plain()
 
     def ln(name, t):
         return F.layer_norm(t, (D_MODEL,), w[p + name + ".weight"], w[p + name + ".bias"], 1e-5)
 
     def ffn(name, t):
-        t = F.linear(t, w[p + name + ".linear1.weight"], w[p + name + ".linear1.bias"])
+        t = ops.linear(w, p + name + ".linear1.weight", t, p + name + ".linear1.bias")
         t = t * torch.sigmoid(t)
-        return F.linear(t, w[p + name + ".linear2.weight"], w[p + name + ".linear2.bias"])
+        return ops.linear(w, p + name + ".linear2.weight", t, p + name + ".linear2.bias")
 
     r = x
     r = r + 0.5 * ffn("feed_forward1", ln("norm_feed_forward1", r))
     # --- rel-pos MHSA
     y = ln("norm_self_att", r)
     a = p + "self_attn."
-    q = F.linear(y, w[a + "linear_q.weight"], w[a + "linear_q.bias"]).view(B, T, N_HEADS, D_K)
-    k = F.linear(y, w[a + "linear_k.weight"], w[a + "linear_k.bias"]).view(B, T, N_HEADS, D_K).transpose(1, 2)
-    v = F.linear(y, w[a + "linear_v.weight"], w[a + "linear_v.bias"]).view(B, T, N_HEADS, D_K).transpose(1, 2)
-    pp = F.linear(pos_emb, w[a + "linear_pos.weight"]).view(1, -1, N_HEADS, D_K).transpose(1, 2)
+    q = ops.linear(w, a + "linear_q.weight", y, a + "linear_q.bias").view(B, T, N_HEADS, D_K)
+    k = ops.linear(w, a + "linear_k.weight", y, a + "linear_k.bias").view(B, T, N_HEADS, D_K).transpose(1, 2)
+    v = ops.linear(w, a + "linear_v.weight", y, a + "linear_v.bias").view(B, T, N_HEADS, D_K).transpose(1, 2)
+    pp = ops.linear(w, a + "linear_pos.weight", pos_emb, None).view(1, -1, N_HEADS, D_K).transpose(1, 2)
     qu = (q + w[a + "pos_bias_u"]).transpose(1, 2)
     qv = (q + w[a + "pos_bias_v"]).transpose(1, 2)
     bd = rel_shift(torch.matmul(qv, pp.transpose(-2, -1)))
@@ -355,32 +453,33 @@ def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torc
     scores = scores.masked_fill(att_mask[:, None], -10000.0)
     attn = torch.softmax(scores, dim=-1).masked_fill(att_mask[:, None], 0.0)
     ctx = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, D_MODEL)
-    r = r + F.linear(ctx, w[a + "linear_out.weight"], w[a + "linear_out.bias"])
+    r = r + ops.linear(w, a + "linear_out.weight", ctx, a + "linear_out.bias")
     # --- conv module
     y = ln("norm_conv", r).transpose(1, 2)
     c = p + "conv."
-    y = F.conv1d(y, w[c + "pointwise_conv1.weight"], w[c + "pointwise_conv1.bias"])
+    y = ops.conv(w, c + "pointwise_conv1.weight", y, c + "pointwise_conv1.bias", F.conv1d)
     y = F.glu(y, dim=1)
     y = y.masked_fill(pad[:, None, :], 0.0)
-    y = F.conv1d(y, w[c + "depthwise_conv.weight"], w[c + "depthwise_conv.bias"], padding=(CONV_K - 1) // 2, groups=D_MODEL)
+    y = ops.conv(w, c + "depthwise_conv.weight", y, c + "depthwise_conv.bias", F.conv1d, padding=(CONV_K - 1) // 2, groups=D_MODEL)
     y = F.batch_norm(y, w[c + "batch_norm.running_mean"], w[c + "batch_norm.running_var"], w[c + "batch_norm.weight"],
                      w[c + "batch_norm.bias"], False, 0.0, 1e-5)
     y = y * torch.sigmoid(y)
-    y = F.conv1d(y, w[c + "pointwise_conv2.weight"], w[c + "pointwise_conv2.bias"]).transpose(1, 2)
+    y = ops.conv(w, c + "pointwise_conv2.weight", y, c + "pointwise_conv2.bias", F.conv1d).transpose(1, 2)
     r = r + y
     r = r + 0.5 * ffn("feed_forward2", ln("norm_feed_forward2", r))
     return ln("norm_out", r)
 
 
 @torch.no_grad()
-def forward(w, audio: torch.Tensor, lengths, n_layers: int = N_LAYERS, taps: dict | None = None):
+def forward(w, audio: torch.Tensor, lengths, n_layers: int = N_LAYERS, taps: dict | None = None, ort: OrtMixed | None = None):
     """audio [B,N] float32, lengths -> (log_probs [B,T,1025], T lengths).  taps (optional dict)
-    receives intermediate activations: 'mel' [B,Tm,80], 'sub' [B,T,512], 'layer{i}' [B,T,512]."""
+    receives intermediate activations: 'mel' [B,Tm,80], 'sub' [B,T,512], 'layer{i}' [B,T,512].
+    ort: route every Linear / Conv through the onnxruntime int4 / dynamic-int8 arithmetic (OrtMixed)."""
     lengths = torch.as_tensor(lengths, dtype=torch.int64)
     feats, tm = frontend(audio, lengths)
     if taps is not None:
         taps["mel"] = feats.transpose(1, 2).contiguous()
-    x, lens = subsampling(w, feats, tm)
+    x, lens = subsampling(w, feats, tm, ort)
     if taps is not None:
         taps["sub"] = x.clone()
     B, T, _ = x.shape
@@ -388,8 +487,12 @@ def forward(w, audio: torch.Tensor, lengths, n_layers: int = N_LAYERS, taps: dic
     pos_emb = rel_pos_emb(T).unsqueeze(0)
     pad = torch.arange(T)[None, :] >= lens[:, None]
     for i in range(n_layers):
-        x = conformer_layer(w, f"encoder.layers.{i}.", x, pos_emb, pad)
+        x = conformer_layer(w, f"encoder.layers.{i}.", x, pos_emb, pad, ort)
         if taps is not None:
             taps[f"layer{i}"] = x.clone()
-    logits = F.linear(x, w["ctc_decoder.decoder_layers.0.weight"].squeeze(-1), w["ctc_decoder.decoder_layers.0.bias"])
+    head = "ctc_decoder.decoder_layers.0."
+    if ort is not None:   # ConvASRDecoder is a 1x1 Conv1d in the exported graph
+        logits = ort.conv(w, head + "weight", x.transpose(1, 2), head + "bias", F.conv1d).transpose(1, 2)
+    else:
+        logits = F.linear(x, w[head + "weight"].squeeze(-1), w[head + "bias"])
     return torch.log_softmax(logits, dim=-1), lens
