@@ -323,6 +323,18 @@ def main():
                 traffic_source = f"no committed counter summary for M = {rows_per_launch}, weights {args.precision}"
         except Exception:
             pass
+        # MFMA utilisation inside the kernel from the committed SQ counter pass (clock-independent: matrix-pipe
+        # busy cycles / SIMD cycles the kernel lasted); likewise quoted, not measured here
+        mfma_util, mfma_source = None, None
+        try:
+            mf = sorted((ROOT / "profiles").glob("r*_mfma_busy.json"))[-1]
+            doc = json.loads(mf.read_text())
+            if int(doc.get("rows", 0)) == rows_per_launch and args.precision == "fp16":
+                mfma_util = doc["kernels"].get(rep["kernel"], {}).get("mfma_util")
+                mfma_source = (f"profiles/{mf.name}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32) over "
+                               f"tools/gemm_bench at M = {rows_per_launch}, not collected in this run")
+        except Exception:
+            pass
         eng.profile_gemm(True)
         nprof = max(2, min(args.steps, 5))
         for _ in range(nprof):
@@ -334,6 +346,7 @@ def main():
         roof = {
             "bound": "mfma", "kernel": rep["kernel"], "shape": rep["shape"], "achieved": round(ach, 2),
             "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "mfma_util_pmc": mfma_util, "mfma_util_source": mfma_source,
             "flops_per_launch": rep["flops"], "avg_launch_us": round(rep["avg_us"], 2), "launches": rep["launches"],
             "other_gemms": {eng.REPLAY_SHAPES[w]: round((lambda r: r["flops"] / (r["avg_us"] * 1e-6) / 1e12)(eng.replay_gemm(w, 50)), 1)
                             for w in (1, 2, 3, 4)},

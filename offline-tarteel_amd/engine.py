@@ -18,6 +18,18 @@ from .normalizer import normalize_arabic
 from .tables import Tables
 
 QV_SOURCE = {0: None, 1: "text", 2: "ctc"}
+QV_MAX_TRANSCRIPT = 1024   # include/qverse.h: characters the device matchers hold per text
+
+
+def front_window(text: str, limit: int = QV_MAX_TRANSCRIPT) -> str:
+    """The longest whole-word prefix of `text` that fits the device's matching window.  The reference's
+    single-text matchers (QuranDB.match_verse behind run_on_full_transcript, VerseTracker._find_best_match)
+    take texts of any length; both match -- and then peel -- the FRONT of the text, so a longer text is
+    matched on its first `limit` characters instead of being refused (documented difference)."""
+    if len(text) <= limit:
+        return text
+    cut = text.rfind(" ", 0, limit + 1)
+    return text[:cut] if cut > 0 else text[:limit]
 FLAG_EMPTY, FLAG_TRUNC, FLAG_USED_CTC, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
 
 
@@ -401,6 +413,7 @@ class Engine:
         if n == 0:
             return []
         last_refs = last_refs or [None] * n
+        texts = [front_window(t) for t in texts]   # > 1,024 characters: matched on the front window
         enc = [self.tables.encode(t) for t in texts]
         off = np.zeros(n + 1, np.int32)
         off[1:] = np.cumsum([len(e) for e in enc])
@@ -450,7 +463,7 @@ class Engine:
         text = normalize_arabic(text)
         if not text.strip():
             return None
-        codes = np.ascontiguousarray(self.tables.encode(text))
+        codes = np.ascontiguousarray(self.tables.encode(front_window(text)))
         bon = self.continuation_bonuses(hint)
         bv = np.ascontiguousarray(np.array([b[0] for b in bon] + [0] * (3 - len(bon)), np.int32))
         bb = np.ascontiguousarray(np.array([b[1] for b in bon] + [0.0] * (3 - len(bon)), np.float64))

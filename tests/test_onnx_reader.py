@@ -239,3 +239,43 @@ def test_constant_nodes_gemm_and_anonymous_conv_operands(tmp_path):
     assert np.array_equal(sd[L + "self_attn.linear_q.weight"], wq) and np.array_equal(sd[L + "self_attn.linear_q.bias"], bq)
     assert np.array_equal(sd[L + "conv.depthwise_conv.weight"], dw) and np.array_equal(sd[L + "conv.depthwise_conv.bias"], db)
     assert np.array_equal(sd[L + "norm_conv.weight"], g)
+
+
+def test_dynamic_quantised_conv_with_bias_behind_add_and_valueless_attribute(tmp_path):
+    """What onnxruntime's quantize_dynamic leaves of a biased Conv under a real export's node naming
+    (/encoder/layers.N/...): ConvInteger on an int8 weight -> Cast -> Mul(scale) -> Add(anonymous bias).
+    The weight is found under '<scope>.weight', the bias by following the consumer chain to the Add.
+    Also: an attribute serialised without a value (proto3 drops transB = 0) parses as the scalar 0."""
+    C = _load("convert_weights")
+    R = _load("onnx_reader")
+    rng = np.random.default_rng(5)
+    D = 8
+    L = "encoder.layers.3."
+    shapes = {L + "conv.pointwise_conv2.weight": (D, D, 1), L + "conv.pointwise_conv2.bias": (D,),
+              L + "feed_forward1.linear1.weight": (D, D), L + "feed_forward1.linear1.bias": (D,)}
+    wq = rng.integers(-127, 128, size=(D, D, 1)).astype(np.int8)
+    scale = np.float32(0.013)
+    bias = rng.normal(size=D).astype(np.float32)
+    gw, gb = rng.normal(size=(D, D)).astype(np.float32), rng.normal(size=D).astype(np.float32)
+    scope = "/encoder/layers.3/conv/pointwise_conv2/"
+    valueless = ld(1, b"transB") + key(20, 0) + vint(2)            # AttributeProto{name, type=INT}, i omitted
+    nodes = [
+        node("DynamicQuantizeLinear", scope + "DQL", ["h"], ["h_q", "h_s", "h_z"]),
+        node("ConvInteger", scope + "Conv_quant", ["h_q", "pw2_quantized", "h_z", "pw2_zero_point"], ["acc"]),
+        node("Cast", scope + "Cast", ["acc"], ["acc_f"]),
+        node("Mul", scope + "Mul", ["acc_f", "mul_scales"], ["scaled"]),
+        node("Add", scope + "Add", ["scaled", "onnx::Add_77"], ["out"]),
+        node("Gemm", "/encoder/layers.3/feed_forward1/linear1/Gemm", ["x", "onnx::Gemm_5", "onnx::Gemm_6"], ["y"], [valueless]),
+    ]
+    inits = [tensor("pw2_quantized", wq), tensor("pw2_scale", np.array([scale], np.float32)),
+             tensor("pw2_zero_point", np.zeros(1, np.int8)), tensor("mul_scales", np.array([0.5], np.float32)),
+             tensor("onnx::Add_77", bias.reshape(1, D, 1)), tensor("onnx::Gemm_5", gw.T.copy()), tensor("onnx::Gemm_6", gb)]
+    p = tmp_path / "dq.onnx"
+    p.write_bytes(model(nodes, inits))
+    ns, _ = R.read_model(str(p))
+    assert [n for n in ns if n.op == "Gemm"][0].attrs["transB"] == 0
+    sd = C.onnx_state_dict(str(p), shapes, verbose=False)
+    assert np.array_equal(sd[L + "conv.pointwise_conv2.weight"], wq.astype(np.float32) * scale)
+    assert np.array_equal(sd[L + "conv.pointwise_conv2.bias"], bias)
+    # Gemm without transB holds [in, out]: transposed to the state-dict's [out, in]
+    assert np.array_equal(sd[L + "feed_forward1.linear1.weight"], gw) and np.array_equal(sd[L + "feed_forward1.linear1.bias"], gb)

@@ -143,7 +143,9 @@ def _parse_attr(buf: bytes):
         elif num == 8:
             ints += _packed_varints(wt, v)
     if val is None:
-        val = ints if ints else floats
+        # repeated fields, or -- when nothing at all was serialised (proto3 omits default values, so
+        # `transB = 0` arrives as a bare name) -- the scalar default 0, which int() / float() accept
+        val = ints if ints else (floats if floats else 0)
     return name, val
 
 
@@ -263,9 +265,29 @@ def float_weights(nodes, inits):
                 continue
             zp = inits.get(n.inputs[3]) if len(n.inputs) > 3 and n.inputs[3] else inits.get(base + "_zero_point")
             w = dequant_linear(inits[n.inputs[1]], scale, zp, 0 if n.op == "ConvInteger" else 1)
-            keys = {base} | ({scope} if scope else set())
+            keys = {base} | ({scope, scope + ".weight"} if scope else set())
             for key in keys:
                 out[key] = (w if n.op == "ConvInteger" else w.T, n.op + (" (transposed to [out, in])" if n.op != "ConvInteger" else ""))
+            # the bias of a dynamically quantised Conv / MatMul is an anonymous initializer added AFTER the
+            # integer op and its rescaling: ConvInteger -> Cast -> Mul(scales) -> Add(bias).  Follow the single-
+            # consumer chain of cheap elementwise nodes to that Add and name its constant operand.
+            if scope:
+                cur, hops = n.outputs[0], 0
+                while hops < 6:
+                    users = [m for m in nodes if cur in m.inputs]
+                    if len(users) != 1:
+                        break
+                    u = users[0]
+                    if u.op == "Add":
+                        other = [i for i in u.inputs if i != cur]
+                        if other and other[0] in inits and np.asarray(inits[other[0]]).dtype in (np.float32, np.float16, np.float64):
+                            b = np.asarray(inits[other[0]], np.float32).reshape(-1)
+                            if b.size == w.shape[0] or (n.op == "MatMulInteger" and b.size == w.shape[1]):
+                                out[scope + ".bias"] = (b, f"bias added behind {n.op} (Add operand named by the node scope)")
+                        break
+                    if u.op not in ("Cast", "Mul", "Reshape", "Identity"):
+                        break
+                    cur, hops = u.outputs[0], hops + 1
         elif n.op == "MatMul" and scope and len(n.inputs) > 1 and n.inputs[1] in out and n.inputs[1] not in _named(out):
             out[scope] = (out[n.inputs[1]][0].T, "MatMul operand [in, out] transposed to [out, in]")
     return out

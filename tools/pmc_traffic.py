@@ -66,10 +66,14 @@ def mfma(argv):
              "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU_MFMA_MOPS_F16", "GRBM_GUI_ACTIVE"]
     per = {n: mean_by_kernel(path, n) for n in names}
     out = {"method": "rocprofv3 --pmc (one SQ pass, no tracing besides --kernel-trace) on tools/gemm_bench at "
-                     f"M = {rows}; counters are summed over the chip per launch and averaged over launches.  "
-                     "mfma_busy_of_sq_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES * 4 SIMDs per CU ... as exported "
-                     "by this rocprofv3: both are chip sums of per-SIMD resp. per-SQ cycle counts, see DESIGN.md); "
-                     "the wave-cycle split (issue / parked / stalled) is the one MI355X_MICROARCH.md describes.",
+                     f"M = {rows}; counters are chip sums per launch, averaged over launches.  "
+                     "SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles per SIMD (= 32 x the number of "
+                     "v_mfma_f32_32x32x16_f16 issued); SQ_BUSY_CYCLES is summed over the 32 shader engines, so the "
+                     "kernel lasted SQ_BUSY_CYCLES / 32 shader cycles and the chip's 1024 SIMDs offered "
+                     "SQ_BUSY_CYCLES * 32 matrix-pipe cycles: mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES * 32) "
+                     "(clock-independent; the TFLOP/s-over-2.5-PF figure of bench.py is the same quantity times actual "
+                     "clock / 2.4 GHz).  The wave-cycle split (parked at s_waitcnt / s_barrier, issue-stalled, issuing) "
+                     "is the one MI355X_MICROARCH.md describes (quad-cycles).",
            "rows": rows, "kernels": {}}
     kernels = set()
     for d in per.values():
@@ -86,9 +90,9 @@ def mfma(argv):
                            ("SQ_ACTIVE_INST_ANY", "frac_wave_cycles_issuing")):
                 if n in e:
                     row[key] = round(e[n] / wc, 4)
-        if e.get("SQ_VALU_MFMA_BUSY_CYCLES") and e.get("GRBM_GUI_ACTIVE"):
-            # chip MFMA capacity in the kernel's own duration: 256 CUs x 4 SIMDs x GUI-active cycles
-            row["mfma_busy_frac_of_capacity"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 1024.0), 4)
+        if e.get("SQ_VALU_MFMA_BUSY_CYCLES") and e.get("SQ_BUSY_CYCLES"):
+            row["kernel_shader_cycles"] = round(e["SQ_BUSY_CYCLES"] / 32.0, 1)
+            row["mfma_util"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["SQ_BUSY_CYCLES"] * 32.0), 4)
         out["kernels"].setdefault(short, row)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
