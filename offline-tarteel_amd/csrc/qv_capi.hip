@@ -291,6 +291,17 @@ static int load_tables(qv_engine *eng, const char *path) {
     const uint32_t *to = (const uint32_t *)blob.get("tok_off");
     QV_TRY(upload(eng, to, (size_t)N * QV_MAX_SPAN + 1, &t.tok_off));
     QV_TRY(upload(eng, (const uint16_t *)blob.get("tok"), (size_t)to[(size_t)N * QV_MAX_SPAN], &t.tok));
+    {   // prefix flags of the token table (see QvTables::tok_pfx)
+        const uint16_t *tk = (const uint16_t *)blob.get("tok");
+        std::vector<uint8_t> pfx(N, 0);
+        for (int v = 0; v < N; ++v)
+            for (int k = 1; k < QV_MAX_SPAN; ++k) {
+                const uint32_t a0 = to[(size_t)v * QV_MAX_SPAN + k - 1], a1 = to[(size_t)v * QV_MAX_SPAN + k], b1 = to[(size_t)v * QV_MAX_SPAN + k + 1];
+                const uint32_t la = a1 - a0, lb = b1 - a1;
+                if (la > 0 && lb >= la && memcmp(tk + a0, tk + a1, sizeof(uint16_t) * la) == 0) pfx[v] |= (uint8_t)(1u << (k - 1));
+            }
+        QV_TRY(upload(eng, pfx.data(), pfx.size(), &t.tok_pfx));
+    }
     const uint32_t *po = (const uint32_t *)blob.get("piece_off");
     QV_TRY(upload(eng, po, (size_t)QV_VOCAB + 1, &t.piece_off));
     QV_TRY(upload(eng, (const uint8_t *)blob.get("piece_codes"), (size_t)po[QV_VOCAB] + 16, &t.piece_codes));
@@ -342,6 +353,8 @@ static int alloc_work(qv_engine *eng, int k) {
     QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_start));
     QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_span));
     QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_score));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_lead));
+    QV_TRY(dalloc(eng, Bz * QV_CAND_CAP * QV_MAX_SPAN, &w.cand_memb));
     QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_loss));
     QV_TRY(dalloc(eng, Bz * QV_CAND_CAP, &w.cand_final));
     QV_TRY(dalloc(eng, Bz, &w.results));

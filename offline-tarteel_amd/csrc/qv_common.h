@@ -78,6 +78,10 @@ struct QvTables {
     // CTC token table: key = v*6 + (span-1)
     const uint32_t *tok_off;     // [N*6+1]
     const uint16_t *tok;
+    // bit k-1 of tok_pfx[v]: the ids of (v, span k) are a PREFIX of the ids of (v, span k+1) (SentencePiece
+    // segments word by word, so a span's ids normally extend the shorter span's; not so where the first ayah
+    // loses its bismillah in a span).  Built at qv_create; lets k_ctc share one alpha recursion between them.
+    const uint8_t *tok_pfx;      // [N]
     // vocabulary pieces: normalised code strings
     const uint32_t *piece_off;   // [1026]
     const uint8_t *piece_codes;
@@ -100,6 +104,7 @@ struct QvUtt {           // one per utterance, device memory (SoA would not buy 
     double base_score;
     int32_t use_ctc;
     int32_t n_cand;
+    int32_t n_lead;        // candidates that run an alpha recursion (k_candidates' plan for k_ctc)
     int32_t win;           // winning candidate index or -1
     float win_norm;
     // match_verse with a continuation hint and without the trigram restriction (qv_match_verse;
@@ -135,6 +140,8 @@ struct QvWork {
     int32_t *cand_start;     // [B][QV_CAND_CAP]
     int32_t *cand_span;      // [B][QV_CAND_CAP]
     double *cand_score;      // [B][QV_CAND_CAP]
+    int16_t *cand_lead;      // [B][QV_CAND_CAP] list of the leaders' candidate indices (first n_lead entries)
+    int16_t *cand_memb;      // [B][QV_CAND_CAP][QV_MAX_SPAN] per leader: candidate index of its (start, span k) prefix, -1 = none
     float *cand_loss;        // [B][QV_CAND_CAP]
     double *cand_final;      // [B][QV_CAND_CAP]
     qv_result *results;      // [B]

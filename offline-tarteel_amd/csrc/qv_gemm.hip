@@ -28,9 +28,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 
 #ifdef QV_GEMM_TRACE
 #define QV_ABL(bit) (g.abl & (bit))
+#define QV_PHASE(slot) do { if (g.phase && tid == 0) g.phase[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = wall_clock64(); } while (0)
 #define QV_TRACE(slot) do { if (g.trace && lane == 0 && (wave & 3) == 0) g.trace[(((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 64 + kt_) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define QV_ABL(bit) false
+#define QV_PHASE(slot) do { } while (0)
 #define QV_TRACE(slot) do { } while (0)
 #endif
 
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QV_PHASE(0);
     const bool loader = wave >= 4;
     const int w4 = wave & 3;                     // index inside the consumer / loader group
     const int wm = w4 >> 1, wn = w4 & 1;
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         QV_TRACE(2);                           // arriving at barrier kt (K-step kt - 1 computed)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (kt == 0) QV_PHASE(1);
         QV_TRACE(0);                           // barrier kt released
         const half_t *sA = (const half_t *)(smem + (kt % NST) * STAGE_BYTES);
         const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         mma(f1);
     }
     __syncthreads();  // every wave is done with the operand stages before the epilogue reuses them
+    QV_PHASE(2);
 #if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
     if (QV_ABL(32)) {   // no epilogue at all (accumulators kept live)
 #pragma unroll
@@ -435,6 +440,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                 if (bt1 >= 0) vt[((size_t)(bt1 >> 16) * QV_D + drow) * g.t_pad + (bt1 & 0xFFFF)] = v1;
             }
         }
+        QV_PHASE(3);
         return;
     }
 
@@ -501,6 +507,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
             if (QV_ABL(16)) { asm volatile("" ::"v"(v)); continue; }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, ((m0 + r) * g.ldo + n0 + c) * 4, 0, 0);
         }
+        QV_PHASE(3);
         return;
     }
 
@@ -561,6 +568,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
             if (QV_ABL(16)) { asm volatile("" ::"v"(*(const half8 *)(sO + r * LDT + c))); continue; }
             __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(sO + r * LDT + c), rs_out16, ((m0 + r) * g.ldo + n0o + c) * 2, 0, 0);
         }
+        QV_PHASE(3);
     }
 }
 

@@ -66,6 +66,7 @@ struct GemmArgs {
 #ifdef QV_GEMM_TRACE
     // dev tool only (tools/gemm_trace.hip): [block][wave][K-step][4] s_memtime stamps
     unsigned long long *trace;
+    unsigned long long *phase;   // [block][4] s_memrealtime (100 MHz) at entry, first barrier release, K loop end, exit
     int abl;   // ablation mask: 1 no MFMA, 2 no fragment reads, 4 no ds_write (LD = 1), 8 no loads (LD = 1)
 #endif
 };

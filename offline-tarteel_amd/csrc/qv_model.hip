@@ -616,6 +616,10 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     const half_t *posp = nullptr;
     TRY(get_pos(eng, m, T, s, &posp));
 
+    // dev-only timing experiment (results are garbage when set): QVERSE_SKIP bit mask -- 1 k_layernorm, 2 k_layernorm2,
+    // 4 attention, 8 dwconv1d, 32 front-end (log-mel + subsampling convs), 64 every encoder GEMM
+    static const int skip = [] { const char *e = getenv("QVERSE_SKIP"); return e ? atoi(e) : 0; }();
+    if (!(skip & 32)) {
     launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, m->mel_stats, B, s);
     if (m->c0) {
         // cross-check path: conv0 and the depthwise conv as two kernels through HBM
@@ -637,9 +641,12 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     g.A = m->c2k; g.W = m->sub_out_w; g.bias = m->sub_out_b; g.out = m->x;
     g.M = M; g.N = QV_D; g.K = 2560; g.lda = 2560; g.ldw = 2560; g.ldo = QV_D; g.alpha = sqrtf((float)QV_D);
     launch_gemm(EPI_F32, g, s);
+    } else {
+        launch_pack_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, d_off, m->c2k, m->row_map, B, s);
+    }
     if (m->save_taps) QV_HIP(hipMemcpyAsync(m->tap_x, m->x, sizeof(float) * (size_t)M * QV_D, hipMemcpyDeviceToDevice, s));
 
-    launch_layernorm(m->x, m->L[0].ln_g[0], m->L[0].ln_b[0], m->ln, M, s);
+    if (!(skip & 1)) launch_layernorm(m->x, m->L[0].ln_g[0], m->L[0].ln_b[0], m->ln, M, s);
     for (int l = 0; l < N_LAYERS; ++l) {
         const LayerW &L = m->L[l];
         auto gemm = [&](int epi, const half_t *A, int K, const WMat &W, const float *bias, void *out, int N, int ldo,
@@ -648,27 +655,28 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.W8 = W.q8; a.w8scale = W.sc8; a.bias = bias; a.out = out; a.out2 = m->vt;
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
             a.row_map = m->row_map;
-            launch_gemm(epi, a, s);
+            if (!(skip & 64)) launch_gemm(epi, a, s);
         };
         // 1/2 FFN
         gemm(EPI_F16_SWISH, m->ln, QV_D, L.ff1_w1, L.ff1_b1, m->hbuf, QV_FF, QV_FF, 1.f);
         gemm(EPI_RESID, m->hbuf, QV_FF, L.ff1_w2, L.ff1_b2, m->x, QV_D, QV_D, 0.5f);
         // rel-pos MHSA
-        launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
+        if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         gemm(EPI_QKV, m->ln, QV_D, L.qkv_w, L.qkv_b, m->qk, 3 * QV_D, 2 * QV_D, 1.f);
-        launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
+        if (!(skip & 4)) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
         gemm(EPI_RESID, m->att, QV_D, L.out_w, L.out_b, m->x, QV_D, QV_D, 1.f);
         // conv module
-        launch_layernorm(m->x, L.ln_g[2], L.ln_b[2], m->ln, M, s);
+        if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[2], L.ln_b[2], m->ln, M, s);
         gemm(EPI_GLU, m->ln, QV_D, L.pw1_w, L.pw1_b, m->glu, 2 * QV_D, QV_D, 1.f);
-        launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, d_off, m->dw, T, B, s);
+        if (!(skip & 8)) launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, d_off, m->dw, T, B, s);
         gemm(EPI_RESID, m->dw, QV_D, L.pw2_w, L.pw2_b, m->x, QV_D, QV_D, 1.f);
         // 1/2 FFN
-        launch_layernorm(m->x, L.ln_g[3], L.ln_b[3], m->ln, M, s);
+        if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[3], L.ln_b[3], m->ln, M, s);
         gemm(EPI_F16_SWISH, m->ln, QV_D, L.ff2_w1, L.ff2_b1, m->hbuf, QV_FF, QV_FF, 1.f);
         gemm(EPI_RESID, m->hbuf, QV_FF, L.ff2_w2, L.ff2_b2, m->x, QV_D, QV_D, 0.5f);
         // norm_out (+ next layer's first LayerNorm)
-        if (l + 1 < N_LAYERS)
+        if (skip & 2) { }
+        else if (l + 1 < N_LAYERS)
             launch_layernorm2(m->x, L.ln_g[4], L.ln_b[4], m->L[l + 1].ln_g[0], m->L[l + 1].ln_b[0], m->ln, M, s);
         else
             launch_layernorm2(m->x, L.ln_g[4], L.ln_b[4], nullptr, nullptr, nullptr, M, s);

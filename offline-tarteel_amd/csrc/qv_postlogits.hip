@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvK
     uint32_t *hti = htk + CAND_HT;                         // [CAND_HT]
     int32_t *refs = (int32_t *)(hti + CAND_HT);            // [128]
     int32_t *roff = refs + 128;                            // [129]
-    int32_t *wsum = roff + 132;                            // [8]
+    int32_t *wsum = roff + 132;                            // [8]: 4 wave sums + the leader counter
     if ((int)blockIdx.x >= *wk.n_fail) return;
     const int b = wk.fail_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QvUtt &u = wk.utt[b];
@@ -1181,24 +1181,79 @@ __global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvK
     double *csc = wk.cand_score + (size_t)b * QV_CAND_CAP;
     for (int i = i0; i < i1; ++i) {
         if (!(keepmask >> (i - i0) & 1u)) continue;
-        if (base < QV_CAND_CAP) { cs[base] = (int32_t)(pkey[i] >> 3); cp[base] = (int32_t)(pkey[i] & 7u); csc[base] = pscore[i]; }
+        if (base < QV_CAND_CAP) {
+            cs[base] = (int32_t)(pkey[i] >> 3); cp[base] = (int32_t)(pkey[i] & 7u); csc[base] = pscore[i];
+            // the table now maps a key to its CANDIDATE index (every keepmask loop is behind the barrier above)
+            uint32_t key = pkey[i], slot = (key * 2654435761u) >> 20;
+            while (htk[slot] != key) slot = (slot + 1) & (CAND_HT - 1);
+            hti[slot] = (uint32_t)base;
+        } else {
+            uint32_t key = pkey[i], slot = (key * 2654435761u) >> 20;
+            while (htk[slot] != key) slot = (slot + 1) & (CAND_HT - 1);
+            hti[slot] = 0xFFFFFFFFu;
+        }
         ++base;
     }
+    const int ncand = total < QV_CAND_CAP ? total : QV_CAND_CAP;
     if (tid == 0) {
-        u.n_cand = total < QV_CAND_CAP ? total : QV_CAND_CAP;
+        u.n_cand = ncand;
         if (overflow || total > QV_CAND_CAP) u.flags |= QV_FLAG_CAND_OVERFLOW;
     }
+    // ---- plan of the CTC rerank: which candidates run an alpha recursion ----------------------------------
+    // The alpha values of the states 0..2P of a target do not depend on what follows its first P tokens, so
+    // ONE recursion over the ids of (start, span k') also yields the loss of every (start, span k < k') whose
+    // ids are a prefix of them (tok_pfx): read alpha_T at the states 2P and 2P - 1.  A candidate's leader is
+    // the feasible candidate with the same start verse and the largest span its ids are a prefix of; only
+    // leaders run (k_ctc), each writes the losses of its members.  Same arithmetic per state as a recursion
+    // of its own: the results are bit-identical, the work drops by the sharing factor (windows around a
+    // reference verse share their start verse up to max_span - 1 times).
+    int32_t *nlead = wsum + 4;
+    if (tid == 0) *nlead = 0;
+    int16_t *lead = wk.cand_lead + (size_t)b * QV_CAND_CAP;
+    int16_t *memb = wk.cand_memb + (size_t)b * QV_CAND_CAP * QV_MAX_SPAN;
+    float *closs = wk.cand_loss + (size_t)b * QV_CAND_CAP;
+    double *cfin = wk.cand_final + (size_t)b * QV_CAND_CAP;
+    for (int i = tid; i < ncand * QV_MAX_SPAN; i += 256) memb[i] = -1;
+    __syncthreads();
+    const int T = u.t_frames, scap = wk.t_cap > 384 ? 768 : 384;
+    for (int c = tid; c < ncand; c += 256) {
+        const int st = cs[c], sp = cp[c];
+        const size_t k0 = (size_t)st * QV_MAX_SPAN;
+        const int L = (int)(tab.tok_off[k0 + sp] - tab.tok_off[k0 + sp - 1]);
+        if (!(L > 0 && 2 * L + 1 <= T && 2 * L + 1 <= scap)) {     // gate of c2c-direct/run.py:332: no loss
+            closs[c] = INFINITY;
+            cfin[c] = -INFINITY;
+            continue;
+        }
+        int leader = c;
+        const unsigned chain = tab.tok_pfx[st];
+        for (int k = kn.max_span; k > sp; --k) {
+            const unsigned need = ((1u << (k - 1)) - 1u) & ~((1u << (sp - 1)) - 1u);   // flags sp .. k - 1
+            if ((chain & need) != need) continue;
+            const int Lk = (int)(tab.tok_off[k0 + k] - tab.tok_off[k0 + k - 1]);
+            if (!(2 * Lk + 1 <= T && 2 * Lk + 1 <= scap)) continue;
+            uint32_t key = (uint32_t)st * 8u + (uint32_t)k, slot = (key * 2654435761u) >> 20;
+            while (htk[slot] != key && htk[slot] != 0xFFFFFFFFu) slot = (slot + 1) & (CAND_HT - 1);
+            if (htk[slot] != key || hti[slot] == 0xFFFFFFFFu) continue;
+            leader = (int)hti[slot];
+            break;
+        }
+        if (leader == c) lead[atomicAdd(nlead, 1)] = (int16_t)c;
+        else memb[(size_t)leader * QV_MAX_SPAN + sp - 1] = (int16_t)c;
+    }
+    __syncthreads();
+    if (tid == 0) u.n_lead = *nlead;
 }
 
 // ------------------------------------------------------------------ 9. CTC -------------
 // ATen LossCTC.cpp float32 alpha recursion (what F.ctc_loss runs on CPU for the reference,
 // c2c-direct/run.py:354-362).  One wave per target; state s = lane*NS + k.
 template <int NS>
-__device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tgt, int L, int lane) {
+__device__ void ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tgt, int L, int lane, float *sa) {
     // The recursion runs in log2 units (alpha2 = alpha * log2 e): v_exp_f32 / v_log_f32 are
     // base-2, so this drops four multiplies per state update; "-inf" is a large finite sentinel,
     // which removes the all-(-inf) special case (exp2(0) = 1, and the sentinel absorbs the rest).
-    const float NEG = -1e30f, LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
+    const float NEG = -1e30f, LOG2E = 1.44269504088896340736f;
     int S = 2 * L + 1;
     int tok[NS];
     bool skip_ok[NS];
@@ -1252,18 +1307,18 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
             for (int k = 0; k < NS; ++k) a[k] = na[k];
         }
     }
-    // l1 = a[S-1], l2 = a[S-2]
-    float l1 = NEG, l2 = NEG;
+    // alpha_T of every state, for the caller's read-outs (its own target and the prefixes it leads)
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        int s = lane * NS + k;
-        if (s == S - 1) l1 = a[k];
-        if (s == S - 2) l2 = a[k];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { l1 = fmaxf(l1, __shfl_xor(l1, o)); l2 = fmaxf(l2, __shfl_xor(l2, o)); }
-    float m = fmaxf(l1, l2);
-    float ll2 = __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(l1 - m) + __builtin_amdgcn_exp2f(l2 - m)) + m;
+    for (int k = 0; k < NS; ++k) sa[lane * NS + k] = a[k];
+}
+
+// loss of the target made of the first P tokens, from the alpha_T row a recursion over at least P tokens left
+// in `sa` (log2 units): -ln(alpha_T(2P) + alpha_T(2P - 1)), INFINITY when no alignment exists.
+__device__ __forceinline__ float ctc_readout(const float *sa, int P) {
+    const float LN2 = 0.693147180559945309417f;
+    const float l1 = sa[2 * P], l2 = sa[2 * P - 1];
+    const float m = fmaxf(l1, l2);
+    const float ll2 = __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(l1 - m) + __builtin_amdgcn_exp2f(l2 - m)) + m;
     if (ll2 < -1e29f) return INFINITY;  // no alignment (the caller applies zero_infinity)
     return -ll2 * LN2;
 }
@@ -1271,53 +1326,65 @@ __device__ float ctc_wave(const float *__restrict__ lp, int T, const uint16_t *_
 // LONG = engine capacity above 30 s (more than 384 states per target): only then are the wide
 // instantiations compiled into the kernel, keeping the common kernel's register footprint small
 template <bool LONG>
-__device__ float ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L, int lane) {
+__device__ void ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L, int lane, float *sa) {
     int S = 2 * L + 1;
-    if (S <= 64) return ctc_wave<1>(lp, T, tgt, L, lane);
-    if (S <= 128) return ctc_wave<2>(lp, T, tgt, L, lane);
-    if (S <= 192) return ctc_wave<3>(lp, T, tgt, L, lane);
-    if (S <= 256) return ctc_wave<4>(lp, T, tgt, L, lane);
-    if (S <= 384 || !LONG) return ctc_wave<6>(lp, T, tgt, L, lane);
-    if (S <= 512) return ctc_wave<8>(lp, T, tgt, L, lane);
-    return ctc_wave<12>(lp, T, tgt, L, lane);
+    if (S <= 64) return ctc_wave<1>(lp, T, tgt, L, lane, sa);
+    if (S <= 128) return ctc_wave<2>(lp, T, tgt, L, lane, sa);
+    if (S <= 192) return ctc_wave<3>(lp, T, tgt, L, lane, sa);
+    if (S <= 256) return ctc_wave<4>(lp, T, tgt, L, lane, sa);
+    if (S <= 384 || !LONG) return ctc_wave<6>(lp, T, tgt, L, lane, sa);
+    if (S <= 512) return ctc_wave<8>(lp, T, tgt, L, lane, sa);
+    return ctc_wave<12>(lp, T, tgt, L, lane, sa);
 }
 
+// One wave per LEADER candidate (k_candidates' plan): one alpha recursion, then the loss of the leader and of
+// every candidate whose ids are a prefix of its ids.
 template <bool LONG>
 __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn, const float *__restrict__ lp, int t_max) {
+    __shared__ float sa_all[4][LONG ? 768 : 384];
     if ((int)blockIdx.y >= *wk.n_fail) return;
     int b = wk.fail_list[blockIdx.y];
     const QvUtt &u = wk.utt[b];
     if (!u.use_ctc) return;
     int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    float *sa = sa_all[threadIdx.x >> 6];
     int T = u.t_frames;
     const float *lpb = lp + (size_t)b * t_max * QV_VOCAB;
-    for (int c = wave; c < u.n_cand; c += nwave) {
-        int st = wk.cand_start[(size_t)b * QV_CAND_CAP + c], sp = wk.cand_span[(size_t)b * QV_CAND_CAP + c];
-        size_t key = (size_t)st * QV_MAX_SPAN + (sp - 1);
-        int L = (int)(tab.tok_off[key + 1] - tab.tok_off[key]);
-        float loss = INFINITY;
-        double fin = -INFINITY;
-        if (L > 0 && 2 * L + 1 <= T && 2 * L + 1 <= (LONG ? 768 : 384)) {  // gate of c2c-direct/run.py:332
-            loss = ctc_dispatch<LONG>(lpb, T, tab.tok + tab.tok_off[key], L, lane);
+    const int16_t *lead = wk.cand_lead + (size_t)b * QV_CAND_CAP;
+    for (int i = wave; i < u.n_lead; i += nwave) {
+        const int c = lead[i];
+        const int st = wk.cand_start[(size_t)b * QV_CAND_CAP + c], sp = wk.cand_span[(size_t)b * QV_CAND_CAP + c];
+        const size_t k0 = (size_t)st * QV_MAX_SPAN;
+        const int L = (int)(tab.tok_off[k0 + sp] - tab.tok_off[k0 + sp - 1]);
+        ctc_dispatch<LONG>(lpb, T, tab.tok + tab.tok_off[k0 + sp - 1], L, lane, sa);
+        // the leader itself (k == sp) and its members
+        const int16_t *memb = wk.cand_memb + ((size_t)b * QV_CAND_CAP + c) * QV_MAX_SPAN;
+        for (int k = 1; k <= sp; ++k) {
+            const int m = k == sp ? c : (int)memb[k - 1];
+            if (m < 0) continue;
+            const int P = (int)(tab.tok_off[k0 + k] - tab.tok_off[k0 + k - 1]);
+            float loss = ctc_readout(sa, P);
             if (isinf(loss)) loss = 0.f;  // zero_infinity=True
-            float norm = __fdiv_rn(loss, (float)L);
+            float norm = __fdiv_rn(loss, (float)P);
             // -norm + TEXT_WEIGHT*text_score - SPAN_PENALTY*(span_len-1), in Python doubles
-            double tw = __dmul_rn(kn.text_weight, wk.cand_score[(size_t)b * QV_CAND_CAP + c]);
-            fin = __dsub_rn(__dadd_rn(-(double)norm, tw), __dmul_rn(kn.span_penalty, (double)(sp - 1)));
-        }
-        if (lane == 0) {
-            wk.cand_loss[(size_t)b * QV_CAND_CAP + c] = loss;
-            wk.cand_final[(size_t)b * QV_CAND_CAP + c] = fin;
+            double tw = __dmul_rn(kn.text_weight, wk.cand_score[(size_t)b * QV_CAND_CAP + m]);
+            double fin = __dsub_rn(__dadd_rn(-(double)norm, tw), __dmul_rn(kn.span_penalty, (double)(k - 1)));
+            if (lane == 0) {
+                wk.cand_loss[(size_t)b * QV_CAND_CAP + m] = loss;
+                wk.cand_final[(size_t)b * QV_CAND_CAP + m] = fin;
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(64) void k_ctc_debug(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tg,
                                                   const int32_t *__restrict__ off, int n, float *__restrict__ loss) {
+    __shared__ float sa[768];
     int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n) return;
     int L = off[c + 1] - off[c];
-    float l = ctc_dispatch<true>(lp, T, tg + off[c], L, lane);
+    ctc_dispatch<true>(lp, T, tg + off[c], L, lane, sa);
+    float l = ctc_readout(sa, L);
     if (lane == 0) loss[c] = l;
 }
 
@@ -1525,7 +1592,9 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
     int rc = launch_retrieval(eng, batch, 0, stream);
     if (rc) return rc;
     qv_stage_mark(eng, 3, stream);
-    if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+    static const int skip = [] { const char *e = getenv("QVERSE_SKIP"); return e ? atoi(e) : 0; }();   // dev-only, see qv_model.hip
+    if (skip & 16) { }
+    else if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
     else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
     hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
     qv_stage_mark(eng, 4, stream);

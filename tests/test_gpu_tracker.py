@@ -88,12 +88,32 @@ def test_track_match_vs_oracle_random(engine, tracker_oracle):
             assert g["score"] == w[3], t
 
 
-def test_track_match_capacity(engine):
-    from offline_tarteel_amd.engine import QvError
+def test_track_match_capacity(engine, tracker_oracle):
+    """Texts longer than the device's 1,024-character window are matched on their longest whole-word front
+    window instead of being refused (the reference has no limit; both of its single-text matchers work on
+    the FRONT of the text): the Python binding windows them, the raw C entry point still reports capacity."""
+    import ctypes as C
+
+    import numpy as np
+
+    from offline_tarteel_amd.engine import QvTrackMatch, front_window
 
     assert engine.track_match(["ا" * 1024])[0] is not None       # QV_MAX_TRANSCRIPT codes still fit
-    with pytest.raises(QvError):
-        engine.track_match(["ا" * 1025])
+    words = " ".join(["الحمد لله رب العالمين"] * 60)             # 1,379 characters
+    assert len(words) > 1024
+    win = front_window(words)
+    assert len(win) <= 1024 and words.startswith(win) and words[len(win)] == " "
+    got, want = engine.track_match([words])[0], engine.track_match([win])[0]
+    assert got == want and got is not None
+    w = tracker_oracle.best_raw(win, None)
+    assert (got["verse"], got["variant"], got["n_words"], got["score"]) == w
+    assert engine.match_verse(words) == engine.match_verse(win)
+    # the C ABI itself refuses (QV_ERR_CAPACITY = 4) rather than truncating silently
+    codes = np.zeros(1025, np.uint8)
+    off, nw, bonus = np.array([0, 1025], np.int32), np.array([1], np.int32), np.array([-1], np.int32)
+    out = (QvTrackMatch * 1)()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert engine.lib.qv_tracker_match(engine.h, p(codes), p(off), p(nw), p(bonus), 1, C.cast(out, C.c_void_p), None) == 4
     assert engine.track_match([]) == []
 
 

@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -56,6 +57,35 @@ int main() {
                 printf("    %-45s %7.2f us\n", names[v], ms * 1e3 / 20);
             }
             g.abl = 0;
+        }
+        {
+            // block-level timeline (100 MHz wall clock, comparable across CUs): when blocks start, how long each phase lasts
+            unsigned long long *dP;
+            const int nblk = (sh.N / 128) * ((M + 127) / 128);
+            CK(hipMalloc(&dP, (size_t)nblk * 4 * 8));
+            CK(hipMemset(dP, 0, (size_t)nblk * 4 * 8));
+            for (int i = 0; i < 3; ++i) launch_gemm(sh.epi, g, 0);
+            CK(hipDeviceSynchronize());
+            g.phase = dP;
+            launch_gemm(sh.epi, g, 0);
+            CK(hipDeviceSynchronize());
+            g.phase = nullptr;
+            std::vector<unsigned long long> hP((size_t)nblk * 4);
+            CK(hipMemcpy(hP.data(), dP, hP.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, hP[b * 4]); t1 = std::max(t1, hP[b * 4 + 3]); }
+            double pro = 0, kl = 0, ep = 0;
+            std::vector<double> starts;
+            for (int b = 0; b < nblk; ++b) {
+                pro += (double)(hP[b * 4 + 1] - hP[b * 4]); kl += (double)(hP[b * 4 + 2] - hP[b * 4 + 1]); ep += (double)(hP[b * 4 + 3] - hP[b * 4 + 2]);
+                starts.push_back((double)(hP[b * 4] - t0) / 100.0);
+            }
+            std::sort(starts.begin(), starts.end());
+            printf("    timeline: kernel span %.2f us (first block entry -> last block exit); per block: entry->first barrier %.2f us, K loop %.2f us, epilogue %.2f us\n",
+                   (double)(t1 - t0) / 100.0, pro / nblk / 100.0, kl / nblk / 100.0, ep / nblk / 100.0);
+            printf("    block entry times (us after the first): p10 %.2f  p25 %.2f  p50 %.2f  p75 %.2f  p90 %.2f  max %.2f\n", starts[nblk / 10], starts[nblk / 4],
+                   starts[nblk / 2], starts[3 * nblk / 4], starts[9 * nblk / 10], starts.back());
+            CK(hipFree(dP));
         }
         for (int i = 0; i < 3; ++i) launch_gemm(sh.epi, g, 0);
         CK(hipMemset(dT, 0, TR * 8));
