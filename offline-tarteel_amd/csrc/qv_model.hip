@@ -619,6 +619,9 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     // dev-only timing experiment (results are garbage when set): QVERSE_SKIP bit mask -- 1 k_layernorm, 2 k_layernorm2,
     // 4 attention, 8 dwconv1d, 32 front-end (log-mel + subsampling convs), 64 every encoder GEMM
     static const int skip = [] { const char *e = getenv("QVERSE_SKIP"); return e ? atoi(e) : 0; }();
+    // ... and QVERSE_DUP launches the (idempotent) kernels of a class TWICE -- results unchanged, the slowdown is
+    // the class's marginal cost under the current overlap: 1 k_layernorm, 4 attention, 8 dwconv1d, 64 FFN-up/QKV/GLU GEMMs
+    static const int dup = [] { const char *e = getenv("QVERSE_DUP"); return e ? atoi(e) : 0; }();
     if (!(skip & 32)) {
     launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, m->mel_stats, B, s);
     if (m->c0) {
@@ -656,22 +659,28 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
             a.row_map = m->row_map;
             if (!(skip & 64)) launch_gemm(epi, a, s);
+            if ((dup & 64) && epi != EPI_RESID) launch_gemm(epi, a, s);
         };
         // 1/2 FFN
         gemm(EPI_F16_SWISH, m->ln, QV_D, L.ff1_w1, L.ff1_b1, m->hbuf, QV_FF, QV_FF, 1.f);
         gemm(EPI_RESID, m->hbuf, QV_FF, L.ff1_w2, L.ff1_b2, m->x, QV_D, QV_D, 0.5f);
         // rel-pos MHSA
         if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
+        if (dup & 1) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         gemm(EPI_QKV, m->ln, QV_D, L.qkv_w, L.qkv_b, m->qk, 3 * QV_D, 2 * QV_D, 1.f);
         if (!(skip & 4)) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
+        if (dup & 4) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
         gemm(EPI_RESID, m->att, QV_D, L.out_w, L.out_b, m->x, QV_D, QV_D, 1.f);
         // conv module
         if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[2], L.ln_b[2], m->ln, M, s);
+        if (dup & 1) launch_layernorm(m->x, L.ln_g[2], L.ln_b[2], m->ln, M, s);
         gemm(EPI_GLU, m->ln, QV_D, L.pw1_w, L.pw1_b, m->glu, 2 * QV_D, QV_D, 1.f);
         if (!(skip & 8)) launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, d_off, m->dw, T, B, s);
+        if (dup & 8) launch_dwconv1d(m->glu, L.dw_w, L.dw_b, d_l3, d_off, m->dw, T, B, s);
         gemm(EPI_RESID, m->dw, QV_D, L.pw2_w, L.pw2_b, m->x, QV_D, QV_D, 1.f);
         // 1/2 FFN
         if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[3], L.ln_b[3], m->ln, M, s);
+        if (dup & 1) launch_layernorm(m->x, L.ln_g[3], L.ln_b[3], m->ln, M, s);
         gemm(EPI_F16_SWISH, m->ln, QV_D, L.ff2_w1, L.ff2_b1, m->hbuf, QV_FF, QV_FF, 1.f);
         gemm(EPI_RESID, m->hbuf, QV_FF, L.ff2_w2, L.ff2_b2, m->x, QV_D, QV_D, 0.5f);
         // norm_out (+ next layer's first LayerNorm)
