@@ -407,6 +407,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
         for (hipEvent_t &e : c.t_copied) e = nullptr;
         for (hipEvent_t &e : c.stage_ev) e = nullptr;
         c.stage_valid = false;
+        c.n_post_graph = 0;
     }
     auto fail = [&](int rc) {
         g_create_error = eng->last_error;
@@ -470,6 +471,7 @@ extern "C" void qv_destroy(qv_engine *e) {
         if (c.done) (void)hipEventDestroy(c.done);
         for (hipEvent_t e2 : c.t_copied) if (e2) (void)hipEventDestroy(e2);
         for (hipEvent_t e2 : c.stage_ev) if (e2) (void)hipEventDestroy(e2);
+        for (int i = 0; i < c.n_post_graph; ++i) (void)hipGraphExecDestroy(c.post_graph[i].exec);
     }
     delete e;
 }

@@ -1585,19 +1585,61 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
         QV_HIP(hipEventRecord(c.t_copied[slot], stream));
         c.t_pending[slot] = true;
     }
-    hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);
-    hipLaunchKernelGGL(k_argmax, dim3(t_max, batch), dim3(64), 0, stream, lp, t_max, wk.utt, wk.frame_ids, wk.t_cap);
-    hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);
-    qv_stage_mark(eng, 2, stream);
-    int rc = launch_retrieval(eng, batch, 0, stream);
-    if (rc) return rc;
-    qv_stage_mark(eng, 3, stream);
     static const int skip = [] { const char *e = getenv("QVERSE_SKIP"); return e ? atoi(e) : 0; }();   // dev-only, see qv_model.hip
-    if (skip & 16) { }
-    else if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
-    else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
-    hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
-    qv_stage_mark(eng, 4, stream);
+    auto launch_chain = [&]() -> int {
+        hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);
+        hipLaunchKernelGGL(k_argmax, dim3(t_max, batch), dim3(64), 0, stream, lp, t_max, wk.utt, wk.frame_ids, wk.t_cap);
+        hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);
+        qv_stage_mark(eng, 2, stream);
+        int rc = launch_retrieval(eng, batch, 0, stream);
+        if (rc) return rc;
+        qv_stage_mark(eng, 3, stream);
+        if (skip & 16) { }
+        else if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
+        qv_stage_mark(eng, 4, stream);
+        return QV_OK;
+    };
+    // One graph launch for the whole chain when its arguments are the ones a graph was captured with: the
+    // engine's own log-prob workspace (qv_predict_batch*), same batch and frame count -- the steady state of a
+    // serving loop.  Everything the 15 kernels decide per utterance (gate, candidate counts, leaders) is read
+    // from device memory, so a replay is the same work as the launches it was captured from.  Caller-owned
+    // log-prob tensors (pointer changes per call), profiled runs and single-context engines (the chain then runs
+    // on the CALLER's stream, which may be the legacy default stream -- not capturable) take the plain launches.
+    // Opt-in (QVERSE_POST_GRAPH=1): measured on one MI355X with three batches in flight it changes nothing
+    // (4.26 vs 4.13 ms per step, within box noise) -- kernel boundaries cost the same inside a graph, and the
+    // host's ~3.5 us per launch is not what limits the step.
+    static const bool use_graph = [] { const char *e = getenv("QVERSE_POST_GRAPH"); return e && atoi(e) != 0; }();
+    QvCtx &gc = eng->ctx[eng->cur_ctx];
+    if (use_graph && eng->n_ctx > 1 && stream == gc.stream && lp == eng->logprobs_ws && !eng->profile_stages) {
+        QvCtx::PostGraph *hit = nullptr;
+        for (int i = 0; i < gc.n_post_graph; ++i)
+            if (gc.post_graph[i].lp == lp && gc.post_graph[i].batch == batch && gc.post_graph[i].t_max == t_max) hit = &gc.post_graph[i];
+        if (!hit && gc.n_post_graph < 4) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            QV_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            int rc = launch_chain();
+            hipError_t e1 = hipStreamEndCapture(stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            QV_HIP(e1);
+            hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            QV_HIP(e2);
+            gc.post_graph[gc.n_post_graph] = {lp, batch, t_max, exec};
+            hit = &gc.post_graph[gc.n_post_graph++];
+        }
+        if (hit) {
+            QV_HIP(hipGraphLaunch(hit->exec, stream));
+        } else {
+            int rc = launch_chain();
+            if (rc) return rc;
+        }
+    } else {
+        int rc = launch_chain();
+        if (rc) return rc;
+    }
     QV_HIP(hipGetLastError());
     eng->last_batch = batch;
     eng->last_tmax = t_max;

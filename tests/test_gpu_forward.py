@@ -5,6 +5,7 @@ Tolerance: north_star asks CTC log-probs within 1e-2; the fp16-operand / fp32-ac
 path lands at ~4e-3 max abs on this workload.
 """
 
+import json
 import os
 
 import pytest
@@ -336,3 +337,34 @@ def test_tiny_and_long_utterances_share_a_packed_batch(setup):
         assert float((one[0, :t1[0]] - lp[b, :t1[0]]).abs().max()) <= 1e-5
     res = eng.predict_batch(a.cuda().contiguous(), lens)
     assert len(res) == 4 and res[0]["t_frames"] == 1
+
+
+def test_post_logits_chain_as_one_graph_launch_is_identical():
+    """QVERSE_POST_GRAPH=1: with batches in flight the 15 post-logits kernels of a batch replay as ONE hipGraph
+    launch (captured on the context's stream the first time a (batch, frames) key is seen).  Same results, bit
+    for bit, as the plain launches -- in a fresh process, because the switch is read once."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    prog = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, offline_tarteel_amd\n"
+        "from offline_tarteel_amd.engine import Engine\n"
+        "from synth import synth_audio\n"
+        "eng = Engine(device=0, with_model=True, seed=3, max_batch=6, max_samples=48000, contexts=2)\n"
+        "a = torch.from_numpy(synth_audio(6, 48000)).cuda(); lens = [48000, 40000, 48000, 32000, 48000, 44800]\n"
+        "out = []\n"
+        "for it in range(5):\n"
+        "    ctx = eng.predict_batch_async(a, lens)\n"
+        "    out.append([(r['surah'], r['ayah'], r['ayah_end'], r['score'], r['n_candidates'], r['flags']) for r in eng.fetch_results(ctx, 6, eng.frames_for(48000))])\n"
+        "print(json.dumps(out))\n"
+    ) % (str(root), str(root / "tests"))
+    res = []
+    for flag in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, QVERSE_POST_GRAPH=flag))
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1] and all(r == res[0][0] for r in res[0])
