@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round evidence in one GPU-box call: GPU tests, smoke, the bench lines, rocprofv3 kernel stats of the
-# same bench command, the clip-length sweep, the post-logits / tracker micro-benchmarks and the
-# PMC traffic passes of the GEMM shapes.  Everything lands in gpurun_out/final/ (copy what is to be
-# judged into profiles/).   usage: tools/final_round.sh [tag]
+# Round evidence in one GPU-box call: GPU tests, smoke, the bench lines (headline, one batch at a time, configs[2],
+# configs[4] workload), rocprofv3 kernel stats of the same bench command, the clip-length sweep, the post-logits /
+# tracker micro-benchmarks, the quantisation / resampler distance tools and the PMC passes of the GEMM shapes.
+# Everything lands in gpurun_out/final/ (copy what is to be judged into profiles/).   usage: tools/final_round.sh [tag]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final
@@ -12,16 +12,18 @@ timeout 900 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; tail -n 2
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -n 1 "$O/smoke.log"
 timeout 400 python bench.py > "$O/bench.json" 2> "$O/bench.err"; cut -c1-170 "$O/bench.json"
 timeout 300 python bench.py --contexts 1 --no-cpu-baseline > "$O/bench_contexts1.json" 2>/dev/null; cut -c1-170 "$O/bench_contexts1.json"
-timeout 300 python bench.py --batch 256 --precision mixed --steps 20 --no-cpu-baseline > "$O/bench_cfg3_b256_int4.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg3_b256_int4.json"
+timeout 300 python bench.py --batch 256 --precision mixed --steps 20 --no-cpu-baseline > "$O/bench_cfg2_b256_mixed.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_mixed.json"
+timeout 300 python bench.py --batch 256 --steps 20 --no-cpu-baseline > "$O/bench_b256_fp16.json" 2>/dev/null; cut -c1-170 "$O/bench_b256_fp16.json"
+timeout 300 python bench.py --workload tta30 --steps 6 --warmup 2 --no-cpu-baseline > "$O/bench_tta30.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30.json"
 timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; tail -n 3 "$O/sweep.log" | cut -c1-200
 timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench.jsonl"
 timeout 200 python tools/tracker_bench.py --cpu-texts 4 > "$O/tracker_bench.jsonl" 2>/dev/null; tail -n 2 "$O/tracker_bench.jsonl"
+timeout 300 python tools/ort_delta.py --seconds 10 --out "$O/ort_semantics_delta.json" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof3" -o p -- python "$R/bench.py" --steps 20 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof1" -o p -- python "$R/bench.py" --steps 20 --contexts 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof3" -o p -- python "$R/bench.py" --steps 20 --no-cpu-baseline --no-post-logits > "$O/bench_under_rocprof.json" 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof1" -o p -- python "$R/bench.py" --steps 20 --contexts 1 --no-cpu-baseline --no-post-logits > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/profpost" -o p -- python "$R/tools/post_bench.py" --steps 5 > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -o p -- "$R/tools/gemm_bench" 10 > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -o p -- "$R/tools/gemm_bench" 10 > /dev/null 2>&1
 cd "$R"
 find "$O" -name "*_kernel_trace.csv" -path "*prof*" -delete   # the traces are large; the stats are what is kept
-ls "$O" "$O"/prof3/* 2>/dev/null | head -40
+bash tools/pmc_round.sh ${1:-final} 8064 > /dev/null 2>&1
+ls "$O" | head -40
