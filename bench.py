@@ -304,8 +304,8 @@ def main():
 
     # ---- roofline of the dominant kernel -----------------------------------------------------
     # Dominant kernel by time (profiles/*_kernel_stats.csv): the GEMM family; its single-shape
-    # member with the largest share is the FFN-up GEMM k_gemm<f16_swish,128>
-    # ([B*T,512] x [512,2048] + Swish, 2 per layer).  It is timed live with HIP events on the launch
+    # member with the largest share is the FFN-up GEMM ([B*T,512] x [512,2048] + Swish, 2 per layer:
+    # k_gemm256<f16_swish> on 256 x 256 tiles when the grid has >= 160 of them, else k_gemm<f16_swish,128>).  It is timed live with HIP events on the launch
     # stream over a back-to-back replay on the engine's own buffers; the in-situ, per-launch event
     # timing of EVERY GEMM class of a few full steps is reported next to it (that one includes the
     # event/launch gap of each launch, so it reads lower).

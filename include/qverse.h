@@ -236,17 +236,25 @@ int qv_debug_forward_tap(qv_engine *e, int32_t what, int32_t layer, float *out_d
 
 /* Measurement hooks for bench.py's roofline line: while enabled, every GEMM launch of the
  * acoustic model is bracketed by HIP events on its own stream.  After synchronising the stream,
- * qv_profile_gemm_read() returns, per kernel class c = epilogue*2 + (tile 128 ? 1 : 0) (14
- * classes), the summed event time in ms, the summed algorithmic FLOPs (2*M*N*K) and the launch
- * count, and clears the log. */
+ * qv_profile_gemm_read() returns, per kernel class c = epilogue*3 + tile (0 = 64-wide, 1 = 128-wide,
+ * 2 = 256 x 256; 21 classes), the summed event time in ms, the summed algorithmic FLOPs (2*M*N*K)
+ * and the launch count, and clears the log. */
 int qv_profile_gemm(qv_engine *e, int32_t enable);
-int qv_profile_gemm_read(qv_engine *e, double *ms14, double *flops14, int32_t *launches14);
+int qv_profile_gemm_read(qv_engine *e, double *ms21, double *flops21, int32_t *launches21);
 /* Replays ONE GEMM of layer 0 with the shapes of the last forward `iters` times back to back
  * between two HIP events on `stream` (SYNCHRONOUS).  which: 0 FFN-up [M,512]x[512,2048]+Swish,
  * 1 FFN-down [M,2048]x[2048,512]+residual, 2 QKV, 3 attention out-projection, 4 pointwise-conv+GLU.
  * Returns the average launch duration in microseconds and the algorithmic FLOPs (2*M*N*K). */
 int qv_profile_replay_gemm(qv_engine *e, int32_t which, int32_t iters, double *avg_us, double *flops_per_launch,
                            void *stream);
+/* Name of the kernel that replay runs, i.e. the tile shape the launcher picks for that GEMM at the last
+ * forward's row count ("k_gemm256<f16_swish>", "k_gemm<resid,128>", ...). */
+int qv_profile_replay_kernel(qv_engine *e, int32_t which, char *name_out, int32_t name_cap);
+/* Process-wide GEMM tile policy, for the tests that compare tile shapes bit for bit: 0 = 128-wide tiles only,
+ * 1 = the default (256 x 256 tiles where N % 256 == 0 and the grid has >= 160 of them), 2 = 256 x 256 wherever
+ * the shape allows, -1 = back to the environment (QVERSE_GEMM_T256) / default.  The tile shape never changes
+ * a result: both kernels form the same products in the same accumulation order. */
+int qv_debug_gemm_tiles(int32_t mode);
 
 /* Stage timers -- the device-side counterpart of C2C_DIRECT_MIXED_PROFILE (experiments/c2c-direct-mixed/
  * run.py:34,76-81,117-124: forward= decode= build= rerank= per file).  While enabled, every batch brackets

@@ -738,11 +738,23 @@ extern "C" int qv_profile_gemm(qv_engine *eng, int32_t enable) {
     return QV_OK;
 }
 
-extern "C" int qv_profile_gemm_read(qv_engine *eng, double *ms14, double *flops14, int32_t *launches14) {
-    if (!eng || !ms14 || !flops14 || !launches14) return QV_ERR_ARG;
-    int n[14];
-    qv_gemm_prof_collect(ms14, flops14, n);
-    for (int i = 0; i < 14; ++i) launches14[i] = n[i];
+extern "C" int qv_profile_gemm_read(qv_engine *eng, double *ms21, double *flops21, int32_t *launches21) {
+    if (!eng || !ms21 || !flops21 || !launches21) return QV_ERR_ARG;
+    int n[21];
+    qv_gemm_prof_collect(ms21, flops21, n);
+    for (int i = 0; i < 21; ++i) launches21[i] = n[i];
+    return QV_OK;
+}
+
+extern "C" int qv_profile_replay_kernel(qv_engine *eng, int32_t which, char *name_out, int32_t name_cap) {
+    if (!eng || !name_out || name_cap < 8) return QV_ERR_ARG;
+    if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
+    return qv_model_replay_kernel(eng, eng->model, which, name_out, name_cap);
+}
+
+extern "C" int qv_debug_gemm_tiles(int32_t mode) {
+    if (mode < -1 || mode > 2) return QV_ERR_ARG;
+    qv_gemm_set_t256(mode);
     return QV_OK;
 }
 

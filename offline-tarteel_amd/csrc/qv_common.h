@@ -189,6 +189,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio_dev, const i
                      int64_t n_max, float *logprobs_dev, int t_max, int32_t *t_out_host, hipStream_t stream);
 int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out_dev, hipStream_t stream);
 int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s);
+int qv_model_replay_kernel(qv_engine *eng, QvModel *m, int which, char *name_out, int cap);
 
 void qv_model_select_ctx(QvModel *m, int k);
 // records stage event `i` of the current context on `s` when stage profiling is on (qv_capi.hip)

@@ -682,9 +682,10 @@ void qv_gemm_prof_enable(bool on) {
     g_prof.flops.clear();
 }
 
-// call after the stream has been synchronised; accumulates into ms[14], flops[14], n[14]
+// call after the stream has been synchronised; accumulates into ms[21], flops[21], n[21]
+// (class = epilogue * 3 + tile: 0 = 64-wide, 1 = 128-wide, 2 = 256 x 256)
 void qv_gemm_prof_collect(double *ms, double *flops, int *n) {
-    for (int i = 0; i < 14; ++i) { ms[i] = 0; flops[i] = 0; n[i] = 0; }
+    for (int i = 0; i < 21; ++i) { ms[i] = 0; flops[i] = 0; n[i] = 0; }
     for (size_t i = 0; i < g_prof.cls.size(); ++i) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) continue;
@@ -730,39 +731,74 @@ static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool na
     }
 }
 
+static int g_t256 = -1;
+void qv_gemm_set_t256(int mode) { g_t256 = mode; }
+
+namespace {
+struct GemmPlan { bool wide, narrow; int nst; };
+
+// Tile and pipeline choice (measured per shape, tools/gemm_bench.hip):
+//  * 256 x 256 tiles, one block per CU (qv_gemm256.hip), for f16 weights when N % 256 == 0 and the grid still covers
+//    most of the chip (>= 160 tiles: FFN-up and QKV at B = 64 x 10 s, every N >= 512 shape at B = 256);
+//  * otherwise 128-wide tiles whenever N allows, register-staged loader waves (QVERSE_GEMM_LD=0: direct global->LDS
+//    loads with 2 stages at >= 400 tiles (two 64 KB blocks per CU), else 3, 4 when the K loop is long);
+//  * int4 weights with too few 128-wide tiles for two blocks per CU (FFN-down, out-projection: N = 512): the consumer
+//    wave of a lone block pays its dequantisation VALU in front of its own MFMAs; 64-wide tiles give every SIMD a
+//    second consumer wave to interleave with.
+GemmPlan gemm_plan(int epi, const GemmArgs &g) {
+    static const int env_nst = [] { const char *e = getenv("QVERSE_GEMM_NST"); return e ? atoi(e) : 0; }();
+    static const int env_narrow = [] { const char *e = getenv("QVERSE_GEMM_NARROW"); return e ? atoi(e) : -1; }();
+    static const int env_ld = [] { const char *e = getenv("QVERSE_GEMM_LD"); return e ? atoi(e) : 1; }();
+    static const int env_t256 = [] { const char *e = getenv("QVERSE_GEMM_T256"); return e ? atoi(e) : 1; }();
+    GemmPlan p;
+    p.narrow = g.N % 128 != 0;
+    if (g.Wq && !p.narrow && (g.N / 128) * ((g.M + 127) / 128) < 400) p.narrow = true;
+    if (env_narrow >= 0 && g.N % 128 == 0 && epi != EPI_GLU) p.narrow = env_narrow != 0;
+    const int tiles = (g.N / (p.narrow ? 64 : 128)) * ((g.M + 127) / 128);
+    p.nst = tiles >= 400 ? 2 : (g.K / 64 >= 16 ? 4 : 3);
+    if (p.narrow && p.nst > 3) p.nst = 3;
+    if (env_nst >= 2 && env_nst <= (p.narrow ? 3 : 4)) p.nst = env_nst;
+    if (env_ld == 1) p.nst = 0;
+    const int t256 = g_t256 >= 0 ? g_t256 : env_t256;
+    p.wide = false;
+    if (t256 > 0 && !g.Wq && !g.W8 && g.N % 256 == 0 && g.bias) {
+        const int tiles256 = (g.N / 256) * ((g.M + 255) / 256);
+        p.wide = t256 >= 2 || tiles256 >= 160;
+    }
+    return p;
+}
+}  // namespace
+
+// "k_gemm256<f16_swish>" / "k_gemm<resid,128>": the kernel launch_gemm picks for this call (measurement reports)
+const char *qv_gemm_kernel_name(int epi, const GemmArgs &g) {
+    static const char *EPI[7] = {"f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"};
+    static thread_local char buf[64];
+    const GemmPlan p = gemm_plan(epi, g);
+    if (p.wide) snprintf(buf, sizeof buf, "k_gemm256<%s>", EPI[epi]);
+    else snprintf(buf, sizeof buf, "k_gemm<%s,%d>", EPI[epi], p.narrow ? 64 : 128);
+    return buf;
+}
+
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     if (g.K % 64 != 0 || g.N % 64 != 0 || (g.Wq && g.K % 128 != 0)) {
         fprintf(stderr, "launch_gemm: unsupported shape N=%d K=%d\n", g.N, g.K);
         abort();
     }
-    // Tile and pipeline choice (measured per shape, tools/gemm_exp.hip): 128-wide tiles whenever N allows;
-    // with >= 400 tiles two 64 KB blocks share a CU (2 stages), with fewer tiles one block per CU
-    // gets a deeper pipeline instead (3 stages, 4 when the K loop is long).
-    static const int env_nst = [] { const char *e = getenv("QVERSE_GEMM_NST"); return e ? atoi(e) : 0; }();
-    static const int env_narrow = [] { const char *e = getenv("QVERSE_GEMM_NARROW"); return e ? atoi(e) : -1; }();
-    bool narrow = g.N % 128 != 0;
-    // int4 weights with too few 128-wide tiles for two blocks per CU (FFN-down, out-projection: N = 512): the
-    // consumer wave of a lone block pays its dequantisation VALU in front of its own MFMAs; 64-wide tiles give
-    // every SIMD a second consumer wave to interleave with
-    if (g.Wq && !narrow && (g.N / 128) * ((g.M + 127) / 128) < 400) narrow = true;
-    if (env_narrow >= 0 && g.N % 128 == 0 && epi != EPI_GLU) narrow = env_narrow != 0;
-    const int tiles = (g.N / (narrow ? 64 : 128)) * ((g.M + 127) / 128);
-    int nst = tiles >= 400 ? 2 : (g.K / 64 >= 16 ? 4 : 3);
-    if (narrow && nst > 3) nst = 3;
-    if (env_nst >= 2 && env_nst <= (narrow ? 3 : 4)) nst = env_nst;
-    // loader waves: MUBUF register staging by default (QVERSE_GEMM_LD=0 selects the direct global->LDS loads)
-    static const int env_ld = [] { const char *e = getenv("QVERSE_GEMM_LD"); return e ? atoi(e) : 1; }();
-    if (env_ld == 1) nst = 0;
-    if (!g_prof.on) { launch_gemm_inner(epi, g, s, narrow, nst); return; }
+    const GemmPlan p = gemm_plan(epi, g);
+    auto go = [&] {
+        if (p.wide && launch_gemm256(epi, g, s)) return;
+        launch_gemm_inner(epi, g, s, p.narrow, p.nst);
+    };
+    if (!g_prof.on) { go(); return; }
     size_t i = g_prof.cls.size();
     while (g_prof.ev.size() < 2 * (i + 1)) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { launch_gemm_inner(epi, g, s, narrow, nst); return; }
+        if (hipEventCreate(&e) != hipSuccess) { go(); return; }
         g_prof.ev.push_back(e);
     }
     (void)hipEventRecord(g_prof.ev[2 * i], s);
-    launch_gemm_inner(epi, g, s, narrow, nst);
+    go();
     (void)hipEventRecord(g_prof.ev[2 * i + 1], s);
-    g_prof.cls.push_back(epi * 2 + (narrow ? 0 : 1));
+    g_prof.cls.push_back(epi * 3 + (p.wide ? 2 : p.narrow ? 0 : 1));
     g_prof.flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
 }

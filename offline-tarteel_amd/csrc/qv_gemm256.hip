@@ -1,0 +1,408 @@
+// qv_gemm256.hip -- the wide-tile variant of the fused-epilogue f16 GEMM (see qv_gemm.hip, qv_kernels.h).
+//
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias) on 256 x 256 x 64 tiles, ONE 512-thread block per CU.
+//
+// Why a second tile shape.  The 128 x 128 kernel (4 consumer waves of 64 x 64 + 4 loader waves, two blocks per CU)
+// moves 32 KB through the CU's vector-memory path (64 B/clk) and 64 KB of fragment reads + 32 KB of stage
+// writes through the LDS array (256 B/clk reads, 128 B/clk wide writes) per 512 matrix-pipe cycles: both
+// paths are ~100 % busy at full MFMA rate, which is why its K loop sits at ~64 % matrix-pipe occupancy whatever
+// the loaders do (DESIGN.md "GEMM, round 2").  A 256 x 256 tile halves the operand bytes per flop on both
+// paths: per 64-deep K-tile a CU loads 64 KB (1024 cycles of the 64 B/clk path) and reads 192 KB of fragments
+// + writes 64 KB of stages (~1280 LDS-array cycles) for 2048 matrix-pipe cycles.
+//
+// Structure: 8 waves as 2 (M) x 4 (N), each owns a 128 x 64 sub-tile (4 x 2 accumulators of 32 x 32 = 128
+// registers), and every wave both stages and computes.  Per K-tile a wave requests its 8 pieces (4 of A, 4 of W,
+// 1 KB = 8 rows x 128 B each) with MUBUF buffer_load_dwordx4 (SGPR descriptor + 32-bit lane offset + scalar
+// K offset: no VALU per load, and unlike FLAT loads they issue next to a busy matrix pipe) into ONE 32-register
+// set one K-tile ahead, and writes them with ds_write_b128 into the other half of a 2-stage LDS ring during the
+// current K-tile: the A pieces in its first half, the W pieces in its second, each followed at once by the
+// requests for the K-tile after (hand-counted vmcnt: loads return in order).  One s_barrier per K-tile; fragment
+// reads are software-pipelined over the four 16-deep sub-steps (two register sets).  LDS image, swizzle and MFMA operand order are those of the 128 x 128 kernel, so every output is
+// BIT-IDENTICAL to it (same products, same accumulation order): tests/test_gpu_gemm256.py compares the two.
+//
+// Epilogue: wave-private.  Each wave pushes its sub-tile through its own 16 KB slice of the (now idle) stage
+// ring, 32 rows at a time, so that every global store is a 16-byte lane-contiguous piece of a 128-byte (f16) or
+// 256-byte (f32) row segment; no block barrier after the K loop's last one, waves drift apart and one wave's
+// stores overlap another's conversion VALU.
+
+#include "qv_kernels.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+constexpr bool out_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; }
+
+#ifdef QV_GEMM_TRACE   // dev tool only (tools/gemm256_trace.hip)
+#define QW_ABL(bit) (g.abl & (bit))
+#define QW_PHASE(slot) do { if (g.phase && tid == 0) g.phase[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = wall_clock64(); } while (0)
+#define QW_TRACE(kt) do { if (g.trace && lane == 0) g.trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 64 + (kt)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QW_ABL(bit) false
+#define QW_PHASE(slot) do { } while (0)
+#define QW_TRACE(kt) do { } while (0)
+#endif
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BN * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    QW_PHASE(0);
+    // XCD-aware tile order (bijective for any tile count): consecutive workgroup ids land on different XCDs;
+    // each XCD gets a contiguous run of tiles, which share A row panels in its private L2
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gx + blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ------------------------------------------------------------------ staging ----------
+    // piece q of this wave: tile rows wave*32 + q*8 .. +7 of A (and of W), 128 B per row; lane -> (row lane>>3,
+    // 16-byte chunk lane&7).  LDS rows are 128 B, chunk c of row r sits at c ^ ((r >> 1) & 7) (conflict-free
+    // ds_read_b128 fragment reads, same image as qv_gemm.hip).
+    const int nk = g.K / BK;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
+    unsigned offA[4], offB[4];
+    int dst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + q * 8 + (lane >> 3), c = lane & 7;
+        int grow = (QW_ABL(64) ? 0 : m0) + row;   // (ablation 64: every block loads tile (0, 0) -- all loads hit L2)
+        grow = grow < g.M ? grow : g.M - 1;   // rows past M repeat the last one; their outputs are never stored
+        offA[q] = (unsigned)(((size_t)grow * g.lda + c * 8) * 2);
+        offB[q] = (unsigned)(((size_t)((QW_ABL(64) ? 0 : n0) + row) * g.ldw + c * 8) * 2);
+        dst[q] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    }
+    u32x4 ra[4], rb[4];
+    auto fetchA = [&](int kt) {
+        if (QW_ABL(8)) return;
+        const int so = kt * (BK * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[q]) : "v"(offA[q]), "s"(rsA), "s"(so) : "memory");
+    };
+    auto fetchB = [&](int kt) {
+        if (QW_ABL(8)) return;
+        const int so = kt * (BK * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[q]) : "v"(offB[q]), "s"(rsB), "s"(so) : "memory");
+    };
+    auto putA = [&](int stage) {
+        if (QW_ABL(4)) return;
+        unsigned char *st = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4 *)(st + dst[q]) = ra[q];
+    };
+    auto putB = [&](int stage) {
+        if (QW_ABL(4)) return;
+        unsigned char *st = smem + stage * STAGE_BYTES + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4 *)(st + dst[q]) = rb[q];
+    };
+
+    fetchA(0);
+    fetchB(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    putA(0);
+    putB(0);
+    if (nk > 1) {
+        fetchA(1);
+        fetchB(1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    struct Frag { half8 a[4]; half8 b[2]; };
+    QW_PHASE(1);
+    // All eight waves run the same phase.  Fragment reads are software-pipelined under the wave's own MFMAs (two
+    // register sets, pinned with sched_barrier); the A pieces of tile kt + 1 are written (and the A pieces of tile
+    // kt + 2 requested) behind the first 8 MFMAs of K-tile kt, the W pieces behind the second 8; one barrier per
+    // K-tile.  Measured against this (tools/lds_mfma_bench.hip, DESIGN.md "GEMM, round 2b"): the two halves of the
+    // block running one phase apart (ping-pong: memory phase of waves 0..3 beside the MFMA phase of waves 4..7) and
+    // the 8 loads spread two per MFMA group -- neither was faster.
+    auto rd = [&](int stage, int ks, Frag &f) {
+        if (QW_ABL(2)) return;
+        const half_t *sA = (const half_t *)(smem + stage * STAGE_BYTES);
+        const half_t *sB = (const half_t *)((const unsigned char *)sA + A_BYTES);
+        const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wn * 64 + j * 32 + (lane & 31);
+            f.b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 128 + i * 32 + (lane & 31);
+            f.a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+        }
+    };
+    auto mma = [&](const Frag &f) {
+#if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+        if (QW_ABL(1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(f.a[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(f.b[j]));
+            return;
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per register quad
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        QW_TRACE(kt);
+        const int cur = kt & 1;
+        const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+        Frag f0 = {}, f1 = {};
+        rd(cur, 0, f0);
+        rd(cur, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has1) {
+            // outstanding, oldest first: A(kt+1) x4, W(kt+1) x4
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            putA(cur ^ 1);
+            if (has2) fetchA(kt + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rd(cur, 2, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has1) {
+            // outstanding: W(kt+1) x4 [, A(kt+2) x4]
+            if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            putB(cur ^ 1);
+            if (has2) fetchB(kt + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rd(cur, 3, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        // stage kt + 1 written (own ds_writes retired) and stage kt read by every wave
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    QW_TRACE(nk);
+    QW_PHASE(2);
+#if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+    if (QW_ABL(32)) {   // no epilogue at all (accumulators kept live)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+#endif
+    // ------------------------------------------------------------------ epilogue ----------
+    // accumulator (i, j), register r: tile row = wm*128 + i*32 + (lane & 31),
+    //   tile column = wn*64 + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+    const int l31 = lane & 31, hi = lane >> 5;
+    unsigned char *sW = smem + wave * 16384;   // this wave's private staging slice
+    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, g.N * 4, 0x00020000);
+    auto ldf4 = [&](const __amdgpu_buffer_rsrc_t &rs, int elem) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 0));
+    };
+    const int nb = n0 + wn * 64;          // first tile column of this wave
+    const int mb = m0 + wm * 128;         // first row of this wave
+    f32x4 bia[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bia[j][q] = ldf4(rs_bias, nb + j * 32 + 8 * q + 4 * hi);
+
+    if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
+        // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  64 frames at a time go through the wave's slice as
+        // [d][frame]; a store instruction then covers two d rows x 64 consecutive frames (4-byte frame pairs).
+        constexpr int LDV = 64 + 2;   // halves per d row (odd dword pitch)
+        half_t *sT = (half_t *)sW;
+        half_t *vt = (half_t *)g.out2;
+        const int fp = lane & 31, dsub = lane >> 5;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sT[(j * 32 + 8 * q + 4 * hi + e) * LDV + ii * 32 + l31] = (half_t)(acc[hh * 2 + ii][j][q * 4 + e] + bia[j][q][e]);
+            const int r0 = mb + hh * 64 + 2 * fp, r1 = r0 + 1;
+            const int bt0 = r0 < g.M ? g.row_map[r0] : -1, bt1 = r1 < g.M ? g.row_map[r1] : -1;
+            const bool pair = bt0 >= 0 && bt1 == bt0 + 1 && (bt0 & 1) == 0;   // same utterance, even frame: one 4-byte store
+            for (int dd = 0; dd < 32; ++dd) {
+                const int d = dd * 2 + dsub;
+                const size_t drow = (size_t)(nb - 2 * QV_D + d);
+                const half_t v0 = sT[d * LDV + 2 * fp], v1 = sT[d * LDV + 2 * fp + 1];
+                if (pair) {
+                    h2_t v = {v0, v1};
+                    *(h2_t *)(vt + ((size_t)(bt0 >> 16) * QV_D + drow) * g.t_pad + (bt0 & 0xFFFF)) = v;
+                } else {
+                    if (bt0 >= 0) vt[((size_t)(bt0 >> 16) * QV_D + drow) * g.t_pad + (bt0 & 0xFFFF)] = v0;
+                    if (bt1 >= 0) vt[((size_t)(bt1 >> 16) * QV_D + drow) * g.t_pad + (bt1 & 0xFFFF)] = v1;
+                }
+            }
+        }
+        return;
+    }
+
+    if (out_is_f32(EPI)) {
+        constexpr int LDT = 64 + 4;   // floats per staged row
+        float *sO = (float *)sW;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 4), 0x00020000);
+        const int rr = lane >> 4, cc = (lane & 15) * 4;   // read-back: 4 rows x 256 B per instruction
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 old[8];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = mb + i * 32 + k * 4 + rr;
+                    if (r < g.M && !QW_ABL(16)) old[k] = ldf4(rs_out, r * g.ldo + nb + cc);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = g.alpha * (acc[i][j][q * 4 + e] + bia[j][q][e]);
+                    *(f32x4 *)(sO + l31 * LDT + j * 32 + 8 * q + 4 * hi) = v;
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = mb + i * 32 + k * 4 + rr;
+                f32x4 v = *(const f32x4 *)(sO + (k * 4 + rr) * LDT + cc);
+                if (r >= g.M || QW_ABL(16)) { asm volatile("" ::"v"(v)); continue; }
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += old[k][e];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (r * g.ldo + nb + cc) * 4, 0, 0);
+            }
+        }
+        return;
+    }
+
+    if (EPI == EPI_GLU) {
+        // W rows interleaved in 32-channel groups, [value(32) | gate(32)] per 64 columns: this wave's two
+        // accumulator columns are one value / gate pair -> 32 output channels
+        constexpr int LDT = 32 + 8;
+        half_t *sO = (half_t *)sW;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 2), 0x00020000);
+        const int rr = lane >> 2, cc = (lane & 3) * 8;    // read-back: 16 rows x 64 B per instruction
+        const int nbo = n0 / 2 + wn * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = acc[i][0][q * 4 + e] + bia[0][q][e], gv = acc[i][1][q * 4 + e] + bia[1][q][e];
+                    o[e] = (half_t)(av * sigm(gv));
+                }
+                *(half4 *)(sO + l31 * LDT + 8 * q + 4 * hi) = o;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = mb + i * 32 + k * 16 + rr;
+                const u32x4 v = *(const u32x4 *)(sO + (k * 16 + rr) * LDT + cc);
+                if (r < g.M && !QW_ABL(16)) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (r * g.ldo + nbo + cc) * 2, 0, 0);
+            }
+        }
+        return;
+    }
+
+    {
+        constexpr int LDT = 64 + 8;   // halves per staged row
+        half_t *sO = (half_t *)sW;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 2), 0x00020000);
+        const int rr = lane >> 3, cc = (lane & 7) * 8;    // read-back: 8 rows x 128 B per instruction
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][q * 4 + e] + bia[j][q][e];
+                        if (EPI == EPI_F16_SWISH) x = x * sigm(x);
+                        if (EPI == EPI_F16_RELU) x = x > 0.f ? x : 0.f;
+                        o[e] = (half_t)x;
+                    }
+                    *(half4 *)(sO + l31 * LDT + j * 32 + 8 * q + 4 * hi) = o;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = mb + i * 32 + k * 8 + rr;
+                const u32x4 v = *(const u32x4 *)(sO + (k * 8 + rr) * LDT + cc);
+                if (r < g.M && !QW_ABL(16)) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (r * g.ldo + nb + cc) * 2, 0, 0);
+            }
+        }
+    }
+}
+
+template <int EPI>
+static void launch256(const GemmArgs &g, hipStream_t s) {
+    constexpr int LDS = 2 * (256 * 64 * 2) * 2;   // two stages of A + W tiles = 128 KB
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        opted = true;
+    }
+    hipLaunchKernelGGL((k_gemm256<EPI>), dim3(g.N / 256, (g.M + 255) / 256), dim3(512), LDS, s, g);
+}
+
+// f16 weights, N % 256 == 0, K % 64 == 0 only; returns false (nothing launched) for anything else
+bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s) {
+    if (g.Wq || g.W8 || g.N % 256 != 0 || g.K % 64 != 0 || !g.bias) return false;
+    switch (epi) {
+        case EPI_F16: launch256<EPI_F16>(g, s); break;
+        case EPI_F16_SWISH: launch256<EPI_F16_SWISH>(g, s); break;
+        case EPI_F16_RELU: launch256<EPI_F16_RELU>(g, s); break;
+        case EPI_RESID: launch256<EPI_RESID>(g, s); break;
+        case EPI_F32: launch256<EPI_F32>(g, s); break;
+        case EPI_QKV: launch256<EPI_QKV>(g, s); break;
+        case EPI_GLU: launch256<EPI_GLU>(g, s); break;
+        default: return false;
+    }
+    return true;
+}

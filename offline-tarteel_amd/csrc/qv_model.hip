@@ -712,12 +712,11 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
 // which: 0 FFN-up (N 2048, K 512, Swish), 1 FFN-down (N 512, K 2048, residual), 2 QKV, 3 attention
 // out-projection, 4 pointwise-conv + GLU.  The residual variants run with alpha = 0 so replaying
 // them does not disturb the stream.
-int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s) {
+static int replay_args(qv_engine *eng, QvModel *m, int which, GemmArgs &a, int &epi) {
     int M = m->last_rows;
-    if (M <= 0 || iters < 1) { qv_set_error(eng, "replay needs a previous forward"); return QV_ERR_ARG; }
+    if (M <= 0) { qv_set_error(eng, "replay needs a previous forward"); return QV_ERR_ARG; }
     const LayerW &L = m->L[0];
-    GemmArgs a = {};
-    int epi;
+    a = GemmArgs{};
     a.M = M; a.out2 = m->vt; a.t_max = m->last_tmax; a.t_pad = (m->last_tmax + 31) / 32 * 32; a.alpha = 1.f;
     a.row_map = m->row_map;
     const WMat *W;
@@ -731,6 +730,24 @@ int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, doubl
     }
     a.W = W->w; a.Wq = W->q; a.wscale = W->sc; a.W8 = W->q8; a.w8scale = W->sc8;
     a.lda = a.K; a.ldw = a.K;
+    return QV_OK;
+}
+
+int qv_model_replay_kernel(qv_engine *eng, QvModel *m, int which, char *name_out, int cap) {
+    GemmArgs a;
+    int epi = 0;
+    int rc = replay_args(eng, m, which, a, epi);
+    if (rc != QV_OK) return rc;
+    snprintf(name_out, (size_t)cap, "%s", qv_gemm_kernel_name(epi, a));
+    return QV_OK;
+}
+
+int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s) {
+    if (iters < 1) return QV_ERR_ARG;
+    GemmArgs a;
+    int epi = 0;
+    int rc = replay_args(eng, m, which, a, epi);
+    if (rc != QV_OK) return rc;
     hipEvent_t e0, e1;
     QV_HIP(hipEventCreate(&e0));
     QV_HIP(hipEventCreate(&e1));

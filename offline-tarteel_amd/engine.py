@@ -119,6 +119,8 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_gemm.argtypes = [vp, i32]
     lib.qv_profile_gemm_read.argtypes = [vp, vp, vp, vp]
     lib.qv_profile_replay_gemm.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.qv_profile_replay_kernel.argtypes = [vp, i32, C.c_char_p, i32]
+    lib.qv_debug_gemm_tiles.argtypes = [i32]
     lib.qv_profile_stages.argtypes = [vp, i32]
     lib.qv_stage_times.argtypes = [vp, i32, vp]
     _lib = lib
@@ -350,20 +352,26 @@ class Engine:
     # ---------------------------------------------------------------- measurement
     GEMM_EPILOGUES = ["f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"]
 
+    def gemm_tiles(self, mode: int):
+        """process-wide GEMM tile policy (qv_debug_gemm_tiles): 0 = 128-wide only, 1 = default, 2 = 256 x 256
+        wherever the shape allows, -1 = environment / default."""
+        self._check(self.lib.qv_debug_gemm_tiles(int(mode)), "qv_debug_gemm_tiles")
+
     def profile_gemm(self, enable: bool):
         self._check(self.lib.qv_profile_gemm(self.h, int(enable)), "qv_profile_gemm")
 
     def profile_gemm_read(self) -> list[dict]:
         """per GEMM kernel class: summed HIP-event ms, algorithmic FLOPs, launches."""
-        ms = np.zeros(14)
-        fl = np.zeros(14)
-        n = np.zeros(14, np.int32)
+        ms = np.zeros(21)
+        fl = np.zeros(21)
+        n = np.zeros(21, np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         self._check(self.lib.qv_profile_gemm_read(self.h, p(ms), p(fl), p(n)), "qv_profile_gemm_read")
         out = []
-        for c in range(14):
+        for c in range(21):
             if n[c]:
-                out.append({"kernel": f"k_gemm<{self.GEMM_EPILOGUES[c // 2]},{128 if c % 2 else 64}>",
+                epi, tile = self.GEMM_EPILOGUES[c // 3], c % 3
+                out.append({"kernel": f"k_gemm256<{epi}>" if tile == 2 else f"k_gemm<{epi},{128 if tile else 64}>",
                             "ms": float(ms[c]), "flops": float(fl[c]), "launches": int(n[c])})
         return out
 
@@ -380,7 +388,6 @@ class Engine:
         self._check(self.lib.qv_stage_times(self.h, ctx, ms.ctypes.data_as(C.c_void_p)), "qv_stage_times")
         return {k: float(v) * 1e-3 for k, v in zip(("forward", "decode", "build", "rerank"), ms)}
 
-    REPLAY_KERNELS = ["k_gemm<f16_swish,128>", "k_gemm<resid,64>", "k_gemm<qkv,128>", "k_gemm<resid,64>", "k_gemm<glu,128>"]
     REPLAY_SHAPES = ["FFN-up [M,512]x[512,2048]+Swish", "FFN-down [M,2048]x[2048,512]+residual", "QKV [M,512]x[512,1536]",
                      "attention out [M,512]x[512,512]+residual", "pointwise conv [M,512]x[512,1024]+GLU"]
 
@@ -390,7 +397,9 @@ class Engine:
         us, fl = C.c_double(), C.c_double()
         self._check(self.lib.qv_profile_replay_gemm(self.h, which, iters, C.byref(us), C.byref(fl), self._stream()),
                     "qv_profile_replay_gemm")
-        return {"kernel": self.REPLAY_KERNELS[which], "shape": self.REPLAY_SHAPES[which], "avg_us": us.value,
+        name = C.create_string_buffer(64)
+        self._check(self.lib.qv_profile_replay_kernel(self.h, which, name, 64), "qv_profile_replay_kernel")
+        return {"kernel": name.value.decode(), "shape": self.REPLAY_SHAPES[which], "avg_us": us.value,
                 "flops": fl.value, "launches": iters}
 
     # ---------------------------------------------------------------- debug ------

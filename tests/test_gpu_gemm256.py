@@ -1,0 +1,77 @@
+"""The 256 x 256-tile GEMM (csrc/qv_gemm256.hip) against the 128-wide one (csrc/qv_gemm.hip).
+
+Both kernels form the same f16 products and accumulate them in the same order (same MFMA
+instruction, same operand order, K walked in the same 16-deep steps), so the tile shape must not
+change a single bit of anything downstream: the log-probs of a whole forward are compared bit for
+bit under the three tile policies (0 = 128-wide only, 1 = default, 2 = 256 x 256 wherever
+N % 256 == 0 -- FFN-up/down, QKV incl. the transposed V store, out-projection, both pointwise
+convolutions incl. GLU, the subsampling projection), on ragged batches whose row counts are not
+multiples of 256.  The oracle comparison of the forward itself lives in test_gpu_forward.py."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import offline_tarteel_amd  # noqa: F401
+    from offline_tarteel_amd.engine import Engine
+
+    e = Engine(device=0, with_model=True, seed=11, max_batch=24, max_samples=160000)
+    yield e
+    e.gemm_tiles(-1)
+
+
+def _forward_bits(eng, audio, lens, mode):
+    import torch
+
+    eng.gemm_tiles(mode)
+    lp, T = eng.forward(audio, lens)
+    torch.cuda.synchronize()
+    return lp.cpu().numpy().view(np.uint32).copy(), list(T)
+
+
+@pytest.mark.parametrize("batch,samples", [(3, 48000), (24, 160000)])
+def test_tile_shape_does_not_change_a_bit_of_the_logprobs(eng, batch, samples):
+    import torch
+
+    from synth import synth_audio
+
+    audio = torch.from_numpy(synth_audio(batch, samples, seed=batch)).cuda()
+    lens = [samples - 1600 * (b % 5) for b in range(batch)]   # ragged: packed row counts are not tile multiples
+    for b in range(batch):
+        audio[b, lens[b]:] = 0
+    ref, T0 = _forward_bits(eng, audio, lens, 0)
+    assert np.isfinite(ref.view(np.float32)).all()
+    for mode in (1, 2):
+        got, T = _forward_bits(eng, audio, lens, mode)
+        assert T == T0
+        assert np.array_equal(got, ref), f"tile policy {mode}: {np.count_nonzero(got != ref)} words differ"
+
+
+def test_replay_reports_the_kernel_the_policy_picks(eng):
+    import torch
+
+    from synth import synth_audio
+
+    audio = torch.from_numpy(synth_audio(24, 160000, seed=2)).cuda()
+    eng.gemm_tiles(0)
+    eng.forward(audio, [160000] * 24)
+    torch.cuda.synchronize()
+    assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm<f16_swish,128>"
+    eng.gemm_tiles(2)
+    assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm256<f16_swish>"
+    assert eng.replay_gemm(1, iters=2)["kernel"] == "k_gemm256<resid>"
+    eng.gemm_tiles(1)   # 24 x 126 rows: 12 x 8 = 96 tiles of 256 x 256 for FFN-up -> below the 160-tile threshold
+    assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm<f16_swish,128>"
+    classes = {}
+    eng.gemm_tiles(2)
+    eng.profile_gemm(True)
+    eng.forward(audio, [160000] * 24)
+    torch.cuda.synchronize()
+    for c in eng.profile_gemm_read():
+        classes[c["kernel"]] = c["launches"]
+    eng.profile_gemm(False)
+    assert classes.get("k_gemm256<f16_swish>") == 34 and classes.get("k_gemm256<qkv>") == 17, classes

@@ -1,7 +1,9 @@
 // gemm_bench.hip -- standalone timing + correctness harness for csrc/qv_gemm.hip (dev tool).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_bench.hip -o tools/gemm_bench
-//   tools/gemm_bench [iters]
+//   tools/gemm_bench [iters] [M] [t256 mode: 0 = 128-wide tiles, 1 = default policy, 2 = 256 x 256 wherever N % 256 == 0]
+// Every shape the 256 x 256 kernel accepts is also compared BIT FOR BIT with the 128-wide kernel (all outputs).
 #include "../offline-tarteel_amd/csrc/qv_gemm.hip"
+#include "../offline-tarteel_amd/csrc/qv_gemm256.hip"
 
 #include <math.h>
 #include <stdlib.h>
@@ -18,6 +20,7 @@ static float frand(uint64_t &s) {
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 50;
     const int M = argc > 2 ? atoi(argv[2]) : 8064;
+    const int mode = argc > 3 ? atoi(argv[3]) : 1;
     struct Sh { const char *name; int epi, N, K, ldo; float alpha; } shapes[] = {
         {"ff_up    swish N2048 K512 ", EPI_F16_SWISH, 2048, 512, 2048, 1.f},
         {"ff_down  resid N512 K2048 ", EPI_RESID, 512, 2048, 512, 0.5f},
@@ -57,6 +60,26 @@ int main(int argc, char **argv) {
         g.A = dA; g.W = dW; g.bias = db; g.out = dO; g.out2 = dV;
         g.M = M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.ldo; g.alpha = sh.alpha;
         g.t_max = 126; g.t_pad = 128; g.row_map = dmap;
+        const size_t vbytes = (size_t)(M / 126 + 1) * 512 * 128 * 2;
+        long ndiff = -1;
+        if (sh.N % 256 == 0) {
+            // bit-for-bit: 128-wide tiles vs 256 x 256 tiles, every output byte (plus Vt for the QKV epilogue)
+            const size_t obytes = (size_t)M * sh.ldo * ((sh.epi == EPI_F32 || sh.epi == EPI_RESID) ? 4 : 2);
+            std::vector<unsigned char> o0(obytes), o1(obytes), v0(vbytes), v1(vbytes);
+            for (int pass = 0; pass < 2; ++pass) {
+                CK(hipMemset(dO, 0, maxO * 4));
+                CK(hipMemset(dV, 0, vbytes));
+                qv_gemm_set_t256(pass ? 2 : 0);
+                launch_gemm(sh.epi, g, 0);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(pass ? o1.data() : o0.data(), dO, obytes, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(pass ? v1.data() : v0.data(), dV, vbytes, hipMemcpyDeviceToHost));
+            }
+            ndiff = 0;
+            for (size_t i = 0; i < obytes; ++i) ndiff += o0[i] != o1[i];
+            if (sh.epi == EPI_QKV) for (size_t i = 0; i < vbytes; ++i) ndiff += v0[i] != v1[i];
+        }
+        qv_gemm_set_t256(mode);
         CK(hipMemset(dO, 0, maxO * 4));
         launch_gemm(sh.epi, g, 0);
         CK(hipDeviceSynchronize());
@@ -92,7 +115,7 @@ int main(int argc, char **argv) {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         double us = ms * 1e3 / iters, fl = 2.0 * M * sh.N * sh.K;
-        printf("%s %8.2f us  %7.1f TF/s  maxerr %.2e\n", sh.name, us, fl / us / 1e6, maxerr);
+        printf("%s %8.2f us  %7.1f TF/s  maxerr %.2e  bytes differing 128-wide vs 256x256: %ld\n", sh.name, us, fl / us / 1e6, maxerr, ndiff);
         int idx = (int)(&sh - shapes);
         tot_ms += per_layer[idx] * us;
         tot_fl += per_layer[idx] * fl;

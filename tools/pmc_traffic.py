@@ -20,7 +20,11 @@ EPI = ["f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"]
 
 
 def short_name(kernel: str):
-    """'void k_gemm<1, 128, 0, 2, 1>(GemmArgs)' -> 'k_gemm<f16_swish,128>' (+ loader / stage variant)."""
+    """'void k_gemm<1, 128, 0, 2, 1>(GemmArgs)' -> 'k_gemm<f16_swish,128>' (+ loader / stage variant);
+    'void k_gemm256<1>(GemmArgs)' -> 'k_gemm256<f16_swish>'."""
+    w = re.search(r"k_gemm256<(\d+)>", kernel)
+    if w:
+        return f"k_gemm256<{EPI[int(w.group(1))]}>", "256 x 256 tiles, one block per CU, every wave stages and computes"
     m = re.search(r"k_gemm<(\d+), (\d+), (\w+), (\d+)(?:, (\d+))?>", kernel)
     if not m:
         return None, None
