@@ -9,6 +9,13 @@
 
 #include "qv_kernels.h"
 
+// (dev switch for A/B builds of tools/gemm_bench.hip: -DQV_GEMM_NOSWAP = stage stores first, then the re-requests)
+#ifdef QV_GEMM_NOSWAP
+#define QV_SWAP false
+#else
+#define QV_SWAP true
+#endif
+
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -256,23 +263,40 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         // Barrier kt: stage kt is written (loaders) and stage kt - 1 is read (consumers).  Between barriers
         // kt - 1 and kt a loader writes stage kt -- the buffer the consumers left before barrier kt - 1 --
         // out of registers that were requested two K-steps ago, then requests K-step kt + 2 into them.
+        // put + fetch fused: write piece q of K-step kt, re-request it for K-step kt + 2 -- alternating stores and
+        // loads keeps the LDS store path and the address path busy at the same time
+        auto swap = [&](int kt, u32x4 (&r)[GR]) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GR) : "memory");   // (a newer batch is always in flight here)
+            unsigned char *st = smem + (kt % NST) * STAGE_BYTES;
+            const int sa = (kt + 2) * (BK * 2), sb = (kt + 2) * stepB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!QV_ABL(4)) *(u32x4 *)(st + dstA[q]) = r[q];
+                if (!QV_ABL(8)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[q]) : "v"(offA[q]), "s"(rsA), "s"(sa) : "memory");
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                if (!QV_ABL(4)) *(u32x4 *)(st + dstB[q]) = r[4 + q];
+                if (!QV_ABL(8)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[4 + q]) : "v"(offB[q]), "s"(rsB), "s"(sb) : "memory");
+            }
+        };
         fetch(0, r0);
         if (nk > 1) fetch(1, r1);
         for (int kt = 0; kt < nk; kt += 2) {
             int kt_ = kt;
             QV_TRACE(0);                       // barrier kt - 1 released
-            put(kt, r0, kt + 1 < nk);
+            if (kt + 2 < nk && QV_SWAP) swap(kt, r0);
+            else { put(kt, r0, kt + 1 < nk); if (kt + 2 < nk) fetch(kt + 2, r0); }
             QV_TRACE(1);                       // (s_memtime waits lgkmcnt: loads landed + writes done)
-            if (kt + 2 < nk) fetch(kt + 2, r0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             QV_TRACE(2);                       // arriving at barrier kt
             __builtin_amdgcn_s_barrier();
             if (kt + 1 < nk) {
                 kt_ = kt + 1;
                 QV_TRACE(0);
-                put(kt + 1, r1, kt + 2 < nk);
+                if (kt + 3 < nk && QV_SWAP) swap(kt + 1, r1);
+                else { put(kt + 1, r1, kt + 2 < nk); if (kt + 3 < nk) fetch(kt + 3, r1); }
                 QV_TRACE(1);
-                if (kt + 3 < nk) fetch(kt + 3, r1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 QV_TRACE(2);
                 __builtin_amdgcn_s_barrier();

@@ -124,6 +124,27 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         for (int q = 0; q < 4; ++q) *(u32x4 *)(st + dst[q]) = rb[q];
     };
 
+    // write piece q, re-request it for the tile after: alternating the two keeps the LDS store path and the
+    // address path busy at the same time (4 stores then 4 loads queue up behind one, then the other)
+    auto swapA = [&](int stage, int kt) {
+        unsigned char *st = smem + stage * STAGE_BYTES;
+        const int so = kt * (BK * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!QW_ABL(4)) *(u32x4 *)(st + dst[q]) = ra[q];
+            if (!QW_ABL(8)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[q]) : "v"(offA[q]), "s"(rsA), "s"(so) : "memory");
+        }
+    };
+    auto swapB = [&](int stage, int kt) {
+        unsigned char *st = smem + stage * STAGE_BYTES + A_BYTES;
+        const int so = kt * (BK * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!QW_ABL(4)) *(u32x4 *)(st + dst[q]) = rb[q];
+            if (!QW_ABL(8)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[q]) : "v"(offB[q]), "s"(rsB), "s"(so) : "memory");
+        }
+    };
+
     fetchA(0);
     fetchB(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -190,8 +211,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         if (has1) {
             // outstanding, oldest first: A(kt+1) x4, W(kt+1) x4
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            putA(cur ^ 1);
-            if (has2) fetchA(kt + 2);
+            if (has2 && QV_SWAP) swapA(cur ^ 1, kt + 2);
+            else { putA(cur ^ 1); if (has2) fetchA(kt + 2); }
         }
         __builtin_amdgcn_sched_barrier(0);
         rd(cur, 2, f0);
@@ -202,8 +223,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
             // outstanding: W(kt+1) x4 [, A(kt+2) x4]
             if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            putB(cur ^ 1);
-            if (has2) fetchB(kt + 2);
+            if (has2 && QV_SWAP) swapB(cur ^ 1, kt + 2);
+            else { putB(cur ^ 1); if (has2) fetchB(kt + 2); }
         }
         __builtin_amdgcn_sched_barrier(0);
         rd(cur, 3, f1);

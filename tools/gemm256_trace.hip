@@ -43,8 +43,8 @@ int main(int argc, char **argv) {
         const int nblk = (sh.N / 256) * ((M + 255) / 256), nk = sh.K / 64;
         printf("%s M=%d: %d blocks, %d K-tiles\n", sh.name, M, nblk, nk);
         const char *names[] = {"full", "no MFMA", "no frag reads", "no MFMA, no frag reads", "no ds_write", "no loads", "no loads, no ds_write",
-                               "MFMA only (no loads/writes/reads)", "barriers + epilogue only", "full K loop, no epilogue", "full, epilogue without global loads/stores", "K loop off, epilogue without global accesses", "K loop off, no epilogue", "full, all blocks load tile (0,0)", "no epilogue, all blocks load tile (0,0)", "full, no s_setprio", "MFMA only, no setprio"};
-        const int masks[] = {0, 1, 2, 3, 4, 8, 12, 14, 15, 32, 16, 15 + 16, 15 + 32, 64, 64 + 32, 128, 128 + 14};
+                               "MFMA only (no loads/writes/reads)", "barriers + epilogue only", "full K loop, no epilogue", "full, epilogue without global loads/stores", "K loop off, epilogue without global accesses", "K loop off, no epilogue", "full, all blocks load tile (0,0)", "no epilogue, all blocks load tile (0,0)", "full, stores then loads (not interleaved)", "full"};
+        const int masks[] = {0, 1, 2, 3, 4, 8, 12, 14, 15, 32, 16, 15 + 16, 15 + 32, 64, 64 + 32, 256, 0};
         for (int v = 0; v < 17; ++v) {
             g.abl = masks[v];
             for (int i = 0; i < 3; ++i) launch_gemm(sh.epi, g, 0);
@@ -57,9 +57,9 @@ int main(int argc, char **argv) {
             printf("    %-40s %7.2f us\n", names[v], ms * 1e3 / 20);
         }
         for (int rep = 0; rep < 3; ++rep) {
-        g.abl = rep == 1 ? 128 : 0;
+        g.abl = rep == 1 ? 256 : 0;
         if (rep == 2) CK(hipMemset(dA, 0, (size_t)M * 2560 * 2));
-        printf("    -- traced launch: %s\n", rep == 0 ? "full" : rep == 1 ? "no s_setprio (ablation 128)" : "full, A = 0");
+        printf("    -- traced launch: %s\n", rep == 0 ? "full" : rep == 1 ? "stores then loads (ablation 256)" : "full, A = 0");
         g.trace = nullptr; g.phase = dP;
         for (int i = 0; i < 5; ++i) launch_gemm(sh.epi, g, 0);
         CK(hipDeviceSynchronize());
@@ -91,18 +91,13 @@ int main(int argc, char **argv) {
         for (int b = 0; b < nblk; ++b) start_spread = std::max(start_spread, (double)(hP[b * 4] - t0) / 100.0);
         printf("    block timeline: prologue %.2f us, K loop %.2f us (mean over blocks); first entry -> last K-loop end %.2f us; entry spread %.2f us\n",
                pro / nblk, loop / nblk, (double)(t3 - t0) / 100.0, start_spread);
-        // per-phase shader cycles (s_memtime) of K-tile 3, wave 0 (group X) and wave 4 (group Y), mean over blocks:
-        // MEM(even) issue | wait + barrier | MMA + barrier | MEM(odd) issue | wait + barrier | MMA + barrier ; whole K-tile
-        for (int w = 0; w < 8; w += 4) {
-            double d[7] = {0, 0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < nblk; ++b) {
-                const unsigned long long *t = &hT[((size_t)b * 8 + w) * 64 + 3 * 8];
-                for (int k = 0; k < 6; ++k) d[k] += (double)(t[k + 1] - t[k]);
-                d[6] += (double)(t[8] - t[0]);
-            }
-            printf("    wave %d K-tile 3: MEM0 issue %.0f | drain+barrier %.0f | MMA0+barrier %.0f | MEM1 issue %.0f | drain+barrier %.0f | MMA1+barrier %.0f ; K-tile %.0f\n",
-                   w, d[0] / nblk, d[1] / nblk, d[2] / nblk, d[3] / nblk, d[4] / nblk, d[5] / nblk, d[6] / nblk);
+        printf("    K-tile cycles (wave 0, s_memtime):");
+        for (int kt = 0; kt < nk && kt < 12; ++kt) {
+            double sm = 0;
+            for (int b = 0; b < nblk; ++b) sm += (double)(hT[((size_t)b * 8) * 64 + kt + 1] - hT[((size_t)b * 8) * 64 + kt]);
+            printf(" %.0f", sm / nblk);
         }
+        printf("\n");
         g.trace = nullptr; g.phase = nullptr;
         }
         CK(hipMemcpy(dA, h.data(), (size_t)M * 2560 * 2, hipMemcpyHostToDevice));

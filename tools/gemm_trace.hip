@@ -5,6 +5,7 @@
 // the next barrier (= its ds_read + MFMA chain) and the time it then waits; for a loader wave the time
 // until its stage is written, until it has re-armed its loads, and its wait.
 #include "../offline-tarteel_amd/csrc/qv_gemm.hip"
+#include "../offline-tarteel_amd/csrc/qv_gemm256.hip"
 
 #include <math.h>
 #include <stdlib.h>
@@ -15,6 +16,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 int main() {
+    qv_gemm_set_t256(0);
     const int M = 8064;
     struct Sh { const char *name; int epi, N, K, ldo; float alpha; } shapes[] = {
         {"ff_up   N2048 K512 ", EPI_F16_SWISH, 2048, 512, 2048, 1.f},
@@ -43,9 +45,9 @@ int main() {
             CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             const char *names[] = {"full", "no MFMA", "no frag reads", "no MFMA, no frag reads", "no ds_write", "no loads", "no loads, no ds_write",
                                    "loaders idle + no frag reads (MFMA only)", "everything off (barriers + epilogue)",
-                                   "K loop off, epilogue without global loads/stores", "K loop off, no epilogue", "full K loop, no epilogue", "full, epilogue without global loads/stores"};
-            const int masks[] = {0, 1, 2, 3, 4, 8, 12, 14, 15, 15 + 16, 15 + 32, 32, 16};
-            for (int v = 0; v < 13; ++v) {
+                                   "K loop off, epilogue without global loads/stores", "K loop off, no epilogue", "full K loop, no epilogue", "full, epilogue without global loads/stores", "full, stores then loads (not interleaved)", "full"};
+            const int masks[] = {0, 1, 2, 3, 4, 8, 12, 14, 15, 15 + 16, 15 + 32, 32, 16, 256, 0};
+            for (int v = 0; v < 15; ++v) {
                 g.abl = masks[v];
                 for (int i = 0; i < 3; ++i) launch_gemm(sh.epi, g, 0);
                 CK(hipEventRecord(e0, 0));
