@@ -9,13 +9,6 @@
 
 #include "qv_kernels.h"
 
-// (dev switch for A/B builds of tools/gemm_bench.hip: -DQV_GEMM_NOSWAP = stage stores first, then the re-requests)
-#ifdef QV_GEMM_NOSWAP
-#define QV_SWAP false
-#else
-#define QV_SWAP true
-#endif
-
 #include <stdio.h>
 #include <stdlib.h>
 

@@ -71,6 +71,13 @@ struct GemmArgs {
 #endif
 };
 
+// (dev switch for A/B builds of tools/gemm_bench.hip: -DQV_GEMM_NOSWAP = stage stores first, then the re-requests)
+#ifdef QV_GEMM_NOSWAP
+#define QV_SWAP false
+#else
+#define QV_SWAP true
+#endif
+
 // WQ: 0 = f16 weights, 4 = W4A16, 8 = W8A16
 // LD: 0 = direct global->LDS loads with NST LDS stages, 1 = register-staged loader waves (NST = 2)
 template <int EPI, int BN, int WQ, int NST, int LD>
