@@ -8,6 +8,7 @@
 // time than the whole K loop.
 
 #include "qv_kernels.h"
+#include "qv_gemm_dequant.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,39 +38,6 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 #endif
 
 constexpr bool epi_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; }
-
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-
-// 8 int4 codes (one 4-byte chunk of the W4 layout) -> 8 halves (q - zp) * scale, in k order.
-// 0x6400 | x is the half 1024 + x, so the integer->float conversion is one OR; the subtraction of
-// off = 1024 + zp is exact and the product rounds once, i.e. the result is half((q - zp) * scale).
-__device__ __forceinline__ half8 dequant8(uint32_t q, half2_t s2, half2_t off) {
-    half8 r;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        uint32_t bits = ((q >> (4 * p)) & 0x000F000Fu) | 0x64006400u;
-        half2_t h = (__builtin_bit_cast(half2_t, bits) - off) * s2;
-        r[2 * p] = h[0];
-        r[2 * p + 1] = h[1];
-    }
-    return r;
-}
-
-// 8 bytes u = q + 128 -> 8 halves q, exactly: a byte next to 0x64 is the half 1024 + u (v_perm_b32 puts
-// it there), and (1024 + u) - 1152 = q needs no rounding.  The per-channel scale is applied in the epilogue.
-__device__ __forceinline__ half8 dequant8_i8(uint2 qv) {
-    const half2_t off = {(_Float16)1152.0f, (_Float16)1152.0f};
-    half8 r;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const uint32_t src = p < 2 ? qv.x : qv.y;
-        const uint32_t bits = __builtin_amdgcn_perm(0x64646464u, src, (p & 1) ? 0x04030402u : 0x04010400u);
-        const half2_t h = __builtin_bit_cast(half2_t, bits) - off;
-        r[2 * p] = h[0];
-        r[2 * p + 1] = h[1];
-    }
-    return r;
-}
 
 }  // namespace
 
@@ -755,7 +723,7 @@ namespace {
 struct GemmPlan { bool wide, narrow; int nst; };
 
 // Tile and pipeline choice (measured per shape, tools/gemm_bench.hip):
-//  * 256 x 256 tiles, one block per CU (qv_gemm256.hip), for f16 weights when N % 256 == 0 and the grid still covers
+//  * 256 x 256 tiles, one block per CU (qv_gemm256.hip), when N % 256 == 0 and the grid still covers
 //    most of the chip (>= 160 tiles: FFN-up and QKV at B = 64 x 10 s, every N >= 512 shape at B = 256);
 //  * otherwise 128-wide tiles whenever N allows, register-staged loader waves (QVERSE_GEMM_LD=0: direct global->LDS
 //    loads with 2 stages at >= 400 tiles (two 64 KB blocks per CU), else 3, 4 when the K loop is long);
@@ -778,7 +746,7 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
     if (env_ld == 1) p.nst = 0;
     const int t256 = g_t256 >= 0 ? g_t256 : env_t256;
     p.wide = false;
-    if (t256 > 0 && !g.Wq && !g.W8 && g.N % 256 == 0 && g.bias) {
+    if (t256 > 0 && g.N % 256 == 0 && g.bias && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
         const int tiles256 = (g.N / 256) * ((g.M + 255) / 256);
         p.wide = t256 >= 2 || tiles256 >= 160;
     }

@@ -26,6 +26,7 @@
 // stores overlap another's conversion VALU.
 
 #include "qv_kernels.h"
+#include "qv_gemm_dequant.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,7 +34,7 @@
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef half2_t h2_t;
 
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
@@ -51,10 +52,14 @@ constexpr bool out_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; 
 
 }  // namespace
 
-template <int EPI>
+// WQ: 0 = f16 weights, 4 = W4A16 (block-128 int4), 8 = W8A16 (per-channel int8); layouts in qv_kernels.h (GemmArgs)
+template <int EPI, int WQ>
 __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
+    constexpr bool W4 = WQ == 4, W8 = WQ == 8;
     constexpr int BM = 256, BN = 256, BK = 64;
-    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BN * BK * 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : W8 ? BN * BK : BN * BK * 2;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NBP = W4 ? 1 : W8 ? 2 : 4;   // 1 KB pieces of the W tile per wave per K-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,19 +89,39 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     // ds_read_b128 fragment reads, same image as qv_gemm.hip).
     const int nk = g.K / BK;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
-    unsigned offA[4], offB[4];
-    int dst[4];
+    const void *bbase = W4 ? (const void *)g.Wq : W8 ? (const void *)g.W8 : (const void *)g.W;
+    const size_t bbytes = W4 ? (size_t)g.N * g.K / 2 : W8 ? (size_t)g.N * g.K : (size_t)g.N * g.ldw * 2;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, (int)bbytes, 0x00020000);
+    constexpr int stepB = W4 ? 2048 : W8 ? 4096 : BK * 2;   // bytes between consecutive K-tiles of a W piece
+    unsigned offA[4], offB[NBP];
+    int dst[4], dstB[NBP];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = wave * 32 + q * 8 + (lane >> 3), c = lane & 7;
         int grow = (QW_ABL(64) ? 0 : m0) + row;   // (ablation 64: every block loads tile (0, 0) -- all loads hit L2)
         grow = grow < g.M ? grow : g.M - 1;   // rows past M repeat the last one; their outputs are never stored
         offA[q] = (unsigned)(((size_t)grow * g.lda + c * 8) * 2);
-        offB[q] = (unsigned)(((size_t)((QW_ABL(64) ? 0 : n0) + row) * g.ldw + c * 8) * 2);
         dst[q] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        if (!W4 && !W8) {
+            offB[q] = (unsigned)(((size_t)((QW_ABL(64) ? 0 : n0) + row) * g.ldw + c * 8) * 2);
+            dstB[q] = A_BYTES + dst[q];
+        }
     }
-    u32x4 ra[4], rb[4];
+    if (W4) {
+        // 64 x 64 nibble tiles, 2 KB contiguous and already in the LDS order: one 1 KB piece (32 tile rows) per wave
+        offB[0] = (unsigned)(((size_t)((n0 >> 6) + (wave >> 1)) * nk) * 2048 + (wave & 1) * 1024 + lane * 16);
+        dstB[0] = A_BYTES + wave * 1024 + lane * 16;
+    }
+    if (W8) {
+        // 64 x 64 byte tiles, 4 KB contiguous and already in the LDS order: two 1 KB pieces (16 tile rows each) per wave
+#pragma unroll
+        for (int q = 0; q < (W8 ? 2 : 0); ++q) {
+            const int pc = wave * 2 + q;
+            offB[q] = (unsigned)(((size_t)((n0 >> 6) + (pc >> 2)) * nk) * 4096 + (pc & 3) * 1024 + lane * 16);
+            dstB[q] = A_BYTES + pc * 1024 + lane * 16;
+        }
+    }
+    u32x4 ra[4], rb[NBP];
     auto fetchA = [&](int kt) {
         if (QW_ABL(8)) return;
         const int so = kt * (BK * 2);
@@ -106,9 +131,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     };
     auto fetchB = [&](int kt) {
         if (QW_ABL(8)) return;
-        const int so = kt * (BK * 2);
+        const int so = kt * stepB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NBP; ++q)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[q]) : "v"(offB[q]), "s"(rsB), "s"(so) : "memory");
     };
     auto putA = [&](int stage) {
@@ -119,9 +144,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     };
     auto putB = [&](int stage) {
         if (QW_ABL(4)) return;
-        unsigned char *st = smem + stage * STAGE_BYTES + A_BYTES;
+        unsigned char *st = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4 *)(st + dst[q]) = rb[q];
+        for (int q = 0; q < NBP; ++q) *(u32x4 *)(st + dstB[q]) = rb[q];
     };
 
     // write piece q, re-request it for the tile after: alternating the two keeps the LDS store path and the
@@ -136,14 +161,24 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         }
     };
     auto swapB = [&](int stage, int kt) {
-        unsigned char *st = smem + stage * STAGE_BYTES + A_BYTES;
-        const int so = kt * (BK * 2);
+        unsigned char *st = smem + stage * STAGE_BYTES;
+        const int so = kt * stepB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (!QW_ABL(4)) *(u32x4 *)(st + dst[q]) = rb[q];
+        for (int q = 0; q < NBP; ++q) {
+            if (!QW_ABL(4)) *(u32x4 *)(st + dstB[q]) = rb[q];
             if (!QW_ABL(8)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[q]) : "v"(offB[q]), "s"(rsB), "s"(so) : "memory");
         }
     };
+
+    // W4: this tile's {scale, 1024 + zero point} pairs [K/128][BN] stay in LDS behind the stage ring for the whole K loop
+    h2_t *sS = (h2_t *)(smem + 2 * STAGE_BYTES);
+    if (W4) {
+        const int nkb = g.K >> 7;
+        for (int idx = tid; idx < BN * nkb; idx += 512) {
+            const int kb = idx / BN, n = idx - kb * BN;
+            sS[idx] = ((const h2_t *)g.wscale)[(size_t)kb * g.N + n0 + n];
+        }
+    }
 
     fetchA(0);
     fetchB(0);
@@ -157,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    struct Frag { half8 a[4]; half8 b[2]; };
+    struct Frag { half8 a[4]; half8 b[2]; uint32_t q4[2]; uint2 q8[2]; };
     QW_PHASE(1);
     // All eight waves run the same phase.  Fragment reads are software-pipelined under the wave's own MFMAs (two
     // register sets, pinned with sched_barrier); the A pieces of tile kt + 1 are written (and the A pieces of tile
@@ -173,7 +208,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = wn * 64 + j * 32 + (lane & 31);
-            f.b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+            if (W4)        // 32-byte rows, 4-byte chunk c at c ^ ((row >> 2) & 7): conflict-free ds_read_b32
+                f.q4[j] = *(const uint32_t *)((const unsigned char *)sB + row * 32 + ((c ^ ((row >> 2) & 7)) << 2));
+            else if (W8)   // 64-byte rows in 4 KB tiles of 64 rows, 8-byte chunk c at c ^ ((row >> 2) & 7); bytes are q + 128
+                f.q8[j] = *(const uint2 *)((const unsigned char *)sB + (row >> 6) * 4096 + (row & 63) * 64 + ((c ^ ((row >> 2) & 7)) << 3));
+            else
+                f.b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -181,13 +221,17 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
             f.a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
         }
     };
+    h2_t sc[2], zo[2];   // W4: this K-tile's scale / offset pairs of the wave's two column fragments
     auto mma = [&](const Frag &f) {
+        half8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = W4 ? dequant8(f.q4[j], sc[j], zo[j]) : W8 ? dequant8_i8(f.q8[j]) : f.b[j];
 #if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
         if (QW_ABL(1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(f.a[i]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(f.b[j]));
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[j]));
             return;
         }
 #endif
@@ -196,21 +240,29 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per register quad
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
     };
     for (int kt = 0; kt < nk; ++kt) {
         QW_TRACE(kt);
         const int cur = kt & 1;
         const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
         Frag f0 = {}, f1 = {};
+        if (W4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const h2_t sz = sS[(kt >> 1) * BN + wn * 64 + j * 32 + (lane & 31)];
+                sc[j] = h2_t{sz[0], sz[0]};
+                zo[j] = h2_t{sz[1], sz[1]};
+            }
+        }
         rd(cur, 0, f0);
         rd(cur, 1, f1);
         __builtin_amdgcn_sched_barrier(0);
         mma(f0);
         __builtin_amdgcn_sched_barrier(0);
         if (has1) {
-            // outstanding, oldest first: A(kt+1) x4, W(kt+1) x4
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // outstanding, oldest first: A(kt+1) x4, W(kt+1) x NBP
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
             if (has2 && QV_SWAP) swapA(cur ^ 1, kt + 2);
             else { putA(cur ^ 1); if (has2) fetchA(kt + 2); }
         }
@@ -220,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         mma(f1);
         __builtin_amdgcn_sched_barrier(0);
         if (has1) {
-            // outstanding: W(kt+1) x4 [, A(kt+2) x4]
+            // outstanding: W(kt+1) x NBP [, A(kt+2) x4]
             if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (has2 && QV_SWAP) swapB(cur ^ 1, kt + 2);
@@ -258,11 +310,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     };
     const int nb = n0 + wn * 64;          // first tile column of this wave
     const int mb = m0 + wm * 128;         // first row of this wave
-    f32x4 bia[2][4];
+    f32x4 bia[2][4], scl[2][4];   // scl: per-channel weight scales (W8A16 only)
+    const __amdgpu_buffer_rsrc_t rs_scl = __builtin_amdgcn_make_buffer_rsrc((void *)(W8 ? g.w8scale : g.bias), 0, g.N * 4, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bia[j][q] = ldf4(rs_bias, nb + j * 32 + 8 * q + 4 * hi);
+        for (int q = 0; q < 4; ++q) {
+            bia[j][q] = ldf4(rs_bias, nb + j * 32 + 8 * q + 4 * hi);
+            if (W8) scl[j][q] = ldf4(rs_scl, nb + j * 32 + 8 * q + 4 * hi);
+        }
 
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
         // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  64 frames at a time go through the wave's slice as
@@ -322,7 +378,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = g.alpha * (acc[i][j][q * 4 + e] + bia[j][q][e]);
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][q * 4 + e];
+                        if (W8) x *= scl[j][q][e];
+                        v[e] = g.alpha * (x + bia[j][q][e]);
+                    }
                     *(f32x4 *)(sO + l31 * LDT + j * 32 + 8 * q + 4 * hi) = v;
                 }
 #pragma unroll
@@ -355,7 +415,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float av = acc[i][0][q * 4 + e] + bia[0][q][e], gv = acc[i][1][q * 4 + e] + bia[1][q][e];
+                    float av = acc[i][0][q * 4 + e], gv = acc[i][1][q * 4 + e];
+                    if (W8) { av *= scl[0][q][e]; gv *= scl[1][q][e]; }
+                    av += bia[0][q][e];
+                    gv += bia[1][q][e];
                     o[e] = (half_t)(av * sigm(gv));
                 }
                 *(half4 *)(sO + l31 * LDT + 8 * q + 4 * hi) = o;
@@ -401,28 +464,49 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     }
 }
 
-template <int EPI>
+template <int EPI, int WQ>
 static void launch256(const GemmArgs &g, hipStream_t s) {
-    constexpr int LDS = 2 * (256 * 64 * 2) * 2;   // two stages of A + W tiles = 128 KB
+    constexpr int LDS = 2 * (256 * 64 * 2) * 2;   // two stages of f16 A + W tiles = 128 KB = the eight epilogue slices
     static bool opted = false;
     if (!opted) {
-        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         opted = true;
     }
-    hipLaunchKernelGGL((k_gemm256<EPI>), dim3(g.N / 256, (g.M + 255) / 256), dim3(512), LDS, s, g);
+    hipLaunchKernelGGL((k_gemm256<EPI, WQ>), dim3(g.N / 256, (g.M + 255) / 256), dim3(512), LDS, s, g);
 }
 
-// f16 weights, N % 256 == 0, K % 64 == 0 only; returns false (nothing launched) for anything else
+// N % 256 == 0, K % 64 == 0 (int4: K % 128 == 0, K <= 4096 for the scale table in LDS); false = nothing launched
 bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s) {
-    if (g.Wq || g.W8 || g.N % 256 != 0 || g.K % 64 != 0 || !g.bias) return false;
+    if (g.N % 256 != 0 || g.K % 64 != 0 || !g.bias) return false;
+    if (g.Wq) {
+        // int4 weights: the Linear layers (FFN, QKV, attention out, linear_pos)
+        if (g.K % 128 != 0 || g.K > 4096) return false;
+        switch (epi) {
+            case EPI_F16: launch256<EPI_F16, 4>(g, s); break;
+            case EPI_F16_SWISH: launch256<EPI_F16_SWISH, 4>(g, s); break;
+            case EPI_RESID: launch256<EPI_RESID, 4>(g, s); break;
+            case EPI_QKV: launch256<EPI_QKV, 4>(g, s); break;
+            default: return false;
+        }
+        return true;
+    }
+    if (g.W8) {
+        // int8 weights: the pointwise convolutions of the conv module
+        switch (epi) {
+            case EPI_GLU: launch256<EPI_GLU, 8>(g, s); break;
+            case EPI_RESID: launch256<EPI_RESID, 8>(g, s); break;
+            default: return false;
+        }
+        return true;
+    }
     switch (epi) {
-        case EPI_F16: launch256<EPI_F16>(g, s); break;
-        case EPI_F16_SWISH: launch256<EPI_F16_SWISH>(g, s); break;
-        case EPI_F16_RELU: launch256<EPI_F16_RELU>(g, s); break;
-        case EPI_RESID: launch256<EPI_RESID>(g, s); break;
-        case EPI_F32: launch256<EPI_F32>(g, s); break;
-        case EPI_QKV: launch256<EPI_QKV>(g, s); break;
-        case EPI_GLU: launch256<EPI_GLU>(g, s); break;
+        case EPI_F16: launch256<EPI_F16, 0>(g, s); break;
+        case EPI_F16_SWISH: launch256<EPI_F16_SWISH, 0>(g, s); break;
+        case EPI_F16_RELU: launch256<EPI_F16_RELU, 0>(g, s); break;
+        case EPI_RESID: launch256<EPI_RESID, 0>(g, s); break;
+        case EPI_F32: launch256<EPI_F32, 0>(g, s); break;
+        case EPI_QKV: launch256<EPI_QKV, 0>(g, s); break;
+        case EPI_GLU: launch256<EPI_GLU, 0>(g, s); break;
         default: return false;
     }
     return true;

@@ -89,7 +89,7 @@ void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out)
 void qv_pack_w8(const float *w, int N, int K, uint8_t *q_out, float *scale_out);
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);
-// 256 x 256 tiles, one block per CU (qv_gemm256.hip): f16 weights and N % 256 == 0 only; false = nothing launched
+// 256 x 256 tiles, one block per CU (qv_gemm256.hip): N % 256 == 0 only; false = nothing launched
 bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s);
 // tile policy of launch_gemm: 0 = 128-wide tiles only, 1 = 256 x 256 where the grid has >= 160 tiles (default), 2 = 256 x 256 wherever the shape allows; -1 = back to QVERSE_GEMM_T256 / the default
 void qv_gemm_set_t256(int mode);

@@ -14,14 +14,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["fp16", "int4_int8"])
+def eng(request):
+    """precision 0 = f16 weights, 1 = QV_PREC_MIXED_INT4_INT8 (block-128 int4 Linear layers + per-channel int8
+    pointwise convolutions, dequantised inside the MFMA operand fetch of either tile shape)."""
     import offline_tarteel_amd  # noqa: F401
     from offline_tarteel_amd.engine import Engine
 
-    e = Engine(device=0, with_model=True, seed=11, max_batch=24, max_samples=160000)
+    e = Engine(device=0, with_model=True, seed=11, max_batch=24, max_samples=160000, precision=request.param)
+    e.mixed = bool(request.param)
     yield e
     e.gemm_tiles(-1)
+    del e
 
 
 def _forward_bits(eng, audio, lens, mode):
@@ -60,12 +64,15 @@ def test_replay_reports_the_kernel_the_policy_picks(eng):
     eng.gemm_tiles(0)
     eng.forward(audio, [160000] * 24)
     torch.cuda.synchronize()
-    assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm<f16_swish,128>"
+    # (int4 weights with fewer than 400 tiles of 128: 64-wide tiles, see launch_gemm's plan)
+    small = "64" if eng.mixed else "128"
+    assert eng.replay_gemm(0, iters=2)["kernel"] == f"k_gemm<f16_swish,{small}>"
+    assert eng.replay_gemm(1, iters=2)["kernel"] == f"k_gemm<resid,{small}>"
     eng.gemm_tiles(2)
     assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm256<f16_swish>"
     assert eng.replay_gemm(1, iters=2)["kernel"] == "k_gemm256<resid>"
     eng.gemm_tiles(1)   # 24 x 126 rows: 12 x 8 = 96 tiles of 256 x 256 for FFN-up -> below the 160-tile threshold
-    assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm<f16_swish,128>"
+    assert eng.replay_gemm(0, iters=2)["kernel"] == f"k_gemm<f16_swish,{small}>"
     classes = {}
     eng.gemm_tiles(2)
     eng.profile_gemm(True)
