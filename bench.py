@@ -352,6 +352,10 @@ def main():
             "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "mfma_util_pmc": mfma_util, "mfma_util_source": mfma_source,
             "flops_per_launch": rep["flops"], "avg_launch_us": round(rep["avg_us"], 2), "launches": rep["launches"],
+            "tile_policy": (f"{1 if tta else args.contexts} batches in flight: 256 x 256 tiles (one block per CU) for every GEMM with N % 256 == 0 and "
+                            + (">= 128 such tiles, or K >= 2048 (FFN-down and the subsampling projection run 64 blocks: fewer CU-microseconds "
+                               "per GEMM, the other batches' kernels take the idle CUs; profiles/r02_f_tile_policy_sweep.txt)" if (1 if tta else args.contexts) >= 3
+                               else ">= 160 such tiles") + ", 128-wide tiles otherwise; other_gemms are stand-alone replays under that policy"),
             "other_gemms": {eng.REPLAY_SHAPES[w]: round((lambda r: r["flops"] / (r["avg_us"] * 1e-6) / 1e12)(eng.replay_gemm(w, 50)), 1)
                             for w in (1, 2, 3, 4)},
             "all_gemm_in_situ_tflops": round(sum(c["flops"] for c in classes) / (gemm_ms * 1e-3) / 1e12, 2),

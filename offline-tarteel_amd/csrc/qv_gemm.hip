@@ -723,8 +723,8 @@ namespace {
 struct GemmPlan { bool wide, narrow; int nst; };
 
 // Tile and pipeline choice (measured per shape, tools/gemm_bench.hip):
-//  * 256 x 256 tiles, one block per CU (qv_gemm256.hip), when N % 256 == 0 and the grid still covers
-//    most of the chip (>= 160 tiles: FFN-up and QKV at B = 64 x 10 s, every N >= 512 shape at B = 256);
+//  * 256 x 256 tiles, one block per CU (qv_gemm256.hip), when N % 256 == 0 and the grid is large enough (see below:
+//    FFN-up and QKV at B = 64 x 10 s, every N >= 512 shape at B = 256; more shapes with >= 3 batches in flight);
 //  * otherwise 128-wide tiles whenever N allows, register-staged loader waves (QVERSE_GEMM_LD=0: direct global->LDS
 //    loads with 2 stages at >= 400 tiles (two 64 KB blocks per CU), else 3, 4 when the K loop is long);
 //  * int4 weights with too few 128-wide tiles for two blocks per CU (FFN-down, out-projection: N = 512): the consumer
@@ -748,7 +748,16 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
     p.wide = false;
     if (t256 > 0 && g.N % 256 == 0 && g.bias && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
         const int tiles256 = (g.N / 256) * ((g.M + 255) / 256);
-        p.wide = t256 >= 2 || tiles256 >= 160;
+        // one batch at a time: a 256 x 256 grid must cover most of the chip (>= 160 tiles) or the 128-wide kernel's
+        // 252+ blocks finish sooner; with >= 3 batches in flight the other batches' kernels take the idle CUs and
+        // what counts is CU time per GEMM -- 128 tiles are enough, and the long-K shapes (FFN-down, the
+        // subsampling projection: 64 tiles at B = 64 x 10 s) go wide as well (+2.3 % end to end, same-box sweep)
+        static const int env_min = [] { const char *e = getenv("QVERSE_GEMM_MINTILES"); return e ? atoi(e) : 0; }();
+        static const int env_min_longk = [] { const char *e = getenv("QVERSE_GEMM_MINTILES_LONGK"); return e ? atoi(e) : 0; }();
+        const bool busy = g.in_flight >= 3;
+        const int min_tiles = env_min > 0 ? env_min : busy ? 128 : 160;
+        const int min_tiles_longk = env_min_longk > 0 ? env_min_longk : busy ? 1 : 160;
+        p.wide = t256 >= 2 || tiles256 >= (g.K >= 2048 ? min_tiles_longk : min_tiles);
     }
     return p;
 }

@@ -47,6 +47,7 @@ struct GemmArgs {
     void *out2;           // EPI_QKV: Vt
     int M, N, K, lda, ldw, ldo;
     float alpha;
+    int in_flight;        // batches the engine keeps in flight on the device (execution contexts); 0/1 = one -- tile policy only
     int t_max, t_pad;     // EPI_QKV
     const int32_t *row_map;  // EPI_QKV: [M] (utterance << 16 | frame) of each packed row
     // W4A16 variant (Wq != nullptr, W unused): block-128 int4 weights, w = (q - zero_point) * scale.

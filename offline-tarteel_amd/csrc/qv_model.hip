@@ -643,6 +643,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     // Linear(2560 -> 512) and xscaling (x * sqrt(d_model)) in one epilogue
     g.A = m->c2k; g.W = m->sub_out_w; g.bias = m->sub_out_b; g.out = m->x;
     g.M = M; g.N = QV_D; g.K = 2560; g.lda = 2560; g.ldw = 2560; g.ldo = QV_D; g.alpha = sqrtf((float)QV_D);
+    g.in_flight = m->n_ctx;
     launch_gemm(EPI_F32, g, s);
     } else {
         launch_pack_rows(m->c2p, t3m, 10 * QV_SUBC, d_l3, d_off, m->c2k, m->row_map, B, s);
@@ -657,7 +658,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             GemmArgs a = {};
             a.A = A; a.W = W.w; a.Wq = W.q; a.wscale = W.sc; a.W8 = W.q8; a.w8scale = W.sc8; a.bias = bias; a.out = out; a.out2 = m->vt;
             a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = ldo; a.alpha = alpha; a.t_max = T; a.t_pad = t_pad;
-            a.row_map = m->row_map;
+            a.row_map = m->row_map; a.in_flight = m->n_ctx;
             if (!(skip & 64)) launch_gemm(epi, a, s);
             if ((dup & 64) && epi != EPI_RESID) launch_gemm(epi, a, s);
         };
@@ -718,7 +719,7 @@ static int replay_args(qv_engine *eng, QvModel *m, int which, GemmArgs &a, int &
     const LayerW &L = m->L[0];
     a = GemmArgs{};
     a.M = M; a.out2 = m->vt; a.t_max = m->last_tmax; a.t_pad = (m->last_tmax + 31) / 32 * 32; a.alpha = 1.f;
-    a.row_map = m->row_map;
+    a.row_map = m->row_map; a.in_flight = m->n_ctx;
     const WMat *W;
     switch (which) {
         case 0: epi = EPI_F16_SWISH; a.A = m->ln; W = &L.ff1_w1; a.bias = L.ff1_b1; a.out = m->hbuf; a.N = QV_FF; a.K = QV_D; a.ldo = QV_FF; break;

@@ -21,10 +21,12 @@ EPI = ["f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"]
 
 def short_name(kernel: str):
     """'void k_gemm<1, 128, 0, 2, 1>(GemmArgs)' -> 'k_gemm<f16_swish,128>' (+ loader / stage variant);
-    'void k_gemm256<1>(GemmArgs)' -> 'k_gemm256<f16_swish>'."""
-    w = re.search(r"k_gemm256<(\d+)>", kernel)
+    'void k_gemm256<1, 0>(GemmArgs)' -> 'k_gemm256<f16_swish>'."""
+    w = re.search(r"k_gemm256<(\d+)(?:, (\d+))?>", kernel)
     if w:
-        return f"k_gemm256<{EPI[int(w.group(1))]}>", "256 x 256 tiles, one block per CU, every wave stages and computes"
+        wq = int(w.group(2) or 0)
+        return (f"k_gemm256<{EPI[int(w.group(1))]}>",
+                "256 x 256 tiles, one block per CU, every wave stages and computes" + (f", int{wq} weights" if wq else ""))
     m = re.search(r"k_gemm<(\d+), (\d+), (\w+), (\d+)(?:, (\d+))?>", kernel)
     if not m:
         return None, None
@@ -35,11 +37,17 @@ def short_name(kernel: str):
     return name, variant
 
 
+LAUNCHES = {}   # kernel name -> launches seen in the last CSV read (tools/gemm_bench also runs every kernel once, cold,
+                # for its bit-for-bit comparison of the two tile shapes: a count of 1-2 marks such a row)
+
+
 def mean_by_kernel(path, counter):
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        LAUNCHES[k] = len(v)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -58,7 +66,7 @@ def traffic(argv):
             continue
         w = write.get(k, 0.0)
         out["kernels"][short] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_size_kib_raw": round(f, 1),
-                                 "write_size_kib": round(w, 1), "variant": variant, "rocprof_name": k}
+                                 "write_size_kib": round(w, 1), "variant": variant, "rocprof_name": k, "launches": LAUNCHES.get(k)}
     json.dump(out, open(argv[2], "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
@@ -87,7 +95,7 @@ def mfma(argv):
         if short is None:
             continue
         e = {n: per[n].get(k) for n in names if per[n].get(k) is not None}
-        row = {"variant": variant, "rocprof_name": k, **{n: round(v, 1) for n, v in e.items()}}
+        row = {"variant": variant, "rocprof_name": k, "launches": LAUNCHES.get(k), **{n: round(v, 1) for n, v in e.items()}}
         if e.get("SQ_WAVE_CYCLES"):
             wc = e["SQ_WAVE_CYCLES"]
             for n, key in (("SQ_WAIT_ANY", "frac_wave_cycles_parked"), ("SQ_WAIT_INST_ANY", "frac_wave_cycles_issue_stalled"),
