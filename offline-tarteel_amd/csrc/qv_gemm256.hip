@@ -31,6 +31,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -242,10 +244,26 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
                 // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per register quad
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
     };
-    for (int kt = 0; kt < nk; ++kt) {
+    // accumulator (i, j), register r: tile row = wm*128 + i*32 + (lane & 31),
+    //   tile column = wn*64 + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+    const int l31 = lane & 31, hi = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, g.N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_scl = __builtin_amdgcn_make_buffer_rsrc((void *)(W8 ? g.w8scale : g.bias), 0, g.N * 4, 0x00020000);
+    auto ldf4 = [&](const __amdgpu_buffer_rsrc_t &rs, int elem) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 0));
+    };
+    const int nb = n0 + wn * 64;          // first tile column of this wave
+    const int mb = m0 + wm * 128;         // first row of this wave
+    f32x4 bia[2][4], scl[2][4];           // bias (and, W8A16, per-channel weight scales) of the wave's 64 columns
+
+    // The last K-tile is written out separately (it stages nothing): +3 % on the long-K residual shapes.  Requesting
+    // the epilogue's bias vectors at its top, and K-tiles 0 and 1 back to back at start-up, were measured on top of
+    // that and are not in: neutral at M = 8064, -4 % on FFN-up / GLU at M = 32,256.
+    auto ktile = [&](int kt, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         QW_TRACE(kt);
         const int cur = kt & 1;
-        const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+        const bool has2 = kt + 2 < nk;
         Frag f0 = {}, f1 = {};
         if (W4) {
 #pragma unroll
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         mma(f0);
         __builtin_amdgcn_sched_barrier(0);
-        if (has1) {
+        if (!LAST) {
             // outstanding, oldest first: A(kt+1) x4, W(kt+1) x NBP
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
             if (has2 && QV_SWAP) swapA(cur ^ 1, kt + 2);
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         mma(f1);
         __builtin_amdgcn_sched_barrier(0);
-        if (has1) {
+        if (!LAST) {
             // outstanding: W(kt+1) x NBP [, A(kt+2) x4]
             if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -287,7 +305,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         // stage kt + 1 written (own ds_writes retired) and stage kt read by every wave
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-    }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) ktile(kt, std::false_type{});
+    ktile(nk - 1, std::true_type{});
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bia[j][q] = ldf4(rs_bias, nb + j * 32 + 8 * q + 4 * hi);
+            if (W8) scl[j][q] = ldf4(rs_scl, nb + j * 32 + 8 * q + 4 * hi);
+        }
     QW_TRACE(nk);
     QW_PHASE(2);
 #if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
@@ -300,25 +327,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     }
 #endif
     // ------------------------------------------------------------------ epilogue ----------
-    // accumulator (i, j), register r: tile row = wm*128 + i*32 + (lane & 31),
-    //   tile column = wn*64 + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
-    const int l31 = lane & 31, hi = lane >> 5;
     unsigned char *sW = smem + wave * 16384;   // this wave's private staging slice
-    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, g.N * 4, 0x00020000);
-    auto ldf4 = [&](const __amdgpu_buffer_rsrc_t &rs, int elem) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 0));
-    };
-    const int nb = n0 + wn * 64;          // first tile column of this wave
-    const int mb = m0 + wm * 128;         // first row of this wave
-    f32x4 bia[2][4], scl[2][4];   // scl: per-channel weight scales (W8A16 only)
-    const __amdgpu_buffer_rsrc_t rs_scl = __builtin_amdgcn_make_buffer_rsrc((void *)(W8 ? g.w8scale : g.bias), 0, g.N * 4, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bia[j][q] = ldf4(rs_bias, nb + j * 32 + 8 * q + 4 * hi);
-            if (W8) scl[j][q] = ldf4(rs_scl, nb + j * 32 + 8 * q + 4 * hi);
-        }
 
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
         // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  64 frames at a time go through the wave's slice as
@@ -364,6 +373,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         const int rr = lane >> 4, cc = (lane & 15) * 4;   // read-back: 4 rows x 256 B per instruction
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // (requesting row group i + 1's old values before group i is stored -- two register sets -- was measured:
+            // no gain, the other waves' epilogues already cover the read latency)
             f32x4 old[8];
             if (EPI == EPI_RESID) {
 #pragma unroll
