@@ -515,14 +515,18 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                     f32x4 sa = {1.f, 1.f, 1.f, 1.f}, sg = sa;
                     if (W8) { sa = ldf4(rs_scl, nb + nl); sg = ldf4(rs_scl, nb + 32 + nl); }
                     half4 o;
+                    f32x4 av, gv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float av = acc[i][0][q * 4 + e], gv = acc[i][NF - 1][q * 4 + e];
-                        if (W8) { av *= sa[e]; gv *= sg[e]; }
-                        av += ba[e];
-                        gv += bg[e];
-                        o[e] = (half_t)(av * sigmoidf_(gv));
+                        av[e] = acc[i][0][q * 4 + e];
+                        gv[e] = acc[i][NF - 1][q * 4 + e];
+                        if (W8) { av[e] *= sa[e]; gv[e] *= sg[e]; }
+                        av[e] += ba[e];
+                        gv[e] += bg[e];
                     }
+                    const f32x4 sgm = sigmoid4(gv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(av[e] * sgm[e]);
                     *(half4 *)(sO + rl * LDT + wn * (WN / 2) + nl) = o;
                 }
                 continue;
@@ -534,10 +538,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                     const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
                     const f32x4 bb = bia[j][q];
                     half4 o;
+                    f32x4 xv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = acc[i][j][q * 4 + e] + bb[e];
+                    if (EPI == EPI_F16_SWISH) xv = swish4(xv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][q * 4 + e] + bb[e];
-                        if (EPI == EPI_F16_SWISH) x = x * sigmoidf_(x);
+                        float x = xv[e];
                         if (EPI == EPI_F16_RELU) x = x > 0.f ? x : 0.f;
                         o[e] = (half_t)x;
                     }

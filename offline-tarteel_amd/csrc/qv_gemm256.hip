@@ -424,14 +424,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 half4 o;
+                f32x4 av, gv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float av = acc[i][0][q * 4 + e], gv = acc[i][1][q * 4 + e];
-                    if (W8) { av *= scl[0][q][e]; gv *= scl[1][q][e]; }
-                    av += bia[0][q][e];
-                    gv += bia[1][q][e];
-                    o[e] = (half_t)(av * sigm(gv));
+                    av[e] = acc[i][0][q * 4 + e];
+                    gv[e] = acc[i][1][q * 4 + e];
+                    if (W8) { av[e] *= scl[0][q][e]; gv[e] *= scl[1][q][e]; }
+                    av[e] += bia[0][q][e];
+                    gv[e] += bia[1][q][e];
                 }
+                const f32x4 sg = sigmoid4(gv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)(av[e] * sg[e]);
                 *(half4 *)(sO + l31 * LDT + 8 * q + 4 * hi) = o;
             }
 #pragma unroll
@@ -456,10 +460,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     half4 o;
+                    f32x4 xv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = acc[i][j][q * 4 + e] + bia[j][q][e];
+                    if (EPI == EPI_F16_SWISH) xv = swish4(xv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][q * 4 + e] + bia[j][q][e];
-                        if (EPI == EPI_F16_SWISH) x = x * sigm(x);
+                        float x = xv[e];
                         if (EPI == EPI_F16_RELU) x = x > 0.f ? x : 0.f;
                         o[e] = (half_t)x;
                     }

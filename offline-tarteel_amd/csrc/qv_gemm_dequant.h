@@ -1,4 +1,5 @@
-// qv_gemm_dequant.h -- int4 / int8 weight codes -> f16 MFMA operands, shared by qv_gemm.hip and qv_gemm256.hip.
+// qv_gemm_dequant.h -- shared by qv_gemm.hip and qv_gemm256.hip: int4 / int8 weight codes -> f16 MFMA operands, and the
+// packed-f32 Swish / sigmoid of the epilogues.
 #pragma once
 
 #include "qv_kernels.h"
@@ -36,3 +37,37 @@ static __device__ __forceinline__ half8 dequant8_i8(uint2 qv) {
     return r;
 }
 
+// x * sigmoid(x) for four values, the scalings and the + 1 as packed f32 operations (v_pk_mul_f32 / v_pk_add_f32
+// handle two values per instruction; the transcendentals stay scalar).  Same values as x * sigm(x): __expf(-x) is
+// exp2(-x * log2 e), and (-x) * c == -(x * c) exactly.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x4 sigmoid4(f32x4 x) {
+    const f32x2 L2E = {0x1.715476p+0f, 0x1.715476p+0f}, ONE = {1.0f, 1.0f};
+    f32x4 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 xv = {x[2 * h], x[2 * h + 1]};
+        const f32x2 y = xv * L2E;
+        const f32x2 e = {__builtin_amdgcn_exp2f(-y[0]), __builtin_amdgcn_exp2f(-y[1])};
+        const f32x2 d = e + ONE;
+        r[2 * h] = __builtin_amdgcn_rcpf(d[0]);
+        r[2 * h + 1] = __builtin_amdgcn_rcpf(d[1]);
+    }
+    return r;
+}
+static __device__ __forceinline__ f32x4 swish4(f32x4 x) {
+    const f32x2 L2E = {0x1.715476p+0f, 0x1.715476p+0f}, ONE = {1.0f, 1.0f};
+    f32x4 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 xv = {x[2 * h], x[2 * h + 1]};
+        const f32x2 y = xv * L2E;
+        const f32x2 e = {__builtin_amdgcn_exp2f(-y[0]), __builtin_amdgcn_exp2f(-y[1])};
+        const f32x2 d = e + ONE;
+        const f32x2 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2 o = xv * s;
+        r[2 * h] = o[0];
+        r[2 * h + 1] = o[1];
+    }
+    return r;
+}
