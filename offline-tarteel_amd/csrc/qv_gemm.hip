@@ -1,8 +1,10 @@
 // qv_gemm.hip -- fused-epilogue f16 GEMM on v_mfma_f32_32x32x16_f16 (see qv_kernels.h).
 //
-// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias).  128 x BN x 64 tiles, 512 threads: 4 consumer waves
-// (2 x 2, fragment reads + MFMA + epilogue) and 4 loader waves (direct global->LDS loads of the
-// stage 1..3 K-steps ahead), 2..4 LDS stages.  The epilogue goes back through LDS so that every
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias).  128 x BN x 64 tiles (BN = 128 or 64), 512 threads: 4 consumer waves
+// (2 x 2, fragment reads + MFMA + epilogue) and 4 loader waves (register-staged MUBUF loads into a 2-stage LDS
+// ring by default; direct global->LDS loads with 2..4 stages under QVERSE_GEMM_LD=0).  The large shapes run on the
+// 256 x 256-tile kernel of qv_gemm256.hip instead (launch_gemm's plan, bottom of this file); both kernels produce
+// bit-identical results.  The epilogue goes back through LDS so that every
 // global store is a full 16-byte lane-contiguous row segment (a wave writes 4 whole tile rows per
 // instruction); storing straight from the MFMA accumulator layout (one row per lane) cost more
 // time than the whole K loop.
