@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     }
 }
 
-// x <- LN_out(x) (f32, in place: the next layer's residual stream), y <- LN_next(x) (f16)
+// x <- LN_out(x) (f32, in place: the next layer's residual stream), y <- LN_next(x) (f16); with g2 == nullptr and y set
+// (last layer) y is the f16 copy of LN_out(x) itself: the CTC head's operand, no separate conversion pass
 __global__ __launch_bounds__(256) void k_layernorm2(float *__restrict__ x, const float *__restrict__ g1, const float *__restrict__ b1,
                                                     const float *__restrict__ g2, const float *__restrict__ b2,
                                                     half_t *__restrict__ y, int M) {
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(256) void k_layernorm2(float *__restrict__ x, const
     }
     const LnParam p1 = ln_param(g1, b1, lane);
     LnParam p2 = p1;
-    if (y) p2 = ln_param(g2, b2, lane);
+    const bool second = y && g2;
+    if (second) p2 = ln_param(g2, b2, lane);
 #pragma unroll
     for (int r = 0; r < LN_ROWS; ++r) {
         if (row0 + r >= M) break;
@@ -437,7 +439,11 @@ __global__ __launch_bounds__(256) void k_layernorm2(float *__restrict__ x, const
         *(f32x4 *)p = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
         if (y) {
-            ln_row_p(o, p2, o2);
+            if (second) ln_row_p(o, p2, o2);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o2[i] = o[i];
+            }
             half8 h;
 #pragma unroll
             for (int i = 0; i < 8; ++i) h[i] = (half_t)o2[i];
