@@ -84,7 +84,7 @@ typedef struct {
     double span_penalty;        /* CTC_DIRECT_SPAN_PENALTY     0.5 */
     int32_t skip_unused_passes; /* 1: skip search()/pass-3 when the gate passes (their output is
                                    unused by the mixed plugin); 0: literal */
-    int32_t n_contexts;         /* 1..4 batches in flight (default 1).  With > 1,
+    int32_t n_contexts;         /* 1..8 batches in flight (default 1).  With > 1,
                                    qv_predict_batch_async() rotates over that many execution
                                    contexts (own activations, workspace and internal stream), so
                                    the latency-bound decode/retrieval/CTC kernels of one batch run

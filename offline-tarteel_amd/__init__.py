@@ -4,7 +4,14 @@ Host-side mirror of the reference's c2c-direct-mixed plugin surface over a C-ABI
 library (csrc/ -> libqverse.so).  See DESIGN.md.
 """
 
+import os
 from pathlib import Path
+
+# Engines with several batches in flight use one HIP stream per batch; the runtime maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise (measured: four
+# context streams 14.8 k utt/s on 4 queues, 17.3 k on 8).  Only effective if set before HIP initialises,
+# i.e. import this package before the first torch.cuda call; an existing setting is left alone.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PKG_DIR = Path(__file__).resolve().parent
 DATA_DIR = PKG_DIR / "data"

@@ -439,7 +439,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
         qv_set_error(eng, "max_samples above 976,000 (61 s) is not supported: the CTC rerank handles at most 768 encoder frames");
         return fail(QV_ERR_CAPACITY);
     }
-    if (cfg->n_contexts > QV_MAX_CTX) { qv_set_error(eng, "n_contexts must be in [1,4]"); return fail(QV_ERR_ARG); }
+    if (cfg->n_contexts > QV_MAX_CTX) { qv_set_error(eng, "n_contexts must be in [1,8]"); return fail(QV_ERR_ARG); }
     eng->knobs = {cfg->top_text, cfg->top_span_refs, cfg->max_span, cfg->threshold, cfg->text_weight,
                   cfg->span_penalty, cfg->skip_unused_passes};
     int ndev = 0;

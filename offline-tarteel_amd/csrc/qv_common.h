@@ -198,7 +198,7 @@ void qv_stage_mark(qv_engine *eng, int i, hipStream_t s);
 // One execution context = everything a batch in flight owns (activations live in QvModel).
 // With n_ctx > 1, qv_predict_batch_async() round-robins the contexts, each on its own internal
 // stream, so the latency-bound post-logits kernels of one batch run under the forward of the next.
-#define QV_MAX_CTX 4
+#define QV_MAX_CTX 8
 // Pinned staging buffers (frame counts here, the model's length table in QvActs) are written by the host
 // and then read by an asynchronous H2D copy: each has QV_STAGE_SLOTS slots used in turn, and a slot is
 // reused only after the event recorded behind its copy has completed -- back-to-back asynchronous calls

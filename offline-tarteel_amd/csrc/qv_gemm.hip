@@ -764,7 +764,8 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
         static const int env_min = [] { const char *e = getenv("QVERSE_GEMM_MINTILES"); return e ? atoi(e) : 0; }();
         static const int env_min_longk = [] { const char *e = getenv("QVERSE_GEMM_MINTILES_LONGK"); return e ? atoi(e) : 0; }();
         const bool busy = g.in_flight >= 3;
-        const int min_tiles = env_min > 0 ? env_min : busy ? 128 : 160;
+        // (four or more batches in flight: wide tiles wherever the shape allows, +1.4 % over the 128-tile threshold)
+        const int min_tiles = env_min > 0 ? env_min : g.in_flight >= 4 ? 1 : busy ? 128 : 160;
         const int min_tiles_longk = env_min_longk > 0 ? env_min_longk : busy ? 1 : 160;
         p.wide = t256 >= 2 || tiles256 >= (g.K >= 2048 ? min_tiles_longk : min_tiles);
     }

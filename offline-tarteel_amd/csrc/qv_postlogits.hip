@@ -1587,6 +1587,7 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
     }
     static const int skip = [] { const char *e = getenv("QVERSE_SKIP"); return e ? atoi(e) : 0; }();   // dev-only, see qv_model.hip
     auto launch_chain = [&]() -> int {
+        if (skip & 128) return QV_OK;   // (timing experiments only: no post-logits chain at all)
         hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);
         hipLaunchKernelGGL(k_argmax, dim3(t_max, batch), dim3(64), 0, stream, lp, t_max, wk.utt, wk.frame_ids, wk.t_cap);
         hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);

@@ -60,4 +60,4 @@ def test_bench_under_torchrun_with_collective_path():
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = _line(p.stdout)
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["batches_in_flight"] == 3
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["batches_in_flight"] == 4

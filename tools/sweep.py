@@ -2,7 +2,7 @@
 """Clip-length sweep of the hot path on one GPU (5-30 s clips plus the mixed-length
 batch), same engine and timing discipline as bench.py.  Writes one JSON document.
 
-    python tools/sweep.py [--out profiles/rNN_sweep.json] [--steps 20] [--contexts 3]
+    python tools/sweep.py [--out profiles/rNN_sweep.json] [--steps 20] [--contexts 4]
 """
 from __future__ import annotations
 
@@ -23,14 +23,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--contexts", type=int, default=3)
+    ap.add_argument("--contexts", type=int, default=4)
     ap.add_argument("--precision", choices=("fp16", "mixed"), default="fp16")
     args = ap.parse_args()
 
+    import offline_tarteel_amd  # noqa: F401  (first: sets GPU_MAX_HW_QUEUES before HIP initialises)
     import numpy as np
     import torch
-
-    import offline_tarteel_amd  # noqa: F401
     from offline_tarteel_amd.engine import Engine
     from synth import synth_audio
 
