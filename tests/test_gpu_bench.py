@@ -34,6 +34,7 @@ def test_bench_single_process_contract():
     # HBM traffic is quoted from a committed counter summary only for the shape it was taken at (M = 8064)
     assert d["roofline"]["traffic"] is None and "no committed counter summary" in d["roofline"]["traffic_source"]
     assert d["dtype"] == "f16" and "not a BASELINE.json configuration" in d["config"]["workload"]
+    assert d["roofline"]["kernel"].startswith("k_gemm") and "batches in flight" in d["roofline"]["tile_policy"]
     # the verse-shaped replay legs: every transcript passes the text gate / every one fails it
     pl = d["post_logits"]
     assert pl["gate_pass"]["use_ctc_fraction"] == 0.0 and pl["gate_fail"]["use_ctc_fraction"] == 1.0
