@@ -242,9 +242,11 @@ def main():
     lengths = [n] * B
     # TTA: the 1.1x-slowed copies are 10 % longer than the clips
     cap = int(n * 1.1) + 1600 if tta else n
+    # TTA: a step is anchor pass -> host gate -> two perturbed batches; never more than two batches in flight
+    n_ctx = min(args.contexts, 2) if tta else args.contexts
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=cap,
                  precision=1 if args.precision == "mixed" else 0, skip_unused_passes=not args.literal,
-                 contexts=1 if tta else args.contexts)
+                 contexts=n_ctx)
     gathered = torch.empty((world * B, 4), dtype=torch.int32, device=f"cuda:{local_rank}") if use_dist else None
     pending = []   # contexts whose packed rows have not been all-gathered yet
     tta_stats = {"gated": 0, "clips": 0}
@@ -358,9 +360,9 @@ def main():
             "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "mfma_util_pmc": mfma_util, "mfma_util_source": mfma_source,
             "flops_per_launch": rep["flops"], "avg_launch_us": round(rep["avg_us"], 2), "launches": rep["launches"],
-            "tile_policy": (f"{1 if tta else args.contexts} batches in flight: 256 x 256 tiles (one block per CU) for every GEMM with N % 256 == 0"
-                            + ("" if (1 if tta else args.contexts) >= 4 else
-                               " and >= 128 such tiles, or K >= 2048" if (1 if tta else args.contexts) >= 3 else " and >= 160 such tiles")
+            "tile_policy": (f"{n_ctx} batches in flight: 256 x 256 tiles (one block per CU) for every GEMM with N % 256 == 0"
+                            + ("" if n_ctx >= 4 else
+                               " and >= 128 such tiles, or K >= 2048" if n_ctx >= 3 else " and >= 160 such tiles")
                             + " (with several batches in flight the small-grid GEMMs run on 64-128 CUs: fewer CU-microseconds per GEMM, the "
                               "other batches' kernels take the idle CUs; profiles/r02_f_tile_policy_sweep.txt), 128-wide tiles otherwise; "
                               "other_gemms are stand-alone replays under that policy"),
@@ -419,7 +421,7 @@ def main():
                        "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
                        "skip_unused_passes": not args.literal, "weights": args.precision,
-                       "batches_in_flight": 1 if tta else args.contexts},
+                       "batches_in_flight": n_ctx},
             "roofline": roof, "cpu_baseline": cpu, "post_logits": post,
         }
         if tta:

@@ -178,6 +178,14 @@ def tta_device_batch(eng, audio, lengths, want_text: bool = True) -> list[dict]:
     hard = [i for i, a in enumerate(anchors) if a["score"] < CONFIDENCE_SKIP_THRESHOLD]
     out = list(anchors)
     per_call = max(1, eng.max_batch // 2)
+    tickets = []   # batches in flight: (context, clip indices, rows kept alive, frame count)
+
+    def join(ticket):
+        ctx, idx, rows, t_max = ticket
+        res = [_to_dict(r, False) for r in eng.fetch_results(ctx, rows.shape[0], t_max, want_text=want_text)]
+        for k, i in enumerate(idx):
+            out[i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
+
     for s0 in range(0, len(hard), per_call):
         idx = hard[s0: s0 + per_call]
         variants = []
@@ -188,9 +196,17 @@ def tta_device_batch(eng, audio, lengths, want_text: bool = True) -> list[dict]:
         rows = torch.zeros((len(variants), max(lens)), dtype=torch.float32, device=audio.device)
         for r, v in enumerate(variants):
             rows[r, : v.numel()] = v
+        if eng.contexts > 1:
+            # the perturbed batches do not depend on one another: keep up to `contexts` of them in flight
+            if len(tickets) == eng.contexts:
+                join(tickets.pop(0))
+            tickets.append((eng.predict_batch_async(rows, lens), idx, rows, eng.frames_for(max(lens))))
+            continue
         res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens, want_text=want_text)]
         for k, i in enumerate(idx):
             out[i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
+    while tickets:
+        join(tickets.pop(0))
     return out
 
 

@@ -84,3 +84,26 @@ def test_configs4_rank_slice_64x30s_vs_oracle_on_hip_logprobs(oracle):
             assert key(alone) == key(got) and alone["score"] == got["score"], b
     finally:
         eng.close()
+
+
+def test_tta_with_batches_in_flight_equals_one_at_a_time():
+    """tta_device_batch keeps the perturbed batches in flight over the engine's contexts; the combined rows must
+    be the ones the one-batch-at-a-time engine returns (seeded random weights gate every clip, so the 0.9x / 1.1x
+    passes run; six clips with max_batch 4 make three perturbed batches -- more than the two contexts)."""
+    import offline_tarteel_amd  # noqa: F401
+    from offline_tarteel_amd.engine import Engine
+    from offline_tarteel_amd.plugin import tta_device_batch
+
+    n = 48000
+    audio = torch.from_numpy(synth_audio(4, n, seed=5)).cuda()
+    lens = [n, n - 3200, n - 800, n - 6400]
+    for b in range(4):
+        audio[b, lens[b]:] = 0
+    got = {}
+    for ctxs in (1, 2):
+        eng = Engine(device=0, with_model=True, seed=20260630, max_batch=4, max_samples=int(n * 1.1) + 1600, contexts=ctxs)
+        got[ctxs] = tta_device_batch(eng, audio, lens, want_text=True)
+        torch.cuda.synchronize()
+        del eng
+    assert all("tta" in r for r in got[1]), "the random-weight anchors are expected to fall below the 0.5 gate"
+    assert got[1] == got[2]
