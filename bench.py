@@ -242,8 +242,8 @@ def main():
     lengths = [n] * B
     # TTA: the 1.1x-slowed copies are 10 % longer than the clips
     cap = int(n * 1.1) + 1600 if tta else n
-    # TTA: a step is anchor pass -> host gate -> two perturbed batches; never more than two batches in flight
-    n_ctx = min(args.contexts, 2) if tta else args.contexts
+    # TTA: anchor pass of the next step + the two perturbed batches of this one: three batches in flight at most
+    n_ctx = min(args.contexts, 3) if tta else args.contexts
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=cap,
                  precision=1 if args.precision == "mixed" else 0, skip_unused_passes=not args.literal,
                  contexts=n_ctx)
@@ -264,23 +264,40 @@ def main():
             if len(pending) >= args.contexts:
                 gather(pending.pop(0))
 
-    def step_tta():
-        # c2c-direct-mixed-tta/run.py:117-149 per batch: anchor pass, 0.5 gate (host decision on the
-        # fetched scores, as in the reference), 0.9x / 1.1x copies of the gated clips resampled on the GPU
-        # and run as further batches, majority / best-score pick; the combined rows are what is gathered
-        from offline_tarteel_amd import dist as qdist
-        from offline_tarteel_amd.plugin import tta_device_batch
+    tta_prev = []   # the previous step's TTA state while its perturbed batches are still in flight
 
-        res = tta_device_batch(eng, audio, lengths, want_text=False)
+    def tta_done(st):
+        from offline_tarteel_amd import dist as qdist
+        from offline_tarteel_amd.plugin import tta_finish
+
+        res = tta_finish(eng, st)
         tta_stats["clips"] += B
         tta_stats["gated"] += sum(1 for r in res if "tta" in r)
         if use_dist:
             rows = torch.from_numpy(qdist.pack_results(res)).cuda(local_rank)
             dist.all_gather_into_tensor(gathered, rows)
 
+    def step_tta():
+        # c2c-direct-mixed-tta/run.py:117-149 per batch: anchor pass, 0.5 gate (host decision on the
+        # fetched scores, as in the reference), 0.9x / 1.1x copies of the gated clips resampled on the GPU
+        # and run as further batches, majority / best-score pick; the combined rows are what is gathered.
+        # With >= 3 contexts the steps are software-pipelined: this step's anchor pass is launched before the
+        # previous step's perturbed batches are joined, so the two run side by side.
+        from offline_tarteel_amd.plugin import tta_start
+
+        if n_ctx >= 3:
+            ctx = eng.predict_batch_async(audio, lengths)
+            if tta_prev:
+                tta_done(tta_prev.pop())
+            tta_prev.append(tta_start(eng, audio, lengths, want_text=False, anchor_ctx=ctx))
+        else:
+            tta_done(tta_start(eng, audio, lengths, want_text=False))
+
     step = step_tta if tta else step_clips
 
     def sync_all():
+        while tta_prev:
+            tta_done(tta_prev.pop())
         while pending:
             gather(pending.pop(0))
         torch.cuda.synchronize()

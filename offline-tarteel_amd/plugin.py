@@ -167,25 +167,20 @@ def _tta_combine(p09: dict, anchor: dict, p11: dict) -> dict:
     return best
 
 
-def tta_device_batch(eng, audio, lengths, want_text: bool = True) -> list[dict]:
-    """c2c-direct-mixed-tta/run.py:117-149 for one batch already in HBM (float32 cuda [B, N], zero
-    padded): anchor pass over every clip, gate 0.5 on the UNROUNDED score, then the 0.9x / 1.1x copies of
-    the gated clips -- made on the GPU (qv_upfirdn, bit-identical to the reference's
-    scipy.signal.resample_poly call) -- as further engine batches (the reference runs them as two
-    threads on one session), and the majority / best-score rule."""
+def tta_start(eng, audio, lengths, want_text: bool = True, anchor_ctx: int | None = None) -> dict:
+    """First half of tta_device_batch: the anchor results (run here, or fetched from context `anchor_ctx` when the
+    caller already launched the anchor pass with predict_batch_async), the 0.5 gate, and the 0.9x / 1.1x copies
+    of the gated clips launched as further batches.  With one context those batches are finished here; with more
+    they stay in flight until tta_finish() -- a serving loop can launch the next batch's anchor pass in between."""
     torch = eng.torch
-    anchors = [_to_dict(r, False) for r in eng.predict_batch(audio, lengths, want_text=want_text)]
+    if anchor_ctx is None:
+        raw = eng.predict_batch(audio, lengths, want_text=want_text)
+    else:
+        raw = eng.fetch_results(anchor_ctx, len(lengths), eng.frames_for(max(lengths)), want_text=want_text)
+    anchors = [_to_dict(r, False) for r in raw]
     hard = [i for i, a in enumerate(anchors) if a["score"] < CONFIDENCE_SKIP_THRESHOLD]
-    out = list(anchors)
+    st = {"anchors": anchors, "out": list(anchors), "tickets": [], "want_text": want_text}
     per_call = max(1, eng.max_batch // 2)
-    tickets = []   # batches in flight: (context, clip indices, rows kept alive, frame count)
-
-    def join(ticket):
-        ctx, idx, rows, t_max = ticket
-        res = [_to_dict(r, False) for r in eng.fetch_results(ctx, rows.shape[0], t_max, want_text=want_text)]
-        for k, i in enumerate(idx):
-            out[i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
-
     for s0 in range(0, len(hard), per_call):
         idx = hard[s0: s0 + per_call]
         variants = []
@@ -197,17 +192,39 @@ def tta_device_batch(eng, audio, lengths, want_text: bool = True) -> list[dict]:
         for r, v in enumerate(variants):
             rows[r, : v.numel()] = v
         if eng.contexts > 1:
-            # the perturbed batches do not depend on one another: keep up to `contexts` of them in flight
-            if len(tickets) == eng.contexts:
-                join(tickets.pop(0))
-            tickets.append((eng.predict_batch_async(rows, lens), idx, rows, eng.frames_for(max(lens))))
+            # the perturbed batches do not depend on one another: keep them in flight (one context stays free for
+            # the caller's next anchor pass when there are more than two)
+            if len(st["tickets"]) >= max(1, eng.contexts - (1 if eng.contexts > 2 else 0)):
+                _tta_join(eng, st, st["tickets"].pop(0))
+            st["tickets"].append((eng.predict_batch_async(rows, lens), idx, rows, eng.frames_for(max(lens))))
             continue
         res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens, want_text=want_text)]
         for k, i in enumerate(idx):
-            out[i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
-    while tickets:
-        join(tickets.pop(0))
-    return out
+            st["out"][i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
+    return st
+
+
+def _tta_join(eng, st: dict, ticket):
+    ctx, idx, rows, t_max = ticket   # (rows: the batch's input, kept alive until it has run)
+    res = [_to_dict(r, False) for r in eng.fetch_results(ctx, rows.shape[0], t_max, want_text=st["want_text"])]
+    for k, i in enumerate(idx):
+        st["out"][i] = _tta_combine(res[2 * k], st["anchors"][i], res[2 * k + 1])
+
+
+def tta_finish(eng, st: dict) -> list[dict]:
+    """Second half: join the perturbed batches still in flight and apply the majority / best-score rule."""
+    while st["tickets"]:
+        _tta_join(eng, st, st["tickets"].pop(0))
+    return st["out"]
+
+
+def tta_device_batch(eng, audio, lengths, want_text: bool = True) -> list[dict]:
+    """c2c-direct-mixed-tta/run.py:117-149 for one batch already in HBM (float32 cuda [B, N], zero
+    padded): anchor pass over every clip, gate 0.5 on the UNROUNDED score, then the 0.9x / 1.1x copies of
+    the gated clips -- made on the GPU (qv_upfirdn, bit-identical to the reference's
+    scipy.signal.resample_poly call) -- as further engine batches (the reference runs them as two
+    threads on one session), and the majority / best-score rule."""
+    return tta_finish(eng, tta_start(eng, audio, lengths, want_text))
 
 
 def predict_tta_arrays(arrays) -> list[dict]:

@@ -50,7 +50,7 @@ def test_bench_tta30_workload_small():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _line(p.stdout)
     assert "TTA" in d["metric"] and d["config"]["tta_gated_fraction"] == 1.0 and d["value"] > 0
-    assert "configs[4]" in d["config"]["workload"] and d["config"]["batches_in_flight"] == 2
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["batches_in_flight"] == 3
 
 
 def test_bench_under_torchrun_with_collective_path():
