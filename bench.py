@@ -42,6 +42,7 @@ import time
 
 # one hardware queue per stream (4 context streams + the caller's + copies); read by the HIP runtime when it initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (launch latency)
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent

@@ -12,6 +12,9 @@ from pathlib import Path
 # context streams 14.8 k utt/s on 4 queues, 17.3 k on 8).  Only effective if set before HIP initialises,
 # i.e. import this package before the first torch.cuda call; an existing setting is left alone.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in device memory instead of host memory the command processor reads over PCIe: the path is ~250 short
+# launches per batch (one batch at a time 12.05 k -> 12.7 k utt/s, four in flight +0.9 %).  Same rule: before HIP initialises.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 PKG_DIR = Path(__file__).resolve().parent
 DATA_DIR = PKG_DIR / "data"
