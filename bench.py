@@ -260,6 +260,9 @@ def main():
 
     def gather(ctx):
         # the path's only exchange: 16 B per utterance, latency-bound
+        # host-side join first (the host would block on this context a step later anyway, when it reuses it): nothing
+        # queued on the device then waits for an older batch, whichever hardware queue the streams share
+        eng.wait(ctx)
         with torch.cuda.stream(gstream):
             dist.all_gather_into_tensor(gathered, eng.packed_results(B, ctx))
 

@@ -161,6 +161,10 @@ int qv_upfirdn(qv_engine *e, const float *x_dev, int64_t n_in, const float *taps
  * per context: */
 int32_t qv_context_count(const qv_engine *e);
 int32_t qv_last_context(const qv_engine *e);     /* context used by the most recent async call */
+/* Host-side join: blocks the calling thread until context `ctx`'s last batch has finished (no-op for an idle
+ * context).  A device-side join (qv_packed_results_ctx on a stream) parks a wait on an OLDER batch in that stream's
+ * hardware queue; when the runtime maps another stream onto the same queue, that stream's work is stuck behind it. */
+int qv_wait_ctx(qv_engine *e, int32_t ctx);
 /* makes `stream` wait for that context's batch, then returns its packed i32[B,4] rows */
 const int32_t *qv_packed_results_ctx(qv_engine *e, int32_t ctx, void *stream);
 /* host copy of that context's results (SYNCHRONOUS) */

@@ -637,6 +637,17 @@ extern "C" const int32_t *qv_packed_results_dev(qv_engine *eng) { return eng ? e
 extern "C" int32_t qv_context_count(const qv_engine *eng) { return eng ? eng->n_ctx : 0; }
 extern "C" int32_t qv_last_context(const qv_engine *eng) { return eng ? eng->cur_ctx : -1; }
 
+extern "C" int qv_wait_ctx(qv_engine *eng, int32_t k) {
+    if (!eng || k < 0 || k >= eng->n_ctx) return QV_ERR_ARG;
+    QvCtx &c = eng->ctx[k];
+    if (eng->n_ctx > 1) {
+        if (c.busy) QV_HIP(hipEventSynchronize(c.done));
+    } else {
+        QV_HIP(hipDeviceSynchronize());   // single-context engines run on the caller's stream, which we were not given
+    }
+    return QV_OK;
+}
+
 extern "C" const int32_t *qv_packed_results_ctx(qv_engine *eng, int32_t k, void *stream) {
     if (!eng || k < 0 || k >= eng->n_ctx) return nullptr;
     QvCtx &c = eng->ctx[k];

@@ -108,6 +108,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_upfirdn.argtypes = [vp, vp, i64, vp, i32, i32, i32, i64, i64, vp, vp]
     lib.qv_context_count.argtypes = [vp]
     lib.qv_last_context.argtypes = [vp]
+    lib.qv_wait_ctx.argtypes = [vp, i32]
     lib.qv_packed_results_ctx.argtypes = [vp, i32, vp]
     lib.qv_packed_results_ctx.restype = vp
     lib.qv_fetch_results_ctx.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -306,6 +307,10 @@ class Engine:
                                            greedy.ctypes.data_as(C.c_void_p) if greedy is not None else None)
         self._check(rc, "qv_fetch_results_ctx")
         return self._results(res, greedy)
+
+    def wait(self, ctx: int):
+        """host-side join of context `ctx` (the value predict_batch_async returned): returns when its batch is done."""
+        self._check(self.lib.qv_wait_ctx(self.h, int(ctx)), "qv_wait_ctx")
 
     def packed_results(self, batch: int, ctx: int | None = None):
         """int32 cuda tensor [batch, 4] = (surah, ayah, ayah_end, float-bits(score)) of the last

@@ -272,6 +272,11 @@ def test_batches_in_flight_equal_one_at_a_time(setup):
             # packed rows joined on the caller's stream
             pk = eng.packed_results(3, t4).cpu()
             assert pk[:, 0].tolist() == [r["surah"] for r in want[4]]
+            # host-side join (qv_wait_ctx), then the rows: what bench.py does before each all-gather
+            t5 = eng.predict_batch_async(*batches[4])
+            eng.wait(t5)
+            assert eng.packed_results(3, t5).cpu()[:, 1].tolist() == [r["ayah"] for r in want[4]]
+            eng.wait(t5)   # idle context: no-op
         # the synchronous entry point still works with contexts > 1
         assert eng.predict_batch(audio, LENS, want_text=False) == want[0]
         # the streaming row's entry points next to batches in flight: the tracker has its own workspace
