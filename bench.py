@@ -69,8 +69,11 @@ def parse():
     ap.add_argument("--literal", action="store_true", help="run search()/pass-3 even when the gate passes")
     ap.add_argument("--contexts", type=int, default=4,
                     help="batches in flight per GPU (execution contexts of the engine, 1..8)")
-    ap.add_argument("--precision", choices=("fp16", "mixed"), default="fp16",
-                    help="fp16 = BASELINE configs[1] (the headline line); mixed = int4 Linear weights (W4A16)")
+    ap.add_argument("--precision", choices=("fp16", "mixed", "ort"), default="fp16",
+                    help="fp16 = BASELINE configs[1] (the headline line); mixed = int4 Linear + int8 pointwise-conv weights "
+                         "dequantised to f16 operands (W4A16 / W8A16); ort = the arithmetic onnxruntime runs on the reference's "
+                         "file: int4 Linear + DynamicQuantizeLinear / ConvInteger (uint8 activations, int8 weights, i8 MFMA) "
+                         "on every Conv (QV_PREC_ORT_MIXED)")
     a = ap.parse_args()
     if a.batch <= 0:
         a.batch = 256 if (a.gpus >= 8 and a.workload == "clips") else 64
@@ -246,8 +249,11 @@ def main():
     # TTA: anchor pass of the next step + the two perturbed batches of this one: three batches in flight at most
     n_ctx = min(args.contexts, 3) if tta else args.contexts
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=cap,
-                 precision=1 if args.precision == "mixed" else 0, skip_unused_passes=not args.literal,
+                 precision={"fp16": 0, "mixed": 1, "ort": 2}[args.precision], skip_unused_passes=not args.literal,
                  contexts=n_ctx)
+    # the engine runs fewer batches in flight than asked for when the runtime cannot run its streams side by side
+    # (qv_probe_concurrent_streams: GPU_MAX_HW_QUEUES was not in place when HIP initialised)
+    n_ctx = eng.contexts
     gathered = torch.empty((world * B, 4), dtype=torch.int32, device=f"cuda:{local_rank}") if use_dist else None
     pending = []   # contexts whose packed rows have not been all-gathered yet
     tta_stats = {"gated": 0, "clips": 0}
@@ -263,8 +269,18 @@ def main():
         # host-side join first (the host would block on this context a step later anyway, when it reuses it): nothing
         # queued on the device then waits for an older batch, whichever hardware queue the streams share
         eng.wait(ctx)
+        # The rows leave the engine-owned buffer on the CALLER's stream: the batch is finished, so the 1 KB copy waits
+        # for nothing, and the context's next batch is ordered behind everything queued on this stream
+        # (qv_predict_batch_async records its input event here) -- its k_result cannot overwrite the rows before they
+        # have been copied, however far the side stream lags behind a slow peer rank.  Only the collective itself runs
+        # on the side stream, behind an event recorded after the copy.
+        rows = eng.packed_results(B, ctx)
+        copied = torch.cuda.Event()
+        copied.record()
+        rows.record_stream(gstream)
         with torch.cuda.stream(gstream):
-            dist.all_gather_into_tensor(gathered, eng.packed_results(B, ctx))
+            gstream.wait_event(copied)
+            dist.all_gather_into_tensor(gathered, rows)
 
     def step_clips():
         # every step runs the WHOLE hot path on one batch; with contexts > 1 up to that many batches
@@ -272,7 +288,7 @@ def main():
         ctx = eng.predict_batch_async(audio, lengths)
         if use_dist:
             pending.append(ctx)
-            if len(pending) >= args.contexts:
+            if len(pending) >= n_ctx:
                 gather(pending.pop(0))
 
     tta_prev = []   # the previous step's TTA state while its perturbed batches are still in flight
@@ -419,9 +435,13 @@ def main():
                    "sample": f"failed: {type(e).__name__}: {e}"}
 
     if rank == 0:
-        mixed = args.precision == "mixed"
+        mixed = args.precision != "fp16"
         wdesc = ("fp16 weights" if not mixed else
-                 "int4 (block-128) Linear + int8 (per-channel) pointwise-conv weights dequantised in the MFMA operand fetch, f16 activations")
+                 "int4 (block-128) Linear + int8 (per-channel) pointwise-conv weights dequantised in the MFMA operand fetch, f16 activations"
+                 if args.precision == "mixed" else
+                 "the reference's onnxruntime arithmetic: int4 (block-128) Linear weights on f16 activations; every Conv as "
+                 "DynamicQuantizeLinear (per-utterance uint8 activations) -> ConvInteger (per-tensor int8 weights, int32 "
+                 "accumulation: i8 MFMA / exact integer stencils) -> float32 rescale")
         if tta:
             cfg_name = "BASELINE.json configs[4]" + ("" if world == 8 else f" workload on {world} GPU(s)")
             workload = (f"c2c-direct-mixed-tta hot path, batch={B}/GPU synthetic {args.seconds:g} s/16 kHz clips: anchor pass, "
@@ -444,13 +464,14 @@ def main():
             "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if not mixed else "f16 (int4/int8 weights)",
+            "dtype": "f16" if not mixed else "f16 (int4/int8 weights)" if args.precision == "mixed" else "f16 Linear (int4 weights) + u8 x i8 -> i32 Conv",
             "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
                        "skip_unused_passes": not args.literal, "weights": args.precision,
-                       "batches_in_flight": n_ctx},
+                       "batches_in_flight": n_ctx,
+                       "concurrent_streams_probe": int(eng.lib.qv_probe_concurrent_streams())},
             "roofline": roof, "cpu_baseline": cpu, "post_logits": post,
         }
         if tta:

@@ -61,8 +61,16 @@ enum {
 
 typedef struct qv_engine qv_engine;
 
-/* Weight precision of the acoustic model resident in HBM. */
-enum { QV_PREC_FP16 = 0, QV_PREC_MIXED_INT4_INT8 = 1 };
+/* Arithmetic of the acoustic model.
+ *   QV_PREC_FP16             f16 weights and GEMM operands, f32 accumulation / residual stream.
+ *   QV_PREC_MIXED_INT4_INT8  storage formats of the reference's file with f16 arithmetic: block-128 int4 Linear weights and
+ *                            per-channel int8 pointwise-conv weights, dequantised in the MFMA operand fetch (W4A16 / W8A16).
+ *   QV_PREC_ORT_MIXED        the ARITHMETIC onnxruntime runs on the reference's file (experiments/c2c-direct-mixed/run.py:1-9):
+ *                            MatMulNBits int4 on the Linear layers, and on EVERY Conv DynamicQuantizeLinear -> ConvInteger:
+ *                            per-utterance uint8 activations (range from the tensor's own min / max), one symmetric int8
+ *                            scale per weight tensor, int32 accumulation (i8 MFMA for the GEMM-shaped convolutions, exact
+ *                            integer stencils for the depthwise / strided ones), float32 rescale.  csrc/qv_ort.h. */
+enum { QV_PREC_FP16 = 0, QV_PREC_MIXED_INT4_INT8 = 1, QV_PREC_ORT_MIXED = 2 };
 
 typedef struct {
     int32_t struct_size;        /* sizeof(qv_config), for forward compatibility */
@@ -159,7 +167,14 @@ int qv_upfirdn(qv_engine *e, const float *x_dev, int64_t n_in, const float *taps
  * until the call's results have been joined) and runs on the context's internal stream; a call
  * blocks the host only when the context it is about to reuse is still busy.  Results are joined
  * per context: */
-int32_t qv_context_count(const qv_engine *e);
+int32_t qv_context_count(const qv_engine *e);      /* may be lower than qv_config.n_contexts, see below */
+/* How many of eight HIP streams the runtime runs side by side on this device (8, 4, 2 or 1; 0 = probe failed):
+ * eight one-wave spin kernels on eight streams, elapsed time over spin time (~1 ms, cached per process).  The runtime maps
+ * streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable ONCE, when HIP initialises; streams
+ * sharing a queue serialise.  qv_create() calls this when n_contexts >= 4 and falls back to 3 contexts -- the best
+ * measured setting on the default 4 queues -- unless all eight streams ran concurrently, so that a host which touched HIP
+ * before exporting GPU_MAX_HW_QUEUES=8 loses ~2 % instead of ~14 %. */
+int32_t qv_probe_concurrent_streams(void);
 int32_t qv_last_context(const qv_engine *e);     /* context used by the most recent async call */
 /* Host-side join: blocks the calling thread until context `ctx`'s last batch has finished (no-op for an idle
  * context).  A device-side join (qv_packed_results_ctx on a stream) parks a wait on an OLDER batch in that stream's
@@ -235,7 +250,12 @@ int qv_debug_ctc_loss(qv_engine *e, const float *logprobs_dev, int32_t t_frames,
 
 /* Intermediate activations of the acoustic model for the layer-wise parity tests.
  * what: 0 = normalised mel features f32[B, t_mel_max, 80]; 1 = subsampling output
- * f32[B, t_max, 512]; 2 = encoder output after layer `layer` f32[B, t_max, 512]. */
+ * f32[B, t_max, 512]; 2 = encoder output after layer `layer` f32[B, t_max, 512].
+ * QV_PREC_ORT_MIXED only (the tensors in front of / behind each quantiser of the conv path):
+ * 3 = norm_conv output, 4 = GLU output, 5 = depthwise conv + BatchNorm + Swish output of layer `layer`,
+ * each f32[B, t_max, 512]; 6 = conv.2 output f32[B, t2_max, 20, 256], 7 = ReLU(conv.3) (same shape),
+ * 8 = conv.5 output f32[B, t_max, 10, 256], 9 = ReLU(conv.6) f32[B, t_max, 10, 256] (rows past an
+ * utterance's length are unspecified for 6..9). */
 int qv_debug_forward_tap(qv_engine *e, int32_t what, int32_t layer, float *out_dev, void *stream);
 
 /* Measurement hooks for bench.py's roofline line: while enabled, every GEMM launch of the

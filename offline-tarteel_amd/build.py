@@ -35,7 +35,9 @@ def _stale(target: Path, deps) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, dev_hooks: bool = False) -> Path:
+    """dev_hooks: compile the timing experiments (QVERSE_SKIP / QVERSE_DUP: drop or duplicate kernel classes) into
+    the forward schedule -- never in the product build."""
     OBJ.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "qverse.h"]
     jobs = []
@@ -46,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *FLAGS, *(["-DQV_DEV_HOOKS"] if dev_hooks else []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -69,4 +71,5 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    hooks = "--dev-hooks" in sys.argv
+    print(build(force="--force" in sys.argv or hooks, verbose=True, dev_hooks=hooks))

@@ -9,10 +9,48 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <fstream>
 #include <mutex>
 
 static std::string g_create_error;
+
+// ---- how many streams does the runtime actually run side by side? ---------------------------------------------------
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read ONCE when HIP initialises;
+// streams that share a queue serialise.  An engine with four batches in flight needs a queue per context stream plus the
+// caller's (14.8 k utt/s on 4 queues against 17.3 k on 8, profiles/r02_h_contexts_hwq_sweep.txt), and a host that touched
+// HIP before the variable was set silently gets the default.  Instead of trusting the environment the library measures:
+// eight streams each run a one-wave kernel that spins for a fixed wall-clock time; the elapsed time over the spin time is
+// how many of them shared a queue.
+namespace {
+__global__ void k_spin(long long ticks) {   // wall_clock64: 100 MHz
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+}  // namespace
+
+extern "C" int32_t qv_probe_concurrent_streams(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    constexpr int NS = 8;
+    constexpr long long SPIN_TICKS = 40000;   // 400 us
+    hipStream_t st[NS] = {};
+    for (int i = 0; i < NS; ++i)
+        if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) return 0;
+    for (int i = 0; i < NS; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], 1LL);   // warm-up: queue creation, code load
+    for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(st[i]);
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < NS; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], SPIN_TICKS);
+        for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(st[i]);
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    for (int i = 0; i < NS; ++i) (void)hipStreamDestroy(st[i]);
+    const double rounds = best / (SPIN_TICKS / 100.0);   // kernels that ran one after the other on the busiest queue
+    cached = rounds < 1.5 ? 8 : rounds < 3.0 ? 4 : rounds < 6.0 ? 2 : 1;
+    return cached;
+}
 
 void qv_set_error(qv_engine *e, const std::string &msg) {
     if (e) e->last_error = msg;
@@ -449,6 +487,10 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     }
     if (hipSetDevice(cfg->device) != hipSuccess) { qv_set_error(eng, "hipSetDevice failed"); return fail(QV_ERR_HIP); }
     eng->device = cfg->device;
+    // four and more batches in flight only pay with a hardware queue per context stream (and one for the caller); when
+    // the runtime runs fewer streams side by side than that -- GPU_MAX_HW_QUEUES unset or set after HIP initialised --
+    // three contexts is the best measured setting (17.0 k utt/s on 4 or 8 queues; four contexts on 4 queues: 14.8 k)
+    if (eng->n_ctx >= 4 && qv_probe_concurrent_streams() < 8) eng->n_ctx = 3;
     int rc = load_tables(eng, cfg->tables_path);
     if (rc) return fail(rc);
     for (int k = 0; k < eng->n_ctx; ++k) {

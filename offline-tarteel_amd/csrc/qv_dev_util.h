@@ -1,0 +1,52 @@
+// qv_dev_util.h -- small device helpers shared by qv_layers.hip and qv_ort.hip (one definition, so that the two
+// translation units normalise a row / a mel feature with the very same float32 operations).
+#pragma once
+
+#include "qv_kernels.h"
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+static __device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// per-feature mean / reciprocal std of the log-mel features from the f64 sums k_melstats accumulated
+static __device__ __forceinline__ void mel_mean_rstd(const double *acc, int b, int f, int tm, float &mean, float &rstd) {
+    double s1 = acc[((size_t)b * QV_NMEL + f) * 2], s2 = acc[((size_t)b * QV_NMEL + f) * 2 + 1];
+    double mu = s1 / tm, var = (s2 - s1 * mu) / (tm - 1);
+    mean = (float)mu;
+    rstd = 1.f / (sqrtf((float)(var > 0.0 ? var : 0.0)) + 1e-5f);
+}
+
+// LayerNorm parameters of one lane (8 channels), requested before the row statistics so that
+// their latency overlaps the reductions
+struct LnParam { f32x4 g0, g1, b0, b1; };
+static __device__ __forceinline__ LnParam ln_param(const float *__restrict__ gam, const float *__restrict__ bet, int lane) {
+    LnParam p;
+    p.g0 = *(const f32x4 *)(gam + lane * 8); p.g1 = *(const f32x4 *)(gam + lane * 8 + 4);
+    p.b0 = *(const f32x4 *)(bet + lane * 8); p.b1 = *(const f32x4 *)(bet + lane * 8 + 4);
+    return p;
+}
+// one wave, one row of 512 (8 values per lane): two-pass variance in registers
+static __device__ __forceinline__ void ln_row_p(const float v[8], const LnParam &p, float o[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    float mu = wave_sum(s) * (1.f / QV_D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { float d = v[i] - mu; q += d * d; }
+    float rs = rsqrtf(wave_sum(q) * (1.f / QV_D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * p.g0[i] + p.b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * p.g1[i] + p.b1[i]; }
+}

@@ -11,10 +11,12 @@
 
 #include "qv_kernels.h"
 #include "qv_gemm_dequant.h"
+#include "qv_ort.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -63,7 +65,12 @@ constexpr bool epi_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; 
 template <int EPI, int BN, int WQ, int NST, int LD>
 __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     constexpr bool W4 = WQ == 4, W8 = WQ == 8;
+    // A8W8 (QV_PREC_ORT_MIXED): both operands are bytes and K counts byte PAIRS, so loaders, LDS image and fragment
+    // reads are the f16 kernel's unchanged -- a 16-byte fragment chunk is 16 k values for v_mfma_i32_32x32x32_i8
+    // instead of 8 halves -- and only the accumulator type and the epilogue differ
+    constexpr bool I8 = WQ == 88;
     static_assert(!W8 || BN == 128, "W8A16 is built for 128-wide tiles only");
+    static_assert(!I8 || (BN == 128 && LD == 1), "A8W8 is built for 128-wide tiles with register-staged loaders only");
     constexpr int BM = 128, BK = 64;
     constexpr int NT = 512;
     constexpr int WN = BN / 2;   // columns per consumer wave
@@ -88,13 +95,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     }
     const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
 
-    f32x16 acc[2][NF];
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<I8, i32x16, f32x16>::type acc_t;
+    acc_t acc[2][NF];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
     // LDS tile rows are 128 B (64 halves); the 16-B chunk index is XORed with (row >> 1) & 7 --
     // on the global SOURCE address (the direct load writes LDS lane-linearly) and on the fragment
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
         // MUBUF addressing: SGPR descriptor + per-lane 32-bit byte offset (fixed for the tile) + a scalar
         // byte offset that advances with the K-step -- no VALU instruction per load (see the header comment)
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
-        const void *bbase = W4 ? (const void *)g.Wq : W8 ? (const void *)g.W8 : (const void *)g.W;
+        const void *bbase = W4 ? (const void *)g.Wq : W8 ? (const void *)g.W8 : I8 ? (const void *)g.Wi8 : (const void *)g.W;
         const size_t bbytes = W4 ? (size_t)g.N * g.K / 2 : W8 ? (size_t)g.N * g.K : (size_t)g.N * g.ldw * 2;
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, (int)bbytes, 0x00020000);
         unsigned offA[4], offB[NB];
@@ -339,10 +349,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
+                for (int j = 0; j < NF; ++j) {
                     // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per
                     // register quad -> 8/16-byte LDS writes in the epilogue
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
+                    if constexpr (I8)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, b[j]), __builtin_bit_cast(i32x4, f.a[i]),
+                                                                          acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
+                }
         };
         // (sched_barrier: left alone, the scheduler sinks every read group back behind the previous MFMAs
         // to save the 16 registers)
@@ -387,6 +402,150 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
     auto ldf4 = [&](const __amdgpu_buffer_rsrc_t &rs, int elem) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 0));
     };
+
+    if constexpr (I8) {
+        // ---- A8W8 epilogue (qv_ort.h): int32 accumulator -> float32, per-utterance activation scale, bias, activation.
+        //   v = float(acc + (128 - zp_x[u]) * wsum[n]) * (s_x[u] * s_w) + bias[n]
+        // The int32 sum is < 2^24 in magnitude (K <= 512 products of |255| x |127|), so the conversion is exact and v
+        // carries exactly the two roundings the reference's Cast -> Mul -> Add chain has.
+        constexpr bool GLU = EPI == EPI_GLU, OUT16 = EPI == EPI_F16_RELU;
+        constexpr bool RELU = EPI == EPI_F16_RELU || EPI == EPI_F32_RELU;
+        constexpr bool FOLD = EPI == EPI_GLU || EPI == EPI_F32_RELU;   // the output feeds another quantiser: track its range
+        constexpr int BNO = GLU ? BN / 2 : BN;
+        constexpr int LDT = BNO + 4;                                   // floats per staged row
+        float *sO = (float *)smem;
+        uint32_t *sMM = (uint32_t *)(smem + BM * LDT * 4);             // [BM][2] range keys of the tile's rows
+        auto row_owner = [&](int grow, bool &valid) {
+            valid = true;
+            if (g.row_map) return g.row_map[grow] >> 16;
+            const int u = grow / g.rows_per_utt;
+            valid = (grow - u * g.rows_per_utt) / g.f_per_t < g.len[u];
+            return u;
+        };
+        if (FOLD) {
+            for (int k = tid; k < BM * 2; k += NT) sMM[k] = (k & 1) ? 0u : 0xFFFFFFFFu;   // empty range
+            __syncthreads();
+        }
+        if (!loader) {
+            const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void *)g.wsum, 0, g.N * 4, 0x00020000);
+            float srow[2];
+            int zc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int grow = m0 + wm * 64 + i * 32 + l31;
+                grow = grow < g.M ? grow : g.M - 1;
+                bool valid;
+                const QParam p = dql_param(g.mm_in + 2 * row_owner(grow, valid));
+                srow[i] = p.scale * g.w_scale;
+                zc[i] = 128 - (int)p.zp;
+            }
+            float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
+            if (GLU) {
+                // W rows interleaved in 32-channel groups: [value(32) | gate(32)] per 64 columns
+                const int nb = n0 + wn * WN;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = 8 * q + 4 * hi;
+                    const f32x4 ba = ldf4(rs_bias, nb + nl), bg = ldf4(rs_bias, nb + 32 + nl);
+                    const i32x4 wa = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, (nb + nl) * 4, 0, 0));
+                    const i32x4 wg = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, (nb + 32 + nl) * 4, 0, 0));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rl = wm * 64 + i * 32 + l31;
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float av = (float)(acc[i][0][q * 4 + e] + zc[i] * wa[e]) * srow[i] + ba[e];
+                            const float gv = (float)(acc[i][NF - 1][q * 4 + e] + zc[i] * wg[e]) * srow[i] + bg[e];
+                            o[e] = av * (1.0f / (1.0f + expf(-gv)));
+                            mn[i] = fminf(mn[i], o[e]);
+                            mx[i] = fmaxf(mx[i], o[e]);
+                        }
+                        *(f32x4 *)(sO + rl * LDT + wn * (WN / 2) + nl) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = wn * WN + j * 32 + 8 * q + 4 * hi;
+                        const f32x4 bb = ldf4(rs_bias, n0 + cl);
+                        const i32x4 ws = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, (n0 + cl) * 4, 0, 0));
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int rl = wm * 64 + i * 32 + l31;
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = (float)(acc[i][j][q * 4 + e] + zc[i] * ws[e]) * srow[i] + bb[e];
+                                if (RELU) v = v > 0.f ? v : 0.f;
+                                o[e] = v;
+                                mn[i] = fminf(mn[i], v);
+                                mx[i] = fmaxf(mx[i], v);
+                            }
+                            *(f32x4 *)(sO + rl * LDT + cl) = o;
+                        }
+                    }
+            }
+            if (FOLD) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rl = wm * 64 + i * 32 + l31;
+                    atomicMin(&sMM[2 * rl], fenc(mn[i]));
+                    atomicMax(&sMM[2 * rl + 1], fenc(mx[i]));
+                }
+            }
+        }
+        __syncthreads();
+        if (FOLD && tid < BM && m0 + tid < g.M) {
+            bool valid;
+            const int u = row_owner(m0 + tid, valid);
+            const uint32_t kn = sMM[2 * tid], kx = sMM[2 * tid + 1];
+            if (valid && kn <= kx) mm_fold_keys(g.mm_out + 2 * u, kn, kx);
+        }
+        // the output descriptor is rebased on this tile's first row: the dense subsampling tensors have millions of rows
+        // (4-byte elements), and a whole-tensor descriptor would need more than its 32-bit size / offsets hold
+        const int tile_rows = g.M - m0 < BM ? g.M - m0 : BM;
+        if (OUT16) {
+            constexpr int CPR = BNO / 8;   // 16-byte chunks of halves per row
+            const __amdgpu_buffer_rsrc_t rs_out16 = __builtin_amdgcn_make_buffer_rsrc((half_t *)g.out + (size_t)m0 * g.ldo, 0,
+                                                                                      tile_rows * g.ldo * 2, 0x00020000);
+            for (int idx = tid; idx < BM * CPR; idx += NT) {
+                const int r = idx / CPR, c = (idx % CPR) * 8;
+                if (r >= tile_rows) continue;
+                const f32x4 a = *(const f32x4 *)(sO + r * LDT + c), b = *(const f32x4 *)(sO + r * LDT + c + 4);
+                const half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, h), rs_out16, (r * g.ldo + n0 + c) * 2, 0, 0);
+            }
+        } else {
+            constexpr int CPR = BNO / 4;            // 16-byte chunks per row
+            constexpr int IT = BM * CPR / NT;       // chunks per thread (exact)
+            const int n0o = GLU ? n0 / 2 : n0;
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((float *)g.out + (size_t)m0 * g.ldo, 0,
+                                                                                    tile_rows * g.ldo * 4, 0x00020000);
+            f32x4 old[IT];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int k = 0; k < IT; ++k) {
+                    const int idx = tid + k * NT, r = idx / CPR, c = (idx % CPR) * 4;
+                    if (r < tile_rows) old[k] = ldf4(rs_out, r * g.ldo + n0o + c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int idx = tid + k * NT, r = idx / CPR, c = (idx % CPR) * 4;
+                if (r >= tile_rows) continue;
+                f32x4 v = *(const f32x4 *)(sO + r * LDT + c);
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = old[k][e] + g.alpha * v[e];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, (r * g.ldo + n0o + c) * 4, 0, 0);
+            }
+        }
+        return;
+    }
 
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
         // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  The tile goes through LDS as [d][frame] so
@@ -573,6 +732,7 @@ static void launch_one(const GemmArgs &g, hipStream_t s) {
     size_t lds = W4 ? NST * ((128 * 64 * 2) + (BN * 32)) + (size_t)BN * (g.K / 128) * 4
                     : W8 ? NST * ((128 * 64 * 2) + (BN * 64)) : NST * ((128 * 64 * 2) + (BN * 64 * 2));
     size_t epi = epi_is_f32(EPI) ? (size_t)128 * (BN + 4) * 4 : (size_t)128 * (BN + 8) * 2;
+    if (WQ == 88) epi = (size_t)128 * ((EPI == EPI_GLU ? BN / 2 : BN) + 4) * 4 + 128 * 2 * 4;   // f32 staging + per-row range keys
     if (epi > lds) lds = epi;
     // more than 64 KB of dynamic LDS is opted into, once per instantiation and only where needed
     if (lds > 64 * 1024) {
@@ -692,6 +852,20 @@ void qv_gemm_prof_collect(double *ms, double *flops, int *n) {
 }
 
 static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool narrow, int nst) {
+    if (g.Wi8) {
+        // int8 activations x int8 weights (QV_PREC_ORT_MIXED): the GEMM-shaped convolutions; 128-wide tiles,
+        // register-staged loaders
+        if (g.N % 128 != 0 || !g.wsum || !g.mm_in) abort();
+        switch (epi) {
+            case EPI_GLU: launch_one<EPI_GLU, 128, 88, 2, 1>(g, s); break;
+            case EPI_RESID: launch_one<EPI_RESID, 128, 88, 2, 1>(g, s); break;
+            case EPI_F32: launch_one<EPI_F32, 128, 88, 2, 1>(g, s); break;
+            case EPI_F32_RELU: launch_one<EPI_F32_RELU, 128, 88, 2, 1>(g, s); break;
+            case EPI_F16_RELU: launch_one<EPI_F16_RELU, 128, 88, 2, 1>(g, s); break;
+            default: abort();
+        }
+        return;
+    }
     if (g.Wq) {
         // int4 weights: the Linear layers only (FFN, QKV, attention out, linear_pos)
         switch (epi) {
@@ -755,7 +929,7 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
     if (env_ld == 1) p.nst = 0;
     const int t256 = g_t256 >= 0 ? g_t256 : env_t256;
     p.wide = false;
-    if (t256 > 0 && g.N % 256 == 0 && g.bias && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
+    if (t256 > 0 && g.N % 256 == 0 && g.bias && !g.Wi8 && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
         const int tiles256 = (g.N / 256) * ((g.M + 255) / 256);
         // one batch at a time: a 256 x 256 grid must cover most of the chip (>= 160 tiles) or the 128-wide kernel's
         // 252+ blocks finish sooner; with >= 3 batches in flight the other batches' kernels take the idle CUs and
@@ -775,10 +949,11 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
 
 // "k_gemm256<f16_swish>" / "k_gemm<resid,128>": the kernel launch_gemm picks for this call (measurement reports)
 const char *qv_gemm_kernel_name(int epi, const GemmArgs &g) {
-    static const char *EPI[7] = {"f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"};
+    static const char *EPI[8] = {"f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv", "f32_relu"};
     static thread_local char buf[64];
     const GemmPlan p = gemm_plan(epi, g);
-    if (p.wide) snprintf(buf, sizeof buf, "k_gemm256<%s>", EPI[epi]);
+    if (g.Wi8) snprintf(buf, sizeof buf, "k_gemm<%s,128,a8w8>", EPI[epi]);
+    else if (p.wide) snprintf(buf, sizeof buf, "k_gemm256<%s>", EPI[epi]);
     else snprintf(buf, sizeof buf, "k_gemm<%s,%d>", EPI[epi], p.narrow ? 64 : 128);
     return buf;
 }
@@ -803,6 +978,6 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     (void)hipEventRecord(g_prof.ev[2 * i], s);
     go();
     (void)hipEventRecord(g_prof.ev[2 * i + 1], s);
-    g_prof.cls.push_back(epi * 3 + (p.wide ? 2 : p.narrow ? 0 : 1));
-    g_prof.flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
+    g_prof.cls.push_back((epi == EPI_F32_RELU ? EPI_F16_RELU : epi) * 3 + (p.wide ? 2 : p.narrow ? 0 : 1));   // (21 classes in the ABI)
+    g_prof.flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K * (g.Wi8 ? 2.0 : 1.0));
 }

@@ -36,7 +36,8 @@ enum {
     EPI_GLU = 3,        // out f16 [M][N/2]: (acc_a + b_a) * sigmoid(acc_g + b_g), W rows pre-interleaved
     EPI_RESID = 4,      // out f32 [M][N] = out + alpha * (acc + bias)   (in place on the residual stream)
     EPI_F32 = 5,        // out f32 = alpha * (acc + bias)
-    EPI_QKV = 6         // N = 1536: q,k -> f16 [M][1024] (+bias), v -> transposed f16 Vt[b][h][64][t_pad]
+    EPI_QKV = 6,        // N = 1536: q,k -> f16 [M][1024] (+bias), v -> transposed f16 Vt[b][h][64][t_pad]
+    EPI_F32_RELU = 7    // out f32 = relu(acc + bias)   (A8W8 only: the ReLU output feeds the next quantiser)
 };
 
 struct GemmArgs {
@@ -64,6 +65,19 @@ struct GemmArgs {
     //   w8scale f32 [N], applied in the epilogue (the MFMA runs on the exact integers)
     const uint8_t *W8;
     const float *w8scale;
+    // A8W8 variant (Wi8 != nullptr; QV_PREC_ORT_MIXED, qv_ort.h): A is s8 [M][2 * lda] = x_q - 128, Wi8 is s8 [N][2 * ldw]
+    // row-major (K, lda, ldw stay in units of 2 bytes, so the staging code is the f16 kernel's byte for byte), the
+    // products run on v_mfma_i32_32x32x32_i8 and the epilogue turns the int32 accumulator into
+    //   float(acc + (128 - zp_x[u]) * wsum[n]) * (s_x[u] * w_scale) + bias[n],  u = the row's utterance,
+    // with {s_x, zp_x} from the {min, max} keys mm_in[2u .. 2u+1].  mm_out (GLU / ReLU epilogues): the output range of
+    // the valid rows is folded into mm_out[2u .. 2u+1] for the next quantiser.
+    const int8_t *Wi8;
+    const int32_t *wsum;      // [N] sum over k of Wi8[n][k]
+    float w_scale;
+    const uint32_t *mm_in;
+    uint32_t *mm_out;
+    const int32_t *len;       // dense rows (row_map == nullptr): valid frames per utterance
+    int rows_per_utt, f_per_t;
 #ifdef QV_GEMM_TRACE
     // dev tool only (tools/gemm_trace.hip): [block][wave][K-step][4] s_memtime stamps
     unsigned long long *trace;
@@ -79,7 +93,7 @@ struct GemmArgs {
 #define QV_SWAP true
 #endif
 
-// WQ: 0 = f16 weights, 4 = W4A16, 8 = W8A16
+// WQ: 0 = f16 weights, 4 = W4A16, 8 = W8A16, 88 = A8W8 (int8 x int8 -> int32)
 // LD: 0 = direct global->LDS loads with NST LDS stages, 1 = register-staged loader waves (NST = 2)
 template <int EPI, int BN, int WQ, int NST, int LD>
 __global__ void k_gemm(GemmArgs g);

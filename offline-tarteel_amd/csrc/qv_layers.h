@@ -28,6 +28,7 @@ void launch_layernorm(const float *x, const float *g, const float *b, half_t *y,
 void launch_layernorm2(float *x, const float *g1, const float *b1, const float *g2, const float *b2, half_t *y, int M,
                        hipStream_t s);
 void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s);
+void launch_to_float(const half_t *x, float *y, size_t n, hipStream_t s);
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_pad, int batch, hipStream_t s);
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,

@@ -7,21 +7,12 @@
 // transposed by the QKV GEMM epilogue so that PV's B operand is K-contiguous too).
 
 #include "qv_layers.h"
+#include "qv_dev_util.h"
 
 #include <math.h>
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------ front-end ----------
@@ -116,13 +107,6 @@ __global__ __launch_bounds__(320) void k_melstats(const float *__restrict__ feat
         atomicAdd(&acc[((size_t)b * QV_NMEL + f) * 2], p1[0][f] + p1[1][f] + p1[2][f] + p1[3][f]);
         atomicAdd(&acc[((size_t)b * QV_NMEL + f) * 2 + 1], p2[0][f] + p2[1][f] + p2[2][f] + p2[3][f]);
     }
-}
-
-__device__ __forceinline__ void mel_mean_rstd(const double *acc, int b, int f, int tm, float &mean, float &rstd) {
-    double s1 = acc[((size_t)b * QV_NMEL + f) * 2], s2 = acc[((size_t)b * QV_NMEL + f) * 2 + 1];
-    double mu = s1 / tm, var = (s2 - s1 * mu) / (tm - 1);
-    mean = (float)mu;
-    rstd = 1.f / (sqrtf((float)(var > 0.0 ? var : 0.0)) + 1e-5f);
 }
 
 // materialise the normalised features (only for the debug tap / parity tests)
@@ -363,28 +347,6 @@ __device__ __forceinline__ void ln_row(const float v[8], const float *__restrict
     for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * g0[i] + b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * g1[i] + b1[i]; }
 }
 
-// LayerNorm parameters of one lane (8 channels), requested before the row statistics so that
-// their latency overlaps the reductions
-struct LnParam { f32x4 g0, g1, b0, b1; };
-__device__ __forceinline__ LnParam ln_param(const float *__restrict__ gam, const float *__restrict__ bet, int lane) {
-    LnParam p;
-    p.g0 = *(const f32x4 *)(gam + lane * 8); p.g1 = *(const f32x4 *)(gam + lane * 8 + 4);
-    p.b0 = *(const f32x4 *)(bet + lane * 8); p.b1 = *(const f32x4 *)(bet + lane * 8 + 4);
-    return p;
-}
-__device__ __forceinline__ void ln_row_p(const float v[8], const LnParam &p, float o[8]) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
-    float mu = wave_sum(s) * (1.f / QV_D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { float d = v[i] - mu; q += d * d; }
-    float rs = rsqrtf(wave_sum(q) * (1.f / QV_D) + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * p.g0[i] + p.b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * p.g1[i] + p.b1[i]; }
-}
-
 // One wave normalises LN_ROWS consecutive rows: all their loads (and the parameters) are in flight
 // before the first reduction, and a wave lives for LN_ROWS rows instead of one.
 #define LN_ROWS 2
@@ -459,6 +421,12 @@ __global__ void k_to_half(const float *__restrict__ x, half_t *__restrict__ y, s
     f32x4 a = *(const f32x4 *)(x + i * 8), c = *(const f32x4 *)(x + i * 8 + 4);
     half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)c[0], (half_t)c[1], (half_t)c[2], (half_t)c[3]};
     *(half8 *)(y + i * 8) = h;
+}
+
+// f16 -> f32 (debug taps)
+__global__ void k_to_float(const half_t *__restrict__ x, float *__restrict__ y, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
 }
 
 // ------------------------------------------------------------------ attention ----------
@@ -938,6 +906,10 @@ void launch_layernorm2(float *x, const float *g1, const float *b1, const float *
 void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s) {
     size_t n8 = n / 8;
     hipLaunchKernelGGL(k_to_half, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, x, y, n8);
+}
+
+void launch_to_float(const half_t *x, float *y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
 }
 
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,

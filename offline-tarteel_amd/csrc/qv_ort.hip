@@ -1,0 +1,455 @@
+// qv_ort.hip -- non-GEMM kernels of QV_PREC_ORT_MIXED (see qv_ort.h): range tracking, DynamicQuantizeLinear, and the
+// depthwise / strided convolutions of the model as exact integer convolutions.
+//
+// Integer arithmetic in float32: |x_q - zp| <= 255, |w_q| <= 127 and at most 9 taps, so every product and every
+// partial sum is an integer below 2^24 -- fmaf on integer-valued floats IS the int32 accumulation of ConvInteger.
+// (The GEMM-shaped convolutions run on the i8 MFMA instead: k_gemm<.., WQ = 88, ..> in qv_gemm.hip.)
+// All of these are HBM-bound elementwise / small-stencil kernels; they keep the tiling of their f16 counterparts in
+// qv_layers.hip (a lane owns 8 channels, weights in registers, sliding windows), only the element type changes.
+
+#include "qv_ort.h"
+#include "qv_dev_util.h"
+
+#include <math.h>
+
+namespace {
+
+__global__ void k_mm_init(uint32_t *__restrict__ mm, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mm[i] = QV_MM_INIT;
+}
+
+__device__ __forceinline__ int owner_utt(const RowOwner &o, int row) { return o.row_map ? (o.row_map[row] >> 16) : row / o.rows_per_utt; }
+
+// per-wave fold of a thread-private range (inactive threads pass +inf / -inf)
+__device__ __forceinline__ void wave_fold(uint32_t *mm, float mn, float mx, int lane) {
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane == 0 && mn <= mx) mm_fold(mm, mn, mx);
+}
+
+// ------------------------------------------------------------------ quantise ----------
+// f32 [rows][C] -> s8 [rows][C]; a thread converts 16 consecutive values (one 16-byte store)
+__global__ __launch_bounds__(256) void k_quant_rows(const float *__restrict__ x, int rows, int C, const RowOwner own,
+                                                    const uint32_t *__restrict__ mm, int8_t *__restrict__ y) {
+    const int cpr = C >> 4;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)rows * cpr) return;
+    const int row = (int)(idx / cpr), c = (int)(idx - (size_t)row * cpr) << 4;
+    const QParam p = dql_param(mm + 2 * owner_utt(own, row));
+    const float *px = x + (size_t)row * C + c;
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *(const f32x4 *)(px + 4 * k);
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t u = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = (int)quant_u8(v[k][e], p) - 128;
+            u |= ((uint32_t)q & 0xFFu) << (8 * e);
+        }
+        w[k] = u;
+    }
+    *(uint4 *)(y + (size_t)row * C + c) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ------------------------------------------------------------------ LayerNorm ----------
+// k_layernorm's row handling (qv_layers.hip): one wave normalises LN_ROWS consecutive rows of 512.
+// QUANT = false: fold the row's output range into its utterance's pair (and keep the f32 output when y32 is set);
+// QUANT = true : recompute the same values, write them as s8.
+#define LNQ_ROWS 2
+template <bool QUANT>
+__global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, const float *__restrict__ gam,
+                                                const float *__restrict__ bet, int M, const int32_t *__restrict__ row_map,
+                                                uint32_t *__restrict__ mm, float *__restrict__ y32, int8_t *__restrict__ y8) {
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LNQ_ROWS, lane = threadIdx.x & 63;
+    if (row0 >= M) return;
+    f32x4 a[LNQ_ROWS], c[LNQ_ROWS];
+#pragma unroll
+    for (int r = 0; r < LNQ_ROWS; ++r) {
+        const int row = row0 + r < M ? row0 + r : M - 1;
+        const float *p = x + (size_t)row * QV_D + lane * 8;
+        a[r] = *(const f32x4 *)p; c[r] = *(const f32x4 *)(p + 4);
+    }
+    const LnParam pr = ln_param(gam, bet, lane);
+#pragma unroll
+    for (int r = 0; r < LNQ_ROWS; ++r) {
+        if (row0 + r >= M) break;
+        const int row = row0 + r, utt = row_map[row] >> 16;
+        float v[8] = {a[r][0], a[r][1], a[r][2], a[r][3], c[r][0], c[r][1], c[r][2], c[r][3]}, o[8];
+        ln_row_p(v, pr, o);
+        if (!QUANT) {
+            float mn = o[0], mx = o[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) { mn = fminf(mn, o[i]); mx = fmaxf(mx, o[i]); }
+            wave_fold(mm + 2 * utt, mn, mx, lane);
+            if (y32) {
+                float *q = y32 + (size_t)row * QV_D + lane * 8;
+                *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
+                *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            }
+        } else {
+            const QParam p = dql_param(mm + 2 * utt);
+            uint32_t w[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = (int)quant_u8(o[i], p) - 128;
+                w[i >> 2] |= ((uint32_t)q & 0xFFu) << (8 * (i & 3));
+            }
+            *(uint2 *)(y8 + (size_t)row * QV_D + lane * 8) = make_uint2(w[0], w[1]);
+        }
+    }
+}
+
+// range of f32 [M][512] packed rows, one wave per row
+__global__ __launch_bounds__(256) void k_rows_minmax(const float *__restrict__ x, int M, const int32_t *__restrict__ row_map,
+                                                     uint32_t *__restrict__ mm) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *p = x + (size_t)row * QV_D + lane * 8;
+    const f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
+    float mn = fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(c[0], c[1]), fminf(c[2], c[3])));
+    float mx = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
+    wave_fold(mm + 2 * (row_map[row] >> 16), mn, mx, lane);
+}
+
+// ------------------------------------------------------------------ conv module --------
+// depthwise Conv1d(512, k = 9, pad 4) as ConvInteger on the quantised GLU output, then BatchNorm (eval) and Swish.
+//   y = float(sum_k (x_q[t + k - 4] - zp) * w_q[k]) * (s_x * s_w) + bias
+//   z = fma(y, alpha, beta)      alpha = gamma / sqrt(var + eps), beta = fma(-mean, alpha, bn_bias): torch's eval-mode
+//                                batch_norm on the CPU, bit for bit (tests/test_oracle_ort_semantics.py)
+//   out = z * sigmoid(z)
+// Frames t >= len read as zero point (real 0), as the reference's padding does.  Same ownership as k_dwconv1d: a lane
+// owns 8 channels and slides over DWQ_TT consecutive frames.
+#define DWQ_TT 4
+__global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ x, const float *__restrict__ wq, float w_scale,
+                                                      const float *__restrict__ bias, const float *__restrict__ bn_alpha,
+                                                      const float *__restrict__ bn_beta, const int32_t *__restrict__ len,
+                                                      const int32_t *__restrict__ row_off, const uint32_t *__restrict__ mm_in,
+                                                      uint32_t *__restrict__ mm_out, float *__restrict__ y) {
+    const int b = blockIdx.y, t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DWQ_TT, lane = threadIdx.x & 63;
+    const int T = len[b], c0 = lane * 8;
+    if (t0 >= T) return;
+    const size_t row0 = (size_t)row_off[b];
+    const QParam p = dql_param(mm_in + 2 * b);
+    const float sxw = p.scale * w_scale;
+    float w[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        f32x4 w0 = *(const f32x4 *)(wq + k * QV_D + c0), w1 = *(const f32x4 *)(wq + k * QV_D + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = w0[c]; w[k][4 + c] = w1[c]; }
+    }
+    float acc[DWQ_TT][8];
+#pragma unroll
+    for (int j = 0; j < DWQ_TT; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DWQ_TT + 8; ++i) {
+        const int tt = t0 - 4 + i;
+        if (tt < 0 || tt >= T) continue;
+        const float *px = x + (row0 + tt) * QV_D + c0;
+        const f32x4 v0 = *(const f32x4 *)px, v1 = *(const f32x4 *)(px + 4);
+        float vf[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { vf[c] = quant_u8(v0[c], p) - p.zp; vf[4 + c] = quant_u8(v1[c], p) - p.zp; }
+#pragma unroll
+        for (int j = 0; j < DWQ_TT; ++j) {
+            const int k = i - j;  // tap index: tt = (t0 + j) + k - 4
+            if (k < 0 || k > 8) continue;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[j][c] = __builtin_fmaf(w[k][c], vf[c], acc[j][c]);
+        }
+    }
+    float bs[8], al[8], be[8];
+    {
+        f32x4 b0 = *(const f32x4 *)(bias + c0), b1 = *(const f32x4 *)(bias + c0 + 4);
+        f32x4 a0 = *(const f32x4 *)(bn_alpha + c0), a1 = *(const f32x4 *)(bn_alpha + c0 + 4);
+        f32x4 e0 = *(const f32x4 *)(bn_beta + c0), e1 = *(const f32x4 *)(bn_beta + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; al[c] = a0[c]; al[4 + c] = a1[c]; be[c] = e0[c]; be[4 + c] = e1[c]; }
+    }
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < DWQ_TT; ++j) {
+        if (t0 + j >= T) break;
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float yv = acc[j][c] * sxw + bs[c];
+            const float z = __builtin_fmaf(yv, al[c], be[c]);
+            o[c] = z * (1.0f / (1.0f + expf(-z)));
+            mn = fminf(mn, o[c]);
+            mx = fmaxf(mx, o[c]);
+        }
+        float *q = y + (row0 + t0 + j) * QV_D + c0;
+        *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
+        *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+    wave_fold(mm_out + 2 * b, mn, mx, lane);
+}
+
+// ------------------------------------------------------------------ front-end ----------
+// range of the normalised log-mel features of the valid frames (the input of conv.0's DynamicQuantizeLinear); the
+// normalisation is the expression k_sub01_ort applies on load
+#define MMQ_CHUNKS 16
+__global__ __launch_bounds__(320) void k_mel_minmax(const float *__restrict__ feats, const int32_t *__restrict__ n_samples, int tm_max,
+                                                    const double *__restrict__ stats, uint32_t *__restrict__ mm) {
+    const int b = blockIdx.y, f = threadIdx.x % QV_NMEL, g = threadIdx.x / QV_NMEL;  // 4 time groups
+    const int tm = n_samples[b] / 160 + 1;
+    const int per = (tm + MMQ_CHUNKS - 1) / MMQ_CHUNKS, t0 = blockIdx.x * per, t1 = min(tm, t0 + per);
+    const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    float mean, rstd;
+    mel_mean_rstd(stats, b, f, tm, mean, rstd);
+    float mn = INFINITY, mx = -INFINITY;
+    for (int t = t0 + g; t < t1; t += 4) {
+        const float v = (x[t * QV_NMEL + f] - mean) * rstd;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    wave_fold(mm + 2 * b, mn, mx, threadIdx.x & 63);
+}
+
+// conv.0 (Conv2d 1 -> 256, 3x3, s2, p1) + ReLU and conv.2 (depthwise 3x3, s2, p1) as integer convolutions; k_sub01's
+// tiling (qv_layers.hip): block = (64-channel group, 4 output frames, utterance), the 19 mel rows it needs sit in LDS
+// -- here as x_q - zp --, the 9 x 40 x 64 conv.0 tile is computed into LDS and the depthwise conv reads it from there.
+//   PASS 0: only the range of ReLU(conv.0) over the valid frames (its DynamicQuantizeLinear needs the max first);
+//   PASS 1: conv.0 again, quantised with that range into the tile (integers 0..255: exact as f16), then conv.2 ->
+//           f32 [B][T2][20][256] with its range folded for conv.3's quantiser.
+#define SQ_TT 4
+#define SQ_R1 (2 * SQ_TT + 1)
+#define SQ_RM (2 * SQ_R1 + 1)
+#define SQ_CG 64
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_mel,
+                                                   const double *__restrict__ stats, const float *__restrict__ w0q, float w0_scale,
+                                                   const float *__restrict__ b0, const int32_t *__restrict__ len1,
+                                                   const float *__restrict__ w1q, float w1_scale, const float *__restrict__ b1,
+                                                   const int32_t *__restrict__ len2, const uint32_t *__restrict__ mm_mel,
+                                                   uint32_t *__restrict__ mm_c0, uint32_t *__restrict__ mm_c1,
+                                                   float *__restrict__ out, int t2_max) {
+    __shared__ float rows[SQ_RM][QV_NMEL + 2];
+    __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
+    __shared__ __attribute__((aligned(16))) half_t tile[SQ_R1][40][SQ_CG];
+    const int b = blockIdx.z, t2_0 = blockIdx.y * SQ_TT, cg = blockIdx.x * SQ_CG, tid = threadIdx.x, lane = tid & 63;
+    const int tin = len_mel[b], l1 = len1[b];
+    const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
+    __syncthreads();
+    const QParam pm = dql_param(mm_mel + 2 * b);
+    const int t1_0 = 2 * t2_0 - 1;         // first conv.0 row of the tile
+    const int tm_0 = 2 * t1_0 - 1;         // first mel row
+    for (int i = tid; i < SQ_RM * (QV_NMEL + 2); i += 256) {
+        int r = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = tm_0 + r;
+        // frames past the utterance and the conv padding are real zeros = the zero point
+        rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_u8((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) - pm.zp : 0.f;
+    }
+    const int c8 = (tid & 7) * 8, pl = tid >> 3;   // 8 channels per thread, 32 positions per pass
+    float w[9][8], bs[8];
+    auto load_w = [&](const float *wt, const float *bias) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            f32x4 wa = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8), wb = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { w[k][c] = wa[c]; w[k][4 + c] = wb[c]; }
+        }
+        f32x4 ba = *(const f32x4 *)(bias + cg + c8), bb = *(const f32x4 *)(bias + cg + c8 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
+    };
+    load_w(w0q, b0);
+    __syncthreads();
+    const float s0 = pm.scale * w0_scale;
+    QParam p0 = {1.f, 0.f};
+    if (PASS == 1) p0 = dql_param(mm_c0 + 2 * b);
+    float mn = INFINITY, mx = -INFINITY;
+    // ---- conv.0 + ReLU (rows outside [0, l1) are the depthwise conv's zero padding)
+    for (int p = pl; p < SQ_R1 * 40; p += 32) {
+        int r = p / 40, f1 = p - r * 40, t1 = t1_0 + r;
+        half8 o;
+        if (t1 < 0 || t1 >= l1) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
+        } else {
+            float acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    float v = rows[2 * r + dt][2 * f1 + df];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], v, acc[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float yv = acc[c] * s0 + bs[c];
+                yv = yv > 0.f ? yv : 0.f;
+                if (PASS == 0) { mn = fminf(mn, yv); mx = fmaxf(mx, yv); }
+                else o[c] = (half_t)(quant_u8(yv, p0) - p0.zp);
+            }
+        }
+        if (PASS == 1) *(half8 *)&tile[r][f1][c8] = o;
+    }
+    if (PASS == 0) {
+        wave_fold(mm_c0 + 2 * b, mn, mx, lane);
+        return;
+    }
+    load_w(w1q, b1);
+    __syncthreads();
+    const float s1 = p0.scale * w1_scale;
+    const int l2 = len2[b];
+    // ---- depthwise 3x3 stride 2 over the tile
+    for (int p = pl; p < SQ_TT * 20; p += 32) {
+        int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
+        if (t2 >= t2_max) continue;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                int f = 2 * fo - 1 + df;
+                if (f < 0 || f >= 40) continue;
+                half8 v = *(const half8 *)&tile[2 * tl + dt][f][c8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
+            }
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            o[c] = acc[c] * s1 + bs[c];
+            if (t2 < l2) { mn = fminf(mn, o[c]); mx = fmaxf(mx, o[c]); }
+        }
+        float *q = out + (((size_t)b * t2_max + t2) * 20 + fo) * QV_SUBC + cg + c8;
+        *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
+        *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+    wave_fold(mm_c1 + 2 * b, mn, mx, lane);
+}
+
+// conv.5: depthwise Conv2d(256, 3x3, s2, p1) as ConvInteger on the quantised f32 input (channels-last); rows
+// t >= len_in[b] read as the zero point.  Same ownership as k_dwconv2d: 8 channels per thread.
+__global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ in, int tin_max, int fin,
+                                                      const int32_t *__restrict__ len_in, const float *__restrict__ wq, float w_scale,
+                                                      const float *__restrict__ bias, const int32_t *__restrict__ len_out,
+                                                      const uint32_t *__restrict__ mm_in, uint32_t *__restrict__ mm_out,
+                                                      float *__restrict__ out, int tout_max, int fout) {
+    const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
+    const int tin = len_in[b];
+    const int c0 = (tid & 31) * 8, fl = tid >> 5;
+    const QParam p = dql_param(mm_in + 2 * b);
+    const float sxw = p.scale * w_scale;
+    float w[9][8], bs[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        f32x4 w0 = *(const f32x4 *)(wq + k * QV_SUBC + c0), w1 = *(const f32x4 *)(wq + k * QV_SUBC + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = w0[c]; w[k][4 + c] = w1[c]; }
+    }
+    {
+        f32x4 b0 = *(const f32x4 *)(bias + c0), b1 = *(const f32x4 *)(bias + c0 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
+    }
+    const bool valid = to < len_out[b];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int fo = fl; fo < fout; fo += 8) {
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            int t = 2 * to - 1 + dt;
+            if (t < 0 || t >= tin) continue;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                int f = 2 * fo - 1 + df;
+                if (f < 0 || f >= fin) continue;
+                const float *px = in + (((size_t)b * tin_max + t) * fin + f) * QV_SUBC + c0;
+                const f32x4 v0 = *(const f32x4 *)px, v1 = *(const f32x4 *)(px + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] = __builtin_fmaf(w[dt * 3 + df][c], quant_u8(v0[c], p) - p.zp, acc[c]);
+                    acc[4 + c] = __builtin_fmaf(w[dt * 3 + df][4 + c], quant_u8(v1[c], p) - p.zp, acc[4 + c]);
+                }
+            }
+        }
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            o[c] = acc[c] * sxw + bs[c];
+            if (valid) { mn = fminf(mn, o[c]); mx = fmaxf(mx, o[c]); }
+        }
+        float *q = out + (((size_t)b * tout_max + to) * fout + fo) * QV_SUBC + c0;
+        *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
+        *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+    wave_fold(mm_out + 2 * b, mn, mx, tid & 63);
+}
+
+}  // namespace
+
+// ====================================================================== launchers ======
+
+void launch_mm_init(uint32_t *mm, size_t n_keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_mm_init, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s, mm, n_keys);
+}
+
+void launch_quant_rows(const float *x, int rows, int C, const RowOwner &own, const uint32_t *mm, int8_t *y, hipStream_t s) {
+    const size_t n = (size_t)rows * (C / 16);
+    hipLaunchKernelGGL(k_quant_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, C, own, mm, y);
+}
+
+void launch_ln_minmax(const float *x, const float *g, const float *b, int M, const int32_t *row_map, uint32_t *mm, float *y32,
+                      hipStream_t s) {
+    hipLaunchKernelGGL((k_ln_ort<false>), dim3((M + 4 * LNQ_ROWS - 1) / (4 * LNQ_ROWS)), dim3(256), 0, s, x, g, b, M, row_map, mm, y32,
+                       (int8_t *)nullptr);
+}
+
+void launch_ln_quant(const float *x, const float *g, const float *b, int M, const int32_t *row_map, const uint32_t *mm, int8_t *y,
+                     hipStream_t s) {
+    hipLaunchKernelGGL((k_ln_ort<true>), dim3((M + 4 * LNQ_ROWS - 1) / (4 * LNQ_ROWS)), dim3(256), 0, s, x, g, b, M, row_map,
+                       (uint32_t *)mm, (float *)nullptr, y);
+}
+
+void launch_rows_minmax(const float *x, int M, const int32_t *row_map, uint32_t *mm, hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_minmax, dim3((M + 3) / 4), dim3(256), 0, s, x, M, row_map, mm);
+}
+
+void launch_dwconv1d_ort(const float *x, const float *wq, float w_scale, const float *bias, const float *bn_alpha,
+                         const float *bn_beta, const int32_t *len, const int32_t *row_off, const uint32_t *mm_in, uint32_t *mm_out,
+                         float *y, int t_max, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_dwconv1d_ort, dim3((t_max + 4 * DWQ_TT - 1) / (4 * DWQ_TT), batch), dim3(256), 0, s, x, wq, w_scale, bias,
+                       bn_alpha, bn_beta, len, row_off, mm_in, mm_out, y);
+}
+
+void launch_mel_minmax(const float *feats, const int32_t *n_samples, int tm_max, const double *stats, uint32_t *mm, int batch,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_mel_minmax, dim3(MMQ_CHUNKS, batch), dim3(320), 0, s, feats, n_samples, tm_max, stats, mm);
+}
+
+void launch_sub01_ort(int pass, const float *feats, int tm_max, const int32_t *len_mel, const double *stats, const float *w0q,
+                      float w0_scale, const float *b0, const int32_t *len1, const float *w1q, float w1_scale, const float *b1,
+                      const int32_t *len2, const uint32_t *mm_mel, uint32_t *mm_c0, uint32_t *mm_c1, float *out, int t2_max,
+                      int batch, hipStream_t s) {
+    const dim3 grid(QV_SUBC / SQ_CG, (t2_max + SQ_TT - 1) / SQ_TT, batch);
+    if (pass == 0)
+        hipLaunchKernelGGL((k_sub01_ort<0>), grid, dim3(256), 0, s, feats, tm_max, len_mel, stats, w0q, w0_scale, b0, len1, w1q,
+                           w1_scale, b1, len2, mm_mel, mm_c0, mm_c1, out, t2_max);
+    else
+        hipLaunchKernelGGL((k_sub01_ort<1>), grid, dim3(256), 0, s, feats, tm_max, len_mel, stats, w0q, w0_scale, b0, len1, w1q,
+                           w1_scale, b1, len2, mm_mel, mm_c0, mm_c1, out, t2_max);
+}
+
+void launch_dwconv2d_ort(const float *in, int tin_max, int fin, const int32_t *len_in, const float *wq, float w_scale,
+                         const float *bias, const int32_t *len_out, const uint32_t *mm_in, uint32_t *mm_out, float *out,
+                         int tout_max, int fout, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_dwconv2d_ort, dim3(1, tout_max, batch), dim3(256), 0, s, in, tin_max, fin, len_in, wq, w_scale, bias,
+                       len_out, mm_in, mm_out, out, tout_max, fout);
+}

@@ -107,6 +107,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_packed_results_dev.restype = vp
     lib.qv_upfirdn.argtypes = [vp, vp, i64, vp, i32, i32, i32, i64, i64, vp, vp]
     lib.qv_context_count.argtypes = [vp]
+    lib.qv_probe_concurrent_streams.argtypes = []
     lib.qv_last_context.argtypes = [vp]
     lib.qv_wait_ctx.argtypes = [vp, i32]
     lib.qv_packed_results_ctx.argtypes = [vp, i32, vp]
@@ -194,6 +195,8 @@ class Engine:
                 raise FileNotFoundError(msg)
             raise QvError(f"qv_create failed ({rc}): {msg}")
         self.h = h
+        # the engine may run fewer batches in flight than asked for (qv_probe_concurrent_streams, include/qverse.h)
+        self.contexts = int(self.lib.qv_context_count(h))
         self.max_batch = max_batch
         self.tables = Tables(self.tables_path)
 

@@ -242,15 +242,27 @@ def quant_dequant_int4_f32scale(w2d: np.ndarray, block: int = 128) -> np.ndarray
 
 
 def dynamic_quantize_linear(x: torch.Tensor):
-    """onnx DynamicQuantizeLinear: (x_q as integer-valued float64, scale, zero_point) of one tensor."""
-    xmin = min(0.0, float(x.min()))
-    xmax = max(0.0, float(x.max()))
-    scale = np.float32((xmax - xmin) / 255.0)
+    """onnx DynamicQuantizeLinear of one tensor: (x_q as integer-valued float64, scale, zero_point), evaluated in
+    FLOAT32 like onnxruntime's CPU kernel does (range widened to include 0; scale = (max - min) / 255; zero point =
+    round-half-even(0 - min / scale) saturated to [0, 255]; x_q = saturate(round-half-even(x / scale) + zero_point)).
+    [EXT] -- the HIP path (csrc/qv_ort.h::dql_param / quant_u8) performs the identical float32 operations."""
+    xmin = np.float32(min(0.0, float(x.min())))
+    xmax = np.float32(max(0.0, float(x.max())))
+    scale = np.float32((xmax - xmin) / np.float32(255.0))                             # float32 subtraction and division
     if scale == 0:
         return torch.zeros_like(x, dtype=torch.float64), np.float32(1.0), 0.0
-    zp = float(np.clip(np.round(np.float32(0.0 - xmin) / scale), 0, 255))           # np.round: half to even
-    xq = torch.clamp(torch.round(x / float(scale)) + zp, 0, 255).to(torch.float64)   # torch.round: half to even
+    zp = float(np.clip(np.rint(np.float32(-xmin) / scale), 0, 255))                   # np.rint: half to even
+    xq = torch.clamp(torch.round(x / float(scale)) + zp, 0, 255).to(torch.float64)     # true f32 division, half to even
     return xq, scale, zp
+
+
+def quantize_weight_int8(wt: torch.Tensor):
+    """quantize_dynamic(weight_type=QInt8) on a Conv weight: ONE symmetric scale per tensor, scale = max|w| / 127,
+    q = saturate(round-half-even(w / scale)) to [-127, 127].  Returns (q as integer-valued float64, scale f32).
+    csrc/qv_model.hip::quant_w8_tensor performs the identical arithmetic."""
+    amax = float(wt.abs().max())
+    sw = np.float32(amax / 127.0) if amax > 0 else np.float32(1.0)
+    return torch.clamp(torch.round(wt / float(sw)), -127, 127).to(torch.float64), sw
 
 
 class OrtMixed:
@@ -275,20 +287,20 @@ class OrtMixed:
 
     def conv(self, w, name: str, x: torch.Tensor, bias_name: str | None, fn, **kw):
         """fn = F.conv1d / F.conv2d.  Quantisation is per CALL of the reference, i.e. per utterance (it
-        feeds batch 1): every batch item gets its own activation scale."""
+        feeds batch 1): every batch item gets its own activation scale.  forward(..., ort=...) therefore runs
+        one utterance at a time, unpadded, so that a call's range never sees padding frames."""
         wt = w[name]
         bias = w[bias_name] if bias_name else None
         if not self._is_conv8(name):
             return fn(x, wt, bias, **kw)
         if name not in self._w8:
-            amax = float(wt.abs().max())
-            sw = np.float32(amax / 127.0) if amax > 0 else np.float32(1.0)
-            self._w8[name] = (torch.clamp(torch.round(wt / float(sw)), -127, 127).to(torch.float64), sw)
+            self._w8[name] = quantize_weight_int8(wt)
         wq, sw = self._w8[name]
         outs = []
         for b in range(x.shape[0]):
             xq, sx, zp = dynamic_quantize_linear(x[b: b + 1])
             acc = fn(xq - zp, wq, None, **kw)                       # exact: integer-valued float64
+            # int32 accumulator -> float32, times the float32 product of the two scales (one rounding), plus bias
             y = (acc * float(np.float32(sx) * np.float32(sw))).to(torch.float32)
             outs.append(y + bias.view(1, -1, *([1] * (y.dim() - 2))) if bias is not None else y)
         return torch.cat(outs, 0)
@@ -392,9 +404,10 @@ def rel_shift(x: torch.Tensor) -> torch.Tensor:
     return x[:, :, 1:].view(b, h, qlen, pos_len)
 
 
-def subsampling(w, feats: torch.Tensor, tm: torch.Tensor, ops=None):
+def subsampling(w, feats: torch.Tensor, tm: torch.Tensor, ops=None, taps: dict | None = None):
     """feats [B,80,Tm] -> [B,T,512]; activations past each stage's valid length are zeroed so a
-    padded batch equals the per-utterance (unpadded) result."""
+    padded batch equals the per-utterance (unpadded) result.  taps (optional) receives the
+    channels-last stage outputs 'c1' (conv.2), 'c1p' (ReLU conv.3), 'c2' (conv.5), 'c2p' (ReLU conv.6): [B,T,F,256]."""
     x = feats.transpose(1, 2).unsqueeze(1)  # [B,1,Tm,80]
     lens = tm.clone()
 
@@ -409,19 +422,25 @@ def subsampling(w, feats: torch.Tensor, tm: torch.Tensor, ops=None):
     x = F.relu(ops.conv(w, pe + "conv.0.weight", x, pe + "conv.0.bias", F.conv2d, stride=2, padding=1))
     lens = (lens + 2 - 3) // 2 + 1
     x = mask_t(x, lens)
-    for dw, pw in ((2, 3), (5, 6)):
+    for k, (dw, pw) in enumerate(((2, 3), (5, 6))):
         x = ops.conv(w, f"{pe}conv.{dw}.weight", x, f"{pe}conv.{dw}.bias", F.conv2d, stride=2, padding=1, groups=SUB_CH)
+        if taps is not None:
+            taps[f"c{k + 1}"] = x.permute(0, 2, 3, 1).contiguous()
         x = F.relu(ops.conv(w, f"{pe}conv.{pw}.weight", x, f"{pe}conv.{pw}.bias", F.conv2d))
         lens = (lens + 2 - 3) // 2 + 1
         x = mask_t(x, lens)
+        if taps is not None:
+            taps[f"c{k + 1}p"] = x.permute(0, 2, 3, 1).contiguous()
     b, c, t, f = x.shape
     x = x.transpose(1, 2).reshape(b, t, c * f)
     x = ops.linear(w, pe + "out.weight", x, pe + "out.bias")
     return x, lens
 
 
-def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torch.Tensor, ops=None):
-    """x [B,T,512]; pad [B,T] True where padded."""
+def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torch.Tensor, ops=None, taps: dict | None = None,
+                    tag: str = ""):
+    """x [B,T,512]; pad [B,T] True where padded.  taps (optional) receives the conv module's stage tensors
+    'lnc<tag>' (norm_conv output), 'glu<tag>' (GLU output), 'dw<tag>' (depthwise conv + BatchNorm + Swish): [B,T,512]."""
     B, T, _ = x.shape
     ops = ops or _Plain()
 
@@ -456,14 +475,20 @@ def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torc
     r = r + ops.linear(w, a + "linear_out.weight", ctx, a + "linear_out.bias")
     # --- conv module
     y = ln("norm_conv", r).transpose(1, 2)
+    if taps is not None:
+        taps["lnc" + tag] = y.transpose(1, 2).contiguous()
     c = p + "conv."
     y = ops.conv(w, c + "pointwise_conv1.weight", y, c + "pointwise_conv1.bias", F.conv1d)
     y = F.glu(y, dim=1)
     y = y.masked_fill(pad[:, None, :], 0.0)
+    if taps is not None:
+        taps["glu" + tag] = y.transpose(1, 2).contiguous()
     y = ops.conv(w, c + "depthwise_conv.weight", y, c + "depthwise_conv.bias", F.conv1d, padding=(CONV_K - 1) // 2, groups=D_MODEL)
     y = F.batch_norm(y, w[c + "batch_norm.running_mean"], w[c + "batch_norm.running_var"], w[c + "batch_norm.weight"],
                      w[c + "batch_norm.bias"], False, 0.0, 1e-5)
     y = y * torch.sigmoid(y)
+    if taps is not None:
+        taps["dw" + tag] = y.transpose(1, 2).contiguous()
     y = ops.conv(w, c + "pointwise_conv2.weight", y, c + "pointwise_conv2.bias", F.conv1d).transpose(1, 2)
     r = r + y
     r = r + 0.5 * ffn("feed_forward2", ln("norm_feed_forward2", r))
@@ -473,13 +498,38 @@ def conformer_layer(w, p: str, x: torch.Tensor, pos_emb: torch.Tensor, pad: torc
 @torch.no_grad()
 def forward(w, audio: torch.Tensor, lengths, n_layers: int = N_LAYERS, taps: dict | None = None, ort: OrtMixed | None = None):
     """audio [B,N] float32, lengths -> (log_probs [B,T,1025], T lengths).  taps (optional dict)
-    receives intermediate activations: 'mel' [B,Tm,80], 'sub' [B,T,512], 'layer{i}' [B,T,512].
-    ort: route every Linear / Conv through the onnxruntime int4 / dynamic-int8 arithmetic (OrtMixed)."""
+    receives intermediate activations: 'mel' [B,Tm,80], 'sub' [B,T,512], 'layer{i}' [B,T,512] (+ the stage tensors
+    of subsampling() / conformer_layer(): 'c1', 'c1p', 'c2', 'c2p', 'lnc{i}', 'glu{i}', 'dw{i}').
+    ort: route every Linear / Conv through the onnxruntime int4 / dynamic-int8 arithmetic (OrtMixed).  The
+    reference feeds onnxruntime ONE unpadded utterance per call (experiments/c2c-direct-mixed/run.py:59-63) and the
+    activation ranges of DynamicQuantizeLinear are per call, so with `ort` every utterance runs alone, trimmed to its
+    length; results (and taps, zero padded) are stacked afterwards."""
     lengths = torch.as_tensor(lengths, dtype=torch.int64)
+    if ort is not None and (audio.shape[0] > 1 or int(lengths[0]) != audio.shape[1]):
+        outs, lens, per = [], [], []
+        for b in range(audio.shape[0]):
+            n = int(lengths[b])
+            tb = {} if taps is not None else None
+            lp, tl = forward(w, audio[b: b + 1, :n].contiguous(), [n], n_layers, tb, ort)
+            outs.append(lp[0])
+            lens.append(int(tl[0]))
+            per.append(tb)
+        T = max(lens)
+        lp = torch.zeros(len(outs), T, VOCAB)
+        for b, o in enumerate(outs):
+            lp[b, : o.shape[0]] = o
+        if taps is not None:
+            for k in per[0]:
+                shp = [max(t[k].shape[1] for t in per)] + list(per[0][k].shape[2:])
+                z = torch.zeros(len(per), *shp)
+                for b, t in enumerate(per):
+                    z[b, : t[k].shape[1]] = t[k][0]
+                taps[k] = z
+        return lp, torch.tensor(lens, dtype=torch.int64)
     feats, tm = frontend(audio, lengths)
     if taps is not None:
         taps["mel"] = feats.transpose(1, 2).contiguous()
-    x, lens = subsampling(w, feats, tm, ort)
+    x, lens = subsampling(w, feats, tm, ort, taps)
     if taps is not None:
         taps["sub"] = x.clone()
     B, T, _ = x.shape
@@ -487,7 +537,7 @@ def forward(w, audio: torch.Tensor, lengths, n_layers: int = N_LAYERS, taps: dic
     pos_emb = rel_pos_emb(T).unsqueeze(0)
     pad = torch.arange(T)[None, :] >= lens[:, None]
     for i in range(n_layers):
-        x = conformer_layer(w, f"encoder.layers.{i}.", x, pos_emb, pad, ort)
+        x = conformer_layer(w, f"encoder.layers.{i}.", x, pos_emb, pad, ort, taps, str(i))
         if taps is not None:
             taps[f"layer{i}"] = x.clone()
     head = "ctc_decoder.decoder_layers.0."

@@ -1,0 +1,212 @@
+"""QV_PREC_ORT_MIXED on the GPU: the arithmetic onnxruntime runs on the reference's model file
+(experiments/c2c-direct-mixed/run.py:1-9 -- MatMulNBits int4 + DynamicQuantizeLinear / ConvInteger on every Conv)
+against its CPU restatement oracle/fastconformer_ref.py::OrtMixed, through the C ABI.
+
+Two kinds of checks:
+  * STAGE checks: the float32 tensor in front of a quantiser is read back from the device (qv_debug_forward_tap 3..9),
+    the oracle runs that one Conv on it, and the device's own output tensor must equal the oracle's.  The integer part
+    (quantised activations, int8 weights, int32 accumulation, float32 rescale + bias) has no tolerance to hide in: one
+    wrong LSB is 4e-3 of the tensor's range; the bounds below are 1e-5 of it (Swish / sigmoid differ by an ulp or two
+    between expf implementations, everything else is expected to be bit-identical and the match rate is printed).
+  * END-TO-END: log-probs against the oracle.  The oracle differs from ITSELF by ~0.05 max / ~0.012 rms when only the
+    float32 summation order changes (1 vs 16 threads; profiles/r03_a_ort_noise_floor.json), because every
+    DynamicQuantizeLinear is a rounding discontinuity; the bound here is that floor with head room, and the f16-weight
+    path (QV_PREC_MIXED_INT4_INT8) must be several times further away.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from synth import synth_audio
+
+pytestmark = pytest.mark.gpu
+
+SEED = 7
+LENS = [48000, 30000, 17777]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    os.environ["QVERSE_DEBUG_TAPS"] = "1"
+    from offline_tarteel_amd.engine import Engine
+    from oracle import fastconformer_ref as R
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    audio = torch.from_numpy(synth_audio(3, 48000))
+    for b, n in enumerate(LENS):
+        audio[b, n:] = 0
+    w = R.random_weights(SEED)
+    eng = Engine(device=0, with_model=True, seed=SEED, precision=2, max_batch=4, max_samples=80000)
+    lp, t = eng.forward(audio.cuda().contiguous(), LENS)
+    torch.cuda.synchronize()
+    tm = [n // 160 + 1 for n in LENS]
+    sl = lambda x: (x + 2 - 3) // 2 + 1  # noqa: E731
+    l1 = [sl(x) for x in tm]
+    l2 = [sl(x) for x in l1]
+    l3 = [sl(x) for x in l2]
+    assert l3 == t
+    yield dict(eng=eng, audio=audio, lp=lp, t=t, w=w, R=R, tm=tm, l1=l1, l2=l2, l3=l3, ort=R.OrtMixed())
+    eng.close()
+    os.environ.pop("QVERSE_DEBUG_TAPS", None)
+
+
+def _report(name, got, want, rel):
+    got, want = got.float(), want.float()
+    scale = float(want.abs().max())
+    d = float((got - want).abs().max())
+    same = float((got == want).float().mean())
+    print(f"[ort-stage] {name}: max|d| {d:.3e} of range {scale:.3e}, bit-identical {same:.6f}")
+    assert d <= rel * scale, (name, d, scale, same)
+
+
+def test_frontend_integer_stages(setup):
+    """normalised mel -> conv.0 + ReLU -> conv.2 | -> conv.3 + ReLU | -> conv.5 | -> conv.6 + ReLU, each stage on the
+    DEVICE's own input tensor."""
+    eng, w, ort = setup["eng"], setup["w"], setup["ort"]
+    tm, l2, l3 = setup["tm"], setup["l2"], setup["l3"]
+    B = len(LENS)
+    pe = "encoder.pre_encode."
+    mel = eng.forward_tap(0, 0, (B, max(tm), 80)).cpu()
+    c1 = eng.forward_tap(6, 0, (B, max(l2), 20, 256)).cpu()
+    c1p = eng.forward_tap(7, 0, (B, max(l2), 20, 256)).cpu()
+    c2 = eng.forward_tap(8, 0, (B, max(l3), 10, 256)).cpu()
+    c2p = eng.forward_tap(9, 0, (B, max(l3), 10, 256)).cpu()
+    for b in range(B):
+        x = mel[b, : tm[b]].unsqueeze(0).unsqueeze(0)                                   # [1,1,Tm,80]
+        y = F.relu(ort.conv(w, pe + "conv.0.weight", x, pe + "conv.0.bias", F.conv2d, stride=2, padding=1))
+        y = ort.conv(w, pe + "conv.2.weight", y, pe + "conv.2.bias", F.conv2d, stride=2, padding=1, groups=256)
+        _report(f"conv.0+conv.2[{b}]", c1[b, : l2[b]], y[0].permute(1, 2, 0), 1e-6)
+        x = c1[b, : l2[b]].permute(2, 0, 1).unsqueeze(0).contiguous()                   # [1,256,T2,20]
+        y = F.relu(ort.conv(w, pe + "conv.3.weight", x, pe + "conv.3.bias", F.conv2d))
+        _report(f"conv.3[{b}]", c1p[b, : l2[b]], y[0].permute(1, 2, 0), 1e-6)
+        x = c1p[b, : l2[b]].permute(2, 0, 1).unsqueeze(0).contiguous()
+        y = ort.conv(w, pe + "conv.5.weight", x, pe + "conv.5.bias", F.conv2d, stride=2, padding=1, groups=256)
+        _report(f"conv.5[{b}]", c2[b, : l3[b]], y[0].permute(1, 2, 0), 1e-6)
+        x = c2[b, : l3[b]].permute(2, 0, 1).unsqueeze(0).contiguous()
+        y = F.relu(ort.conv(w, pe + "conv.6.weight", x, pe + "conv.6.bias", F.conv2d))
+        _report(f"conv.6[{b}]", c2p[b, : l3[b]], y[0].permute(1, 2, 0).half().float(), 1e-6)   # stored as f16 (feeds the int4 Linear)
+
+
+@pytest.mark.parametrize("layer", [0, 8, 16])
+def test_conv_module_stages(setup, layer):
+    """norm_conv output -> pointwise_conv1 + GLU | -> depthwise_conv + BatchNorm + Swish, on the device's own inputs."""
+    eng, w, ort, T = setup["eng"], setup["w"], setup["ort"], setup["t"]
+    B = len(LENS)
+    c = f"encoder.layers.{layer}.conv."
+    lnc = eng.forward_tap(3, layer, (B, max(T), 512)).cpu()
+    glu = eng.forward_tap(4, layer, (B, max(T), 512)).cpu()
+    dw = eng.forward_tap(5, layer, (B, max(T), 512)).cpu()
+    for b in range(B):
+        x = lnc[b, : T[b]].t().unsqueeze(0).contiguous()                                # [1,512,T]
+        y = F.glu(ort.conv(w, c + "pointwise_conv1.weight", x, c + "pointwise_conv1.bias", F.conv1d), dim=1)
+        _report(f"L{layer} pw1+GLU[{b}]", glu[b, : T[b]], y[0].t(), 1e-5)
+        x = glu[b, : T[b]].t().unsqueeze(0).contiguous()
+        y = ort.conv(w, c + "depthwise_conv.weight", x, c + "depthwise_conv.bias", F.conv1d, padding=4, groups=512)
+        y = F.batch_norm(y, w[c + "batch_norm.running_mean"], w[c + "batch_norm.running_var"], w[c + "batch_norm.weight"],
+                         w[c + "batch_norm.bias"], False, 0.0, 1e-5)
+        y = y * torch.sigmoid(y)
+        _report(f"L{layer} dw+BN+Swish[{b}]", dw[b, : T[b]], y[0].t(), 1e-5)
+
+
+def test_whole_layer_and_head_on_device_inputs(setup):
+    """one whole Conformer layer (covers pointwise_conv2's residual epilogue) and the CTC head, each from the device's own
+    input: the Linear layers run f16-operand GEMMs here, so the bound is the f16 path's, with room for an LSB flip."""
+    eng, w, ort, R, T = setup["eng"], setup["w"], setup["ort"], setup["R"], setup["t"]
+    B = len(LENS)
+    x0 = eng.forward_tap(1, 0, (B, max(T), 512)).cpu()
+    x1 = eng.forward_tap(2, 0, (B, max(T), 512)).cpu()
+    xe = eng.forward_tap(2, 16, (B, max(T), 512)).cpu()
+    head = "ctc_decoder.decoder_layers.0."
+    for b in range(B):
+        t = T[b]
+        pos = R.rel_pos_emb(t).unsqueeze(0)
+        pad = torch.zeros(1, t, dtype=torch.bool)
+        y = R.conformer_layer(w, "encoder.layers.0.", x0[b: b + 1, :t], pos, pad, ort)
+        d = float((y[0] - x1[b, :t]).abs().max())
+        print(f"[ort-stage] layer0[{b}]: max|d| {d:.3e} (values ~ +-3)")
+        assert d <= 5e-2, d
+        lg = ort.conv(w, head + "weight", xe[b: b + 1, :t].transpose(1, 2), head + "bias", F.conv1d).transpose(1, 2)
+        want = torch.log_softmax(lg, -1)[0]
+        got = setup["lp"][b, :t].cpu()
+        _report(f"head[{b}]", got, want, 2e-6)
+
+
+def test_logprobs_against_the_oracle_and_its_noise_floor(setup):
+    R, w, T = setup["R"], setup["w"], setup["t"]
+    lp_ref, t_ref = R.forward(w, setup["audio"], LENS, ort=R.OrtMixed())
+    assert t_ref.tolist() == T
+    got = setup["lp"].cpu()
+    d = torch.cat([(got[b, : T[b]] - lp_ref[b, : T[b]]).flatten() for b in range(len(T))])
+    mx, rms = float(d.abs().max()), float(d.pow(2).mean().sqrt())
+    same = sum(int((got[b, : T[b]].argmax(-1) == lp_ref[b, : T[b]].argmax(-1)).sum()) for b in range(len(T))) / sum(T)
+    print(f"[ort-e2e] hip_ort vs OrtMixed: max {mx:.4f} rms {rms:.5f} argmax {same:.4f}")
+    # the oracle against itself (threads 1 vs 16): 0.05-0.07 max, 0.012 rms, 0.97-0.99 argmax
+    assert mx <= 0.2 and rms <= 0.03 and same >= 0.95, (mx, rms, same)
+    for b, n in enumerate(T):
+        assert torch.allclose(got[b, :n].exp().sum(-1), torch.ones(n), atol=1e-4)
+    # the f16-arithmetic mixed path is a different model from this one
+    from offline_tarteel_amd.engine import Engine
+
+    eng1 = Engine(device=0, with_model=True, seed=SEED, precision=1, max_batch=4, max_samples=80000)
+    try:
+        lp1, _ = eng1.forward(setup["audio"].cuda().contiguous(), LENS)
+        d1 = torch.cat([(lp1[b, : T[b]].cpu() - lp_ref[b, : T[b]]).flatten() for b in range(len(T))])
+        print(f"[ort-e2e] hip_mixed (W4A16/W8A16) vs OrtMixed: max {float(d1.abs().max()):.4f} rms {float(d1.pow(2).mean().sqrt()):.5f}")
+        assert float(d1.pow(2).mean().sqrt()) > 1.5 * rms
+    finally:
+        eng1.close()
+
+
+def test_batch_invariance_is_exact(setup):
+    """the activation ranges are per utterance: an utterance alone == the same utterance inside a ragged batch, bit for bit
+    (the reference quantises per call and feeds batch 1)."""
+    eng, audio = setup["eng"], setup["audio"]
+    for b in (1, 2):
+        n = LENS[b]
+        lp1, t1 = eng.forward(audio[b: b + 1, :n].cuda().contiguous(), [n])
+        assert t1[0] == setup["t"][b]
+        assert torch.equal(lp1[0, : t1[0]], setup["lp"][b, : t1[0]])
+
+
+def test_predict_batch_runs_the_whole_path(setup, oracle):
+    eng = setup["eng"]
+    res = eng.predict_batch(setup["audio"].cuda().contiguous(), LENS)
+    for i, n in enumerate(setup["t"]):
+        want = oracle.predict_logprobs(setup["lp"][i, :n].cpu().numpy())
+        assert res[i]["greedy_ids"] == want["greedy_ids"]
+        assert (res[i]["surah"], res[i]["ayah"], res[i]["ayah_end"], res[i]["source"]) == (
+            want["surah"], want["ayah"], want["ayah_end"], want["source"])
+
+
+def test_configs2_batch256_ort_mixed_vs_oracle_sample():
+    """BASELINE configs[2] at full size (256 clips x 10 s) in the reference's arithmetic: two utterances of the batch
+    against the oracle (noise-floor bound), and a third against itself run alone (exact)."""
+    from offline_tarteel_amd.engine import Engine
+    from oracle import fastconformer_ref as R
+
+    n = 160000
+    audio = torch.from_numpy(synth_audio(256, n, seed=31))
+    eng = Engine(device=0, with_model=True, seed=20260630, precision=2, max_batch=256, max_samples=n)
+    try:
+        a = audio.cuda().contiguous()
+        lp, T = eng.forward(a, [n] * 256)
+        torch.cuda.synchronize()
+        assert T == [126] * 256
+        one, _ = eng.forward(a[200:201].contiguous(), [n])
+        assert torch.equal(one[0], lp[200])
+        w = R.random_weights(20260630)
+        for b in (0, 255):
+            ref, _ = R.forward(w, audio[b: b + 1], [n], ort=R.OrtMixed())
+            d = (lp[b].cpu() - ref[0])
+            mx, rms = float(d.abs().max()), float(d.pow(2).mean().sqrt())
+            same = float((lp[b].cpu().argmax(-1) == ref[0].argmax(-1)).float().mean())
+            print(f"[ort-e2e] B=256 utt {b}: max {mx:.4f} rms {rms:.5f} argmax {same:.4f}")
+            assert mx <= 0.25 and rms <= 0.035 and same >= 0.93, (b, mx, rms, same)
+        res = eng.predict_batch(a, [n] * 256, want_text=False)
+        assert len(res) == 256 and all(r["t_frames"] == 126 for r in res)
+    finally:
+        eng.close()

@@ -68,3 +68,49 @@ def test_ort_forward_runs_and_is_closer_to_the_device_weights_than_to_fp32():
     assert lp_ort.shape == lp32.shape and torch.isfinite(lp_ort).all()
     d32, dq = float((lp_ort - lp32).abs().max()), float((lp_ort - lpq).abs().max())
     assert 0 < dq < d32
+
+
+def test_ort_forward_is_per_utterance_like_the_reference_feeds_it():
+    """The reference hands onnxruntime ONE unpadded utterance per call and DynamicQuantizeLinear takes its range from
+    the call's tensor: under `ort` a ragged batch must equal each utterance run alone, bit for bit, taps included."""
+    from synth import synth_audio
+
+    w = R.random_weights(7, n_layers=2)
+    lens = [16000, 11000]
+    a = torch.from_numpy(synth_audio(2, 16000))
+    a[1, lens[1]:] = 0
+    taps = {}
+    lp, T = R.forward(w, a, lens, n_layers=2, taps=taps, ort=R.OrtMixed())
+    for b, n in enumerate(lens):
+        t1 = {}
+        one, To = R.forward(w, a[b: b + 1, :n].contiguous(), [n], n_layers=2, taps=t1, ort=R.OrtMixed())
+        t = int(To[0])
+        assert int(T[b]) == t and torch.equal(one[0, :t], lp[b, :t])
+        for k in ("mel", "c1", "c1p", "c2", "c2p", "sub", "lnc1", "glu1", "dw1", "layer1"):
+            assert torch.equal(taps[k][b, : t1[k].shape[1]], t1[k][0]), k
+    assert float(taps["glu0"][1, int(T[1]):].abs().max()) == 0.0      # stacked taps are zero padded
+
+
+def test_batch_norm_eval_formula_the_device_uses_is_torchs():
+    """csrc/qv_ort.hip::k_dwconv1d_ort applies BatchNorm as fma(y, alpha, beta) with alpha = gamma * (1 / sqrt(var + eps)),
+    beta = fma(-mean, alpha, bias) (prepared in csrc/qv_model.hip): torch's eval-mode batch_norm on the CPU, bit for bit."""
+    rng = np.random.default_rng(3)
+    C, T = 512, 97
+    y = rng.standard_normal((1, C, T)).astype(np.float32) * 3
+    mean, var = rng.standard_normal(C).astype(np.float32) * 0.1, np.abs(rng.standard_normal(C).astype(np.float32)) * 0.1 + 1
+    g, b = 1 + rng.standard_normal(C).astype(np.float32) * 0.1, rng.standard_normal(C).astype(np.float32) * 0.1
+    ref = F.batch_norm(torch.from_numpy(y), torch.from_numpy(mean), torch.from_numpy(var), torch.from_numpy(g), torch.from_numpy(b),
+                       False, 0.0, 1e-5).numpy()
+    alpha = (g * (np.float32(1) / np.sqrt(var + np.float32(1e-5)).astype(np.float32))).astype(np.float32)
+    beta = (b.astype(np.float64) - mean.astype(np.float64) * alpha.astype(np.float64)).astype(np.float32)          # fma(-mean, alpha, b)
+    out = (y.astype(np.float64) * alpha[None, :, None].astype(np.float64) + beta[None, :, None].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(out, ref)
+
+
+def test_weight_quantiser_is_one_symmetric_scale_per_tensor():
+    rng = np.random.default_rng(4)
+    w = torch.from_numpy(rng.normal(size=(8, 3, 9)).astype(np.float32))
+    q, s = R.quantize_weight_int8(w)
+    assert s == np.float32(float(w.abs().max()) / 127.0)
+    assert float(q.abs().max()) == 127.0 and torch.equal(q, torch.round(q))
+    assert float((q * float(s) - w).abs().max()) <= float(s) / 2 + 1e-7
