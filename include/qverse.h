@@ -168,12 +168,12 @@ int qv_upfirdn(qv_engine *e, const float *x_dev, int64_t n_in, const float *taps
  * blocks the host only when the context it is about to reuse is still busy.  Results are joined
  * per context: */
 int32_t qv_context_count(const qv_engine *e);      /* may be lower than qv_config.n_contexts, see below */
-/* How many of eight HIP streams the runtime runs side by side on this device (8, 4, 2 or 1; 0 = probe failed):
- * eight one-wave spin kernels on eight streams, elapsed time over spin time (~1 ms, cached per process).  The runtime maps
- * streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable ONCE, when HIP initialises; streams
- * sharing a queue serialise.  qv_create() calls this when n_contexts >= 4 and falls back to 3 contexts -- the best
- * measured setting on the default 4 queues -- unless all eight streams ran concurrently, so that a host which touched HIP
- * before exporting GPU_MAX_HW_QUEUES=8 loses ~2 % instead of ~14 %. */
+/* How many of SIX fresh HIP streams (four contexts + the caller's + one for copies) the runtime runs side by side on this
+ * device: 6, 3, 2 or 1 (0 = probe failed).  Six one-wave spin kernels on six streams, elapsed time over spin time (~1 ms,
+ * cached per process).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the
+ * variable ONCE, when HIP initialises; streams sharing a queue serialise.  qv_create() calls this when n_contexts >= 4 and
+ * falls back to 3 contexts -- the best measured setting on the default 4 queues -- unless all six ran concurrently, so
+ * that a host which touched HIP before exporting GPU_MAX_HW_QUEUES=8 loses ~2 % instead of ~14 %. */
 int32_t qv_probe_concurrent_streams(void);
 int32_t qv_last_context(const qv_engine *e);     /* context used by the most recent async call */
 /* Host-side join: blocks the calling thread until context `ctx`'s last batch has finished (no-op for an idle

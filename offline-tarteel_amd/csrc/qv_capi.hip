@@ -20,8 +20,8 @@ static std::string g_create_error;
 // streams that share a queue serialise.  An engine with four batches in flight needs a queue per context stream plus the
 // caller's (14.8 k utt/s on 4 queues against 17.3 k on 8, profiles/r02_h_contexts_hwq_sweep.txt), and a host that touched
 // HIP before the variable was set silently gets the default.  Instead of trusting the environment the library measures:
-// eight streams each run a one-wave kernel that spins for a fixed wall-clock time; the elapsed time over the spin time is
-// how many of them shared a queue.
+// six fresh streams (four contexts + the caller's + one for copies) each run a one-wave kernel that spins for a fixed
+// wall-clock time; the elapsed time over the spin time is how many of them shared a queue.
 namespace {
 __global__ void k_spin(long long ticks) {   // wall_clock64: 100 MHz
     const long long t0 = wall_clock64();
@@ -29,10 +29,11 @@ __global__ void k_spin(long long ticks) {   // wall_clock64: 100 MHz
 }
 }  // namespace
 
+#define QV_PROBE_STREAMS 6
 extern "C" int32_t qv_probe_concurrent_streams(void) {
     static int cached = 0;
     if (cached) return cached;
-    constexpr int NS = 8;
+    constexpr int NS = QV_PROBE_STREAMS;
     constexpr long long SPIN_TICKS = 40000;   // 400 us
     hipStream_t st[NS] = {};
     for (int i = 0; i < NS; ++i)
@@ -47,8 +48,9 @@ extern "C" int32_t qv_probe_concurrent_streams(void) {
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
     for (int i = 0; i < NS; ++i) (void)hipStreamDestroy(st[i]);
-    const double rounds = best / (SPIN_TICKS / 100.0);   // kernels that ran one after the other on the busiest queue
-    cached = rounds < 1.5 ? 8 : rounds < 3.0 ? 4 : rounds < 6.0 ? 2 : 1;
+    // kernels that ran one after the other on the busiest queue: 1 = all six side by side
+    const double rounds = best / (SPIN_TICKS / 100.0);
+    cached = rounds < 1.5 ? NS : rounds < 2.5 ? NS / 2 : rounds < 4.5 ? 2 : 1;
     return cached;
 }
 
@@ -490,7 +492,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     // four and more batches in flight only pay with a hardware queue per context stream (and one for the caller); when
     // the runtime runs fewer streams side by side than that -- GPU_MAX_HW_QUEUES unset or set after HIP initialised --
     // three contexts is the best measured setting (17.0 k utt/s on 4 or 8 queues; four contexts on 4 queues: 14.8 k)
-    if (eng->n_ctx >= 4 && qv_probe_concurrent_streams() < 8) eng->n_ctx = 3;
+    if (eng->n_ctx >= 4 && qv_probe_concurrent_streams() < QV_PROBE_STREAMS) eng->n_ctx = 3;
     int rc = load_tables(eng, cfg->tables_path);
     if (rc) return fail(rc);
     for (int k = 0; k < eng->n_ctx; ++k) {

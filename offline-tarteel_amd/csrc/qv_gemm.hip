@@ -498,11 +498,23 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
             }
         }
         __syncthreads();
-        if (FOLD && tid < BM && m0 + tid < g.M) {
-            bool valid;
-            const int u = row_owner(m0 + tid, valid);
-            const uint32_t kn = sMM[2 * tid], kx = sMM[2 * tid + 1];
-            if (valid && kn <= kx) mm_fold_keys(g.mm_out + 2 * u, kn, kx);
+        if (FOLD) {
+            // One atomic pair per (tile, utterance), not per row: all tiles start at once and every row's pair would
+            // land on its utterance's two addresses (measured: 200 us for this GEMM instead of 15).  A tile's rows are
+            // sorted by utterance, so the first row of each run reduces the run.
+            int *sU = (int *)(sMM + 2 * BM);       // [BM] owner of each row, -1 = not a valid row
+            if (tid < BM) {
+                bool valid = false;
+                int u = -1;
+                if (m0 + tid < g.M) u = row_owner(m0 + tid, valid);
+                sU[tid] = valid && sMM[2 * tid] <= sMM[2 * tid + 1] ? u : -1;
+            }
+            __syncthreads();
+            if (tid < BM && sU[tid] >= 0 && (tid == 0 || sU[tid - 1] != sU[tid])) {
+                uint32_t kn = sMM[2 * tid], kx = sMM[2 * tid + 1];
+                for (int k = tid + 1; k < BM && sU[k] == sU[tid]; ++k) { kn = min(kn, sMM[2 * k]); kx = max(kx, sMM[2 * k + 1]); }
+                mm_fold_keys(g.mm_out + 2 * sU[tid], kn, kx);
+            }
         }
         // the output descriptor is rebased on this tile's first row: the dense subsampling tensors have millions of rows
         // (4-byte elements), and a whole-tensor descriptor would need more than its 32-bit size / offsets hold
@@ -732,7 +744,7 @@ static void launch_one(const GemmArgs &g, hipStream_t s) {
     size_t lds = W4 ? NST * ((128 * 64 * 2) + (BN * 32)) + (size_t)BN * (g.K / 128) * 4
                     : W8 ? NST * ((128 * 64 * 2) + (BN * 64)) : NST * ((128 * 64 * 2) + (BN * 64 * 2));
     size_t epi = epi_is_f32(EPI) ? (size_t)128 * (BN + 4) * 4 : (size_t)128 * (BN + 8) * 2;
-    if (WQ == 88) epi = (size_t)128 * ((EPI == EPI_GLU ? BN / 2 : BN) + 4) * 4 + 128 * 2 * 4;   // f32 staging + per-row range keys
+    if (WQ == 88) epi = (size_t)128 * ((EPI == EPI_GLU ? BN / 2 : BN) + 4) * 4 + 128 * 3 * 4;   // f32 staging + per-row range keys and owners
     if (epi > lds) lds = epi;
     // more than 64 KB of dynamic LDS is opted into, once per instantiation and only where needed
     if (lds > 64 * 1024) {

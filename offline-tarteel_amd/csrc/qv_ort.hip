@@ -21,11 +21,32 @@ __global__ void k_mm_init(uint32_t *__restrict__ mm, size_t n) {
 
 __device__ __forceinline__ int owner_utt(const RowOwner &o, int row) { return o.row_map ? (o.row_map[row] >> 16) : row / o.rows_per_utt; }
 
-// per-wave fold of a thread-private range (inactive threads pass +inf / -inf)
-__device__ __forceinline__ void wave_fold(uint32_t *mm, float mn, float mx, int lane) {
+// Folding a range into a site's pair is an L2 atomic on ONE address per utterance: thousands of waves doing it at once
+// serialise there (first version: k_ln_ort 79 us instead of 6, the GLU GEMM 200 us instead of 15).  So ranges are
+// reduced inside the block first -- one atomic pair per (block, utterance) -- and mm_fold's plain read drops the pair
+// altogether once the site's keys have moved past it.
+//
+// whole block = ONE utterance: thread-private ranges (inactive threads pass +inf / -inf) -> one fold by thread 0.
+// Every thread of the block must call it (it synchronises); sh: 2 floats per wave.
+__device__ __forceinline__ void block_fold(uint32_t *mm, float mn, float mx, float *sh) {
     mn = wave_min(mn);
     mx = wave_max(mx);
-    if (lane == 0 && mn <= mx) mm_fold(mm, mn, mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) { sh[2 * wave] = mn; sh[2 * wave + 1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) { mn = fminf(mn, sh[2 * w]); mx = fmaxf(mx, sh[2 * w + 1]); }
+        if (mn <= mx) mm_fold(mm, mn, mx);
+    }
+}
+// rows of several utterances in one block: per-row ranges in LDS (utt < 0 = no row), rows of an utterance are
+// consecutive; the first row of every run reduces its run and folds it.  Threads 0..n_rows-1 take part, after a barrier.
+__device__ __forceinline__ void rows_fold(uint32_t *mm_site, const int *s_utt, const float *s_mn, const float *s_mx, int n_rows, int r) {
+    if (r >= n_rows || s_utt[r] < 0) return;
+    if (r > 0 && s_utt[r - 1] == s_utt[r]) return;
+    float mn = s_mn[r], mx = s_mx[r];
+    for (int k = r + 1; k < n_rows && s_utt[k] == s_utt[r]; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); }
+    mm_fold(mm_site + 2 * s_utt[r], mn, mx);
 }
 
 // ------------------------------------------------------------------ quantise ----------
@@ -64,8 +85,10 @@ template <bool QUANT>
 __global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, const float *__restrict__ gam,
                                                 const float *__restrict__ bet, int M, const int32_t *__restrict__ row_map,
                                                 uint32_t *__restrict__ mm, float *__restrict__ y32, int8_t *__restrict__ y8) {
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LNQ_ROWS, lane = threadIdx.x & 63;
-    if (row0 >= M) return;
+    __shared__ int s_utt[4 * LNQ_ROWS];
+    __shared__ float s_mn[4 * LNQ_ROWS], s_mx[4 * LNQ_ROWS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * LNQ_ROWS;
     f32x4 a[LNQ_ROWS], c[LNQ_ROWS];
 #pragma unroll
     for (int r = 0; r < LNQ_ROWS; ++r) {
@@ -76,15 +99,21 @@ __global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, con
     const LnParam pr = ln_param(gam, bet, lane);
 #pragma unroll
     for (int r = 0; r < LNQ_ROWS; ++r) {
-        if (row0 + r >= M) break;
-        const int row = row0 + r, utt = row_map[row] >> 16;
+        const int row = row0 + r;
+        if (row >= M) {
+            if (!QUANT && lane == 0) s_utt[wave * LNQ_ROWS + r] = -1;
+            continue;
+        }
+        const int utt = row_map[row] >> 16;
         float v[8] = {a[r][0], a[r][1], a[r][2], a[r][3], c[r][0], c[r][1], c[r][2], c[r][3]}, o[8];
         ln_row_p(v, pr, o);
         if (!QUANT) {
             float mn = o[0], mx = o[0];
 #pragma unroll
             for (int i = 1; i < 8; ++i) { mn = fminf(mn, o[i]); mx = fmaxf(mx, o[i]); }
-            wave_fold(mm + 2 * utt, mn, mx, lane);
+            mn = wave_min(mn);
+            mx = wave_max(mx);
+            if (lane == 0) { s_utt[wave * LNQ_ROWS + r] = utt; s_mn[wave * LNQ_ROWS + r] = mn; s_mx[wave * LNQ_ROWS + r] = mx; }
             if (y32) {
                 float *q = y32 + (size_t)row * QV_D + lane * 8;
                 *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
@@ -101,18 +130,35 @@ __global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, con
             *(uint2 *)(y8 + (size_t)row * QV_D + lane * 8) = make_uint2(w[0], w[1]);
         }
     }
+    if (!QUANT) {
+        __syncthreads();
+        rows_fold(mm, s_utt, s_mn, s_mx, 4 * LNQ_ROWS, threadIdx.x);
+    }
 }
 
-// range of f32 [M][512] packed rows, one wave per row
+// range of f32 [M][512] packed rows: a wave takes 4 rows, a block 16
+#define RMM_ROWS 4
 __global__ __launch_bounds__(256) void k_rows_minmax(const float *__restrict__ x, int M, const int32_t *__restrict__ row_map,
                                                      uint32_t *__restrict__ mm) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const float *p = x + (size_t)row * QV_D + lane * 8;
-    const f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
-    float mn = fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(c[0], c[1]), fminf(c[2], c[3])));
-    float mx = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
-    wave_fold(mm + 2 * (row_map[row] >> 16), mn, mx, lane);
+    __shared__ int s_utt[4 * RMM_ROWS];
+    __shared__ float s_mn[4 * RMM_ROWS], s_mx[4 * RMM_ROWS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < RMM_ROWS; ++r) {
+        const int row = (blockIdx.x * 4 + wave) * RMM_ROWS + r;
+        float mn = INFINITY, mx = -INFINITY;
+        if (row < M) {
+            const float *p = x + (size_t)row * QV_D + lane * 8;
+            const f32x4 a = *(const f32x4 *)p, c = *(const f32x4 *)(p + 4);
+            mn = fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(c[0], c[1]), fminf(c[2], c[3])));
+            mx = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) { s_utt[wave * RMM_ROWS + r] = row < M ? (row_map[row] >> 16) : -1; s_mn[wave * RMM_ROWS + r] = mn; s_mx[wave * RMM_ROWS + r] = mx; }
+    }
+    __syncthreads();
+    rows_fold(mm, s_utt, s_mn, s_mx, 4 * RMM_ROWS, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ conv module --------
@@ -129,12 +175,15 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
                                                       const float *__restrict__ bn_beta, const int32_t *__restrict__ len,
                                                       const int32_t *__restrict__ row_off, const uint32_t *__restrict__ mm_in,
                                                       uint32_t *__restrict__ mm_out, float *__restrict__ y) {
+    __shared__ float s_fold[8];
     const int b = blockIdx.y, t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DWQ_TT, lane = threadIdx.x & 63;
     const int T = len[b], c0 = lane * 8;
-    if (t0 >= T) return;
+    if (blockIdx.x * 4 * DWQ_TT >= T) return;   // (whole block)
     const size_t row0 = (size_t)row_off[b];
     const QParam p = dql_param(mm_in + 2 * b);
     const float sxw = p.scale * w_scale;
+    float mn = INFINITY, mx = -INFINITY;
+    if (t0 < T) {
     float w[9][8];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -172,7 +221,6 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; al[c] = a0[c]; al[4 + c] = a1[c]; be[c] = e0[c]; be[4 + c] = e1[c]; }
     }
-    float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < DWQ_TT; ++j) {
         if (t0 + j >= T) break;
@@ -189,7 +237,8 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
         *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
-    wave_fold(mm_out + 2 * b, mn, mx, lane);
+    }
+    block_fold(mm_out + 2 * b, mn, mx, s_fold);
 }
 
 // ------------------------------------------------------------------ front-end ----------
@@ -210,7 +259,8 @@ __global__ __launch_bounds__(320) void k_mel_minmax(const float *__restrict__ fe
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
     }
-    wave_fold(mm + 2 * b, mn, mx, threadIdx.x & 63);
+    __shared__ float s_fold[10];
+    block_fold(mm + 2 * b, mn, mx, s_fold);
 }
 
 // conv.0 (Conv2d 1 -> 256, 3x3, s2, p1) + ReLU and conv.2 (depthwise 3x3, s2, p1) as integer convolutions; k_sub01's
@@ -234,6 +284,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     __shared__ float rows[SQ_RM][QV_NMEL + 2];
     __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
     __shared__ __attribute__((aligned(16))) half_t tile[SQ_R1][40][SQ_CG];
+    __shared__ float s_fold[8];
     const int b = blockIdx.z, t2_0 = blockIdx.y * SQ_TT, cg = blockIdx.x * SQ_CG, tid = threadIdx.x, lane = tid & 63;
     const int tin = len_mel[b], l1 = len1[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
@@ -296,7 +347,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
         if (PASS == 1) *(half8 *)&tile[r][f1][c8] = o;
     }
     if (PASS == 0) {
-        wave_fold(mm_c0 + 2 * b, mn, mx, lane);
+        block_fold(mm_c0 + 2 * b, mn, mx, s_fold);
         return;
     }
     load_w(w1q, b1);
@@ -330,7 +381,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
         *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
-    wave_fold(mm_c1 + 2 * b, mn, mx, lane);
+    block_fold(mm_c1 + 2 * b, mn, mx, s_fold);
 }
 
 // conv.5: depthwise Conv2d(256, 3x3, s2, p1) as ConvInteger on the quantised f32 input (channels-last); rows
@@ -340,6 +391,7 @@ __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ 
                                                       const float *__restrict__ bias, const int32_t *__restrict__ len_out,
                                                       const uint32_t *__restrict__ mm_in, uint32_t *__restrict__ mm_out,
                                                       float *__restrict__ out, int tout_max, int fout) {
+    __shared__ float s_fold[8];
     const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
     const int tin = len_in[b];
     const int c0 = (tid & 31) * 8, fl = tid >> 5;
@@ -390,7 +442,7 @@ __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ 
         *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
-    wave_fold(mm_out + 2 * b, mn, mx, tid & 63);
+    block_fold(mm_out + 2 * b, mn, mx, s_fold);
 }
 
 }  // namespace
@@ -419,7 +471,7 @@ void launch_ln_quant(const float *x, const float *g, const float *b, int M, cons
 }
 
 void launch_rows_minmax(const float *x, int M, const int32_t *row_map, uint32_t *mm, hipStream_t s) {
-    hipLaunchKernelGGL(k_rows_minmax, dim3((M + 3) / 4), dim3(256), 0, s, x, M, row_map, mm);
+    hipLaunchKernelGGL(k_rows_minmax, dim3((M + 4 * RMM_ROWS - 1) / (4 * RMM_ROWS)), dim3(256), 0, s, x, M, row_map, mm);
 }
 
 void launch_dwconv1d_ort(const float *x, const float *wq, float w_scale, const float *bias, const float *bn_alpha,
