@@ -65,6 +65,8 @@ def parse():
                     help="clips: the plain hot path; tta30: c2c-direct-mixed-tta on 30 s clips (configs[4])")
     ap.add_argument("--no-post-logits", action="store_true", help="skip the verse-shaped post-logits replay legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the short secondary legs (BASELINE configs[2] and configs[4] workloads) of the default run")
     ap.add_argument("--cpu-sample", type=int, default=24, help="clips timed on the host for cpu_baseline")
     ap.add_argument("--literal", action="store_true", help="run search()/pass-3 even when the gate passes")
     ap.add_argument("--contexts", type=int, default=4,
@@ -124,10 +126,54 @@ def post_logits_legs(eng, B: int, T: int, steps: int = 10):
     return out
 
 
+def host_cores():
+    """(logical CPUs, physical cores) of this node -- SURVEY.md 8(d) asks for both next to the CPU line."""
+    logical = os.cpu_count() or 1
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return logical, (len(phys) or logical)
+
+
+def post_logits_cpu_split(orc, lps, budget_s: float = 8.0):
+    """the C restatement of the post-logits stages on the host: one thread, and one thread per utterance on all cores
+    (ctypes releases the GIL inside the C calls).  lps: list of [T,1025] float32 arrays."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    t0 = time.perf_counter()
+    done = 0
+    for lp in lps:
+        orc.predict_logprobs(lp)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    one = done / (time.perf_counter() - t0)
+    workers = min(len(lps), os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(orc.predict_logprobs, lps))
+    allc = len(lps) / (time.perf_counter() - t0)
+    return {"post_logits_1_thread_utt_per_s": round(one, 3), "post_logits_all_cores_utt_per_s": round(allc, 3),
+            "post_logits_all_cores_threads": workers}
+
+
 def cpu_baseline(audio_np, n_clips: int, what: str = "10 s clips"):
     """oracle ("port"): fp32 PyTorch-CPU forward + C post-logits, per-file like the reference."""
     import numpy as np
     import torch
+
+    logical, physical = host_cores()
 
     from oracle import fastconformer_ref as R
     from oracle.oracle import Oracle
@@ -165,6 +211,7 @@ def cpu_baseline(audio_np, n_clips: int, what: str = "10 s clips"):
             t_post += t2 - t1
         return {
             "value": round(done / (t_fwd + t_post), 4), "unit": "utterances/s", "cores": os.cpu_count(),
+            "host_logical_cpus": logical, "host_physical_cores": physical,
             "kind": "reference",
             "sample": f"{done} of the benchmark's {what}, batch 1: onnxruntime CPUExecutionProvider on "
                       f"{os.path.basename(ref_onnx)} with default session options ({t_fwd / done:.2f} s per clip) + C "
@@ -182,26 +229,66 @@ def cpu_baseline(audio_np, n_clips: int, what: str = "10 s clips"):
     lp, T = R.forward(w, torch.from_numpy(audio_np[:1]), [n])
     orc.predict_logprobs(lp[0, : int(T[0])].numpy())
     done = 0
+    kept = []
     for i in range(n_clips):
-        if t_fwd + t_post > 30.0:
+        if t_fwd + t_post > 22.0:
             break
         done += 1
         t0 = time.perf_counter()
         lp, T = R.forward(w, torch.from_numpy(audio_np[i: i + 1]), [n])
         t1 = time.perf_counter()
-        orc.predict_logprobs(lp[0, : int(T[0])].numpy())
+        lpn = np.ascontiguousarray(lp[0, : int(T[0])].numpy())
+        orc.predict_logprobs(lpn)
         t2 = time.perf_counter()
+        kept.append(lpn)
         t_fwd += t1 - t0
         t_post += t2 - t1
     tot = t_fwd + t_post
     n_clips = done
+    try:   # the post-logits CPU leg single-threaded and on all cores
+        split = post_logits_cpu_split(orc, kept * max(1, min(8, (os.cpu_count() or 1) // max(1, len(kept)))))
+    except Exception as e:
+        split = {"post_logits_split_error": f"{type(e).__name__}: {e}"}
     return {
         "value": round(n_clips / tot, 4), "unit": "utterances/s", "cores": torch.get_num_threads(),
+        "host_logical_cpus": logical, "host_physical_cores": physical, **split,
         "kind": "port",
         "sample": f"{n_clips} of the benchmark's {what}, batch 1 like the reference "
-                  f"(fp32 PyTorch forward {t_fwd / n_clips:.2f} s + C post-logits {t_post / n_clips:.2f} s per clip); "
-                  "reference ORT/ONNX path unavailable on this node (no onnxruntime, no weight file)",
+                  f"(fp32 PyTorch forward on {torch.get_num_threads()} threads {t_fwd / n_clips:.2f} s + C post-logits on 1 thread "
+                  f"{t_post / n_clips:.2f} s per clip; `cores` = the forward's threads, the host has {physical} physical cores / "
+                  f"{logical} logical CPUs); reference ORT/ONNX path unavailable on this node (no onnxruntime, no weight file)",
     }
+
+
+def extra_legs():
+    """Short driver-visible legs of the secondary BASELINE configs, each a fresh `bench.py` process on this GPU (the
+    engine's capacity is fixed at creation): configs[2] = 256 clips x 10 s with int4 + int8 weights, once in the
+    reference's onnxruntime arithmetic (QV_PREC_ORT_MIXED) and once with f16 operands (QV_PREC_MIXED_INT4_INT8);
+    configs[4]'s per-GPU workload = 64 clips x 30 s through the TTA wrapper.  Returns {name: compact line}."""
+    import subprocess
+
+    legs = {
+        "configs2_b256_ort_mixed": ["--precision", "ort", "--batch", "256", "--steps", "10", "--warmup", "3"],
+        "configs2_b256_mixed_f16_operands": ["--precision", "mixed", "--batch", "256", "--steps", "10", "--warmup", "3"],
+        "configs4_tta30_per_gpu": ["--workload", "tta30", "--steps", "5", "--warmup", "2"],
+    }
+    out = {}
+    for name, flags in legs.items():
+        try:
+            p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *flags, "--no-cpu-baseline", "--no-post-logits", "--no-extra"],
+                               capture_output=True, text=True, timeout=420, cwd=str(ROOT))
+            rows = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+            d = json.loads(rows[-1])
+            out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                         "steps": d["steps"], "dtype": d["dtype"], "workload": d["config"]["workload"],
+                         "batches_in_flight": d["config"]["batches_in_flight"],
+                         "roofline_kernel": d["roofline"]["kernel"], "roofline_frac": d["roofline"]["frac"],
+                         "all_gemm_in_situ_tflops": d["roofline"]["all_gemm_in_situ_tflops"]}
+            if "tta_gated_fraction" in d["config"]:
+                out[name]["tta_gated_fraction"] = d["config"]["tta_gated_fraction"]
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def main():
@@ -434,6 +521,12 @@ def main():
             cpu = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"failed: {type(e).__name__}: {e}"}
 
+    extra = None
+    default_line = (world == 1 and not tta and args.precision == "fp16" and B == 64 and args.seconds == 10.0)
+    if rank == 0 and default_line and not args.no_extra:
+        eng.close()   # the legs create engines of their own on this GPU
+        extra = extra_legs()
+
     if rank == 0:
         mixed = args.precision != "fp16"
         wdesc = ("fp16 weights" if not mixed else
@@ -472,7 +565,7 @@ def main():
                        "skip_unused_passes": not args.literal, "weights": args.precision,
                        "batches_in_flight": n_ctx,
                        "concurrent_streams_probe": int(eng.lib.qv_probe_concurrent_streams())},
-            "roofline": roof, "cpu_baseline": cpu, "post_logits": post,
+            "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "extra": extra,
         }
         if tta:
             out["config"]["tta_gated_fraction"] = round(tta_stats["gated"] / max(1, tta_stats["clips"]), 3)

@@ -117,6 +117,7 @@ def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int 
     for s0 in range(0, len(present), batch if use_batch else 1):
         group = present[s0: s0 + (batch if use_batch else 1)]
         paths = [str(corpus_dir / s["file"]) for s in group]
+        errors = [None] * len(group)
         try:
             t0 = time.perf_counter()
             if use_predict:
@@ -130,29 +131,35 @@ def run_experiment(exp: dict, samples: list[dict], corpus_dir: Path, batch: int 
         except Exception as e:
             print(f"  Error on {[s['id'] for s in group]}: {e}")
             emissions, elapsed = [[] for _ in group], 0.0
+            errors = [f"{type(e).__name__}: {e}"] * len(group)
             if use_batch and len(group) > 1:
                 # one undecodable / over-long file must not empty the whole group: the reference isolates
                 # failures per sample (runner.py:297-325), so the group is retried file by file
-                emissions, per_file = [], []
+                emissions, per_file, errors = [], [], []
                 for path in paths:
                     try:
                         t0 = time.perf_counter()
                         emissions.append(predict_to_emissions(mod.predict(path)))
                         per_file.append(time.perf_counter() - t0)
+                        errors.append(None)
                     except Exception as e1:
                         print(f"  Error on {Path(path).name}: {e1}")
                         emissions.append([])
                         per_file.append(0.0)
+                        errors.append(f"{type(e1).__name__}: {e1}")
                 elapsed = per_file
         if not isinstance(elapsed, list):
             elapsed = [elapsed] * len(group)
-        for (sample, em), elapsed in zip(zip(group, emissions), elapsed):
+        for (sample, em), elapsed, err in zip(zip(group, emissions), elapsed, errors):
             expected = sample.get("expected_verses", [{"surah": sample["surah"], "ayah": sample["ayah"]}])
             sc = score_sequence(expected, em)
             for k in tot:
                 tot[k] += sc[k]
             latencies.append(elapsed)
-            per_sample.append({"id": sample["id"], "expected": expected, "predicted": em, **sc, "latency": elapsed})
+            row = {"id": sample["id"], "expected": expected, "predicted": em, **sc, "latency": elapsed}
+            if err:   # (additive key: which exception emptied this row -- tools/v1_parity.py tells undecodable audio from engine errors)
+                row["error"] = err
+            per_sample.append(row)
     n = len(per_sample)
     return {
         "name": exp["name"] if mode == "full" else f"{exp['name']} (stream {chunk_seconds:.0f}s)",

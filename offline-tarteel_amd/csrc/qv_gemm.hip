@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
                 int grow = m0 + wm * 64 + i * 32 + l31;
                 grow = grow < g.M ? grow : g.M - 1;
                 bool valid;
-                const QParam p = dql_param(g.mm_in + 2 * row_owner(grow, valid));
+                const QParam p = dql_param(g.mm_in + QV_MM_STRIDE * row_owner(grow, valid));
                 srow[i] = p.scale * g.w_scale;
                 zc[i] = 128 - (int)p.zp;
             }
@@ -452,12 +452,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int rl = wm * 64 + i * 32 + l31;
-                        f32x4 o;
+                        f32x4 o, av, gv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float av = (float)(acc[i][0][q * 4 + e] + zc[i] * wa[e]) * srow[i] + ba[e];
-                            const float gv = (float)(acc[i][NF - 1][q * 4 + e] + zc[i] * wg[e]) * srow[i] + bg[e];
-                            o[e] = av * (1.0f / (1.0f + expf(-gv)));
+                            av[e] = (float)(acc[i][0][q * 4 + e] + zc[i] * wa[e]) * srow[i] + ba[e];
+                            gv[e] = (float)(acc[i][NF - 1][q * 4 + e] + zc[i] * wg[e]) * srow[i] + bg[e];
+                        }
+                        const f32x4 sg = sigmoid4(gv);   // (v_exp_f32 / v_rcp_f32: a few 1e-7 relative, like any libm's expf)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = av[e] * sg[e];
                             mn[i] = fminf(mn[i], o[e]);
                             mx[i] = fmaxf(mx[i], o[e]);
                         }
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm(GemmArgs g) {
             if (tid < BM && sU[tid] >= 0 && (tid == 0 || sU[tid - 1] != sU[tid])) {
                 uint32_t kn = sMM[2 * tid], kx = sMM[2 * tid + 1];
                 for (int k = tid + 1; k < BM && sU[k] == sU[tid]; ++k) { kn = min(kn, sMM[2 * k]); kx = max(kx, sMM[2 * k + 1]); }
-                mm_fold_keys(g.mm_out + 2 * sU[tid], kn, kx);
+                mm_fold_keys(g.mm_out + QV_MM_STRIDE * sU[tid], kn, kx);
             }
         }
         // the output descriptor is rebased on this tile's first row: the dense subsampling tensors have millions of rows

@@ -235,7 +235,7 @@ struct QvActs {
     // QV_PREC_ORT_MIXED: the float32 tensors in front of the quantisers, the s8 operand buffer, the range keys
     float *c1f, *c1pf, *c2f, *gluf, *dwf;
     int8_t *q8;
-    uint32_t *mm;        // [MM_SITES][max_batch][2]
+    uint32_t *mm;        // [MM_SITES][max_batch][QV_MM_STRIDE]: {min, max} keys at the front of each utterance's slot
     float *tap_lnc, *tap_glu, *tap_dw;   // [N_LAYERS][M][512] each when save_taps
 };
 
@@ -656,7 +656,7 @@ int alloc_context(qv_engine *eng, QvModel *m, int k, bool sub_unfused) {
         TRY(dal(eng, m, M * QV_D, &m->gluf));
         TRY(dal(eng, m, M * QV_D, &m->dwf));
         TRY(dal(eng, m, std::max(Bz * m->t2_cap * 20 * QV_SUBC, M * QV_D), &m->q8));
-        TRY(dal(eng, m, (size_t)MM_SITES * Bz * 2, &m->mm));
+        TRY(dal(eng, m, (size_t)MM_SITES * Bz * QV_MM_STRIDE, &m->mm));
         if (m->save_taps) {
             TRY(dal(eng, m, (size_t)N_LAYERS * M * QV_D, &m->tap_lnc));
             TRY(dal(eng, m, (size_t)N_LAYERS * M * QV_D, &m->tap_glu));
@@ -694,6 +694,17 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     m->t3_cap = stage_len(m->t2_cap);
     size_t Bz = (size_t)B, M = Bz * m->t3_cap;
     int t_pad_cap = (m->t3_cap + 31) / 32 * 32;
+    {
+        // the GEMM kernels address their operands through buffer descriptors with a 32-bit size and 32-bit byte offsets:
+        // refuse capacities where the largest operand (the first subsampling activation, the 2560-wide projection input,
+        // the FFN hidden layer, the padded logits) would not fit, instead of wrapping around silently
+        const size_t worst = std::max(std::max(Bz * m->t2_cap * 20 * QV_SUBC * 2, M * 2560 * 2), std::max(M * QV_FF * 2, M * HEAD_N * 4));
+        if (worst >= (1ull << 31)) {
+            qv_set_error(eng, "max_batch x max_samples too large: a GEMM operand would exceed the 2 GiB one buffer descriptor addresses "
+                              "(reduce max_batch or max_samples; e.g. 256 x 30 s fits, 2048 x 10 s does not -- shard across engines)");
+            return QV_ERR_CAPACITY;
+        }
+    }
     const char *tp = getenv("QVERSE_DEBUG_TAPS");
     m->save_taps = tp && tp[0] == '1';
     m->n_ctx = eng->n_ctx;
@@ -771,11 +782,11 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     constexpr int skip = 0, dup = 0;
 #endif
     uint32_t *mm_base = m->mm;
-    auto mm_site = [&](int site) { return mm_base + (size_t)site * MB * 2; };
+    auto mm_site = [&](int site) { return mm_base + (size_t)site * MB * QV_MM_STRIDE; };
     if (m->ort) {
         // QV_PREC_ORT_MIXED front-end: every Conv is DynamicQuantizeLinear -> ConvInteger (qv_ort.h); the strided /
         // depthwise ones as exact integer stencils, the two pointwise ones on the i8 MFMA
-        launch_mm_init(m->mm, (size_t)MM_SITES * MB * 2, s);
+        launch_mm_init(m->mm, (size_t)MM_SITES * MB * QV_MM_STRIDE, s);
         launch_logmel(audio, n_max, d_n, m->ft, m->feats, tm_max, m->mel_stats, B, s);
         launch_mel_minmax(m->feats, d_n, tm_max, m->mel_stats, mm_site(MM_MEL), B, s);
         for (int pass = 0; pass < 2; ++pass)
@@ -856,7 +867,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         // conv module
         if (m->ort) {
             // norm_conv -> [DQL] pointwise_conv1 + GLU -> [DQL] depthwise_conv -> BatchNorm -> Swish -> [DQL] pointwise_conv2
-            uint32_t *mm_ln = mm_site(MM_LAYER(l)), *mm_glu = mm_ln + (size_t)MB * 2, *mm_dw = mm_glu + (size_t)MB * 2;
+            uint32_t *mm_ln = mm_site(MM_LAYER(l)), *mm_glu = mm_ln + (size_t)MB * QV_MM_STRIDE, *mm_dw = mm_glu + (size_t)MB * QV_MM_STRIDE;
             const size_t tap_off = (size_t)l * M * QV_D;
             launch_ln_minmax(m->x, L.ln_g[2], L.ln_b[2], M, m->row_map, mm_ln, m->save_taps ? m->tap_lnc + tap_off : nullptr, s);
             launch_ln_quant(m->x, L.ln_g[2], L.ln_b[2], M, m->row_map, mm_ln, m->q8, s);
@@ -949,7 +960,7 @@ static int replay_args(qv_engine *eng, QvModel *m, int which, GemmArgs &a, int &
         // the range it folds into the GLU site is the one the last forward already left there
         a.A = (const half_t *)m->q8; a.W = nullptr; a.Wi8 = L.o_pw1.wq; a.wsum = L.o_pw1.wsum; a.w_scale = L.o_pw1.scale;
         a.out = m->gluf; a.K = QV_D / 2; a.lda = a.ldw = QV_D / 2;
-        a.mm_in = m->mm + (size_t)MM_LAYER(0) * m->max_batch * 2; a.mm_out = (uint32_t *)a.mm_in + (size_t)m->max_batch * 2;
+        a.mm_in = m->mm + (size_t)MM_LAYER(0) * m->max_batch * QV_MM_STRIDE; a.mm_out = (uint32_t *)a.mm_in + (size_t)m->max_batch * QV_MM_STRIDE;
     }
     return QV_OK;
 }

@@ -19,6 +19,10 @@
 #include "qv_kernels.h"
 
 #define QV_MM_INIT 0x80000000u   // fenc(+0.0f)
+// u32 slots per utterance in a site's key array: {min, max} at the front of a 256-byte slot of its own.  Packed two per
+// 8 bytes, the pairs of a whole batch sat in a handful of cache lines and every fold of every block went through the same
+// L2 channel's atomic unit (k_ln_ort: 26 us against 6 for the plain LayerNorm); one slot per utterance spreads them.
+#define QV_MM_STRIDE 64
 
 static __host__ __device__ __forceinline__ uint32_t fenc(float f) {
     uint32_t u = __builtin_bit_cast(uint32_t, f);

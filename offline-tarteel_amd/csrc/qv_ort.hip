@@ -46,7 +46,7 @@ __device__ __forceinline__ void rows_fold(uint32_t *mm_site, const int *s_utt, c
     if (r > 0 && s_utt[r - 1] == s_utt[r]) return;
     float mn = s_mn[r], mx = s_mx[r];
     for (int k = r + 1; k < n_rows && s_utt[k] == s_utt[r]; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); }
-    mm_fold(mm_site + 2 * s_utt[r], mn, mx);
+    mm_fold(mm_site + QV_MM_STRIDE * s_utt[r], mn, mx);
 }
 
 // ------------------------------------------------------------------ quantise ----------
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_quant_rows(const float *__restrict__ x,
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)rows * cpr) return;
     const int row = (int)(idx / cpr), c = (int)(idx - (size_t)row * cpr) << 4;
-    const QParam p = dql_param(mm + 2 * owner_utt(own, row));
+    const QParam p = dql_param(mm + QV_MM_STRIDE * owner_utt(own, row));
     const float *px = x + (size_t)row * C + c;
     f32x4 v[4];
 #pragma unroll
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, con
                 *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
             }
         } else {
-            const QParam p = dql_param(mm + 2 * utt);
+            const QParam p = dql_param(mm + QV_MM_STRIDE * utt);
             uint32_t w[2] = {0, 0};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
     const int T = len[b], c0 = lane * 8;
     if (blockIdx.x * 4 * DWQ_TT >= T) return;   // (whole block)
     const size_t row0 = (size_t)row_off[b];
-    const QParam p = dql_param(mm_in + 2 * b);
+    const QParam p = dql_param(mm_in + QV_MM_STRIDE * b);
     const float sxw = p.scale * w_scale;
     float mn = INFINITY, mx = -INFINITY;
     if (t0 < T) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
         for (int c = 0; c < 8; ++c) {
             const float yv = acc[j][c] * sxw + bs[c];
             const float z = __builtin_fmaf(yv, al[c], be[c]);
-            o[c] = z * (1.0f / (1.0f + expf(-z)));
+            o[c] = z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-(z * 0x1.715476p+0f)));   // Swish on v_exp_f32 / v_rcp_f32
             mn = fminf(mn, o[c]);
             mx = fmaxf(mx, o[c]);
         }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
     }
-    block_fold(mm_out + 2 * b, mn, mx, s_fold);
+    block_fold(mm_out + QV_MM_STRIDE * b, mn, mx, s_fold);
 }
 
 // ------------------------------------------------------------------ front-end ----------
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(320) void k_mel_minmax(const float *__restrict__ fe
         mx = fmaxf(mx, v);
     }
     __shared__ float s_fold[10];
-    block_fold(mm + 2 * b, mn, mx, s_fold);
+    block_fold(mm + QV_MM_STRIDE * b, mn, mx, s_fold);
 }
 
 // conv.0 (Conv2d 1 -> 256, 3x3, s2, p1) + ReLU and conv.2 (depthwise 3x3, s2, p1) as integer convolutions; k_sub01's
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
     if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
     __syncthreads();
-    const QParam pm = dql_param(mm_mel + 2 * b);
+    const QParam pm = dql_param(mm_mel + QV_MM_STRIDE * b);
     const int t1_0 = 2 * t2_0 - 1;         // first conv.0 row of the tile
     const int tm_0 = 2 * t1_0 - 1;         // first mel row
     for (int i = tid; i < SQ_RM * (QV_NMEL + 2); i += 256) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     __syncthreads();
     const float s0 = pm.scale * w0_scale;
     QParam p0 = {1.f, 0.f};
-    if (PASS == 1) p0 = dql_param(mm_c0 + 2 * b);
+    if (PASS == 1) p0 = dql_param(mm_c0 + QV_MM_STRIDE * b);
     float mn = INFINITY, mx = -INFINITY;
     // ---- conv.0 + ReLU (rows outside [0, l1) are the depthwise conv's zero padding)
     for (int p = pl; p < SQ_R1 * 40; p += 32) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
         if (PASS == 1) *(half8 *)&tile[r][f1][c8] = o;
     }
     if (PASS == 0) {
-        block_fold(mm_c0 + 2 * b, mn, mx, s_fold);
+        block_fold(mm_c0 + QV_MM_STRIDE * b, mn, mx, s_fold);
         return;
     }
     load_w(w1q, b1);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
         *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
-    block_fold(mm_c1 + 2 * b, mn, mx, s_fold);
+    block_fold(mm_c1 + QV_MM_STRIDE * b, mn, mx, s_fold);
 }
 
 // conv.5: depthwise Conv2d(256, 3x3, s2, p1) as ConvInteger on the quantised f32 input (channels-last); rows
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ 
     const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
     const int tin = len_in[b];
     const int c0 = (tid & 31) * 8, fl = tid >> 5;
-    const QParam p = dql_param(mm_in + 2 * b);
+    const QParam p = dql_param(mm_in + QV_MM_STRIDE * b);
     const float sxw = p.scale * w_scale;
     float w[9][8], bs[8];
 #pragma unroll
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ 
         *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
-    block_fold(mm_out + 2 * b, mn, mx, s_fold);
+    block_fold(mm_out + QV_MM_STRIDE * b, mn, mx, s_fold);
 }
 
 }  // namespace

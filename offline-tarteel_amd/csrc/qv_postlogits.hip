@@ -1585,7 +1585,11 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
         QV_HIP(hipEventRecord(c.t_copied[slot], stream));
         c.t_pending[slot] = true;
     }
+#ifdef QV_DEV_HOOKS
     static const int skip = [] { const char *e = getenv("QVERSE_SKIP"); return e ? atoi(e) : 0; }();   // dev-only, see qv_model.hip
+#else
+    constexpr int skip = 0;
+#endif
     auto launch_chain = [&]() -> int {
         if (skip & 128) return QV_OK;   // (timing experiments only: no post-logits chain at all)
         hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);

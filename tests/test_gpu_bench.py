@@ -62,3 +62,48 @@ def test_bench_under_torchrun_with_collective_path():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = _line(p.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["batches_in_flight"] == 4
+
+
+_CTX_PROG = r"""
+import os, sys, json, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ.pop("GPU_MAX_HW_QUEUES", None)
+late = sys.argv[1] == "late"
+import torch
+if late:   # a host application that touched HIP before the package could export GPU_MAX_HW_QUEUES
+    torch.zeros(8, device="cuda").sum().item()
+import offline_tarteel_amd
+from offline_tarteel_amd.engine import Engine
+from synth import synth_audio
+eng = Engine(device=0, with_model=True, seed=20260630, max_batch=64, max_samples=160000, contexts=4)
+a = torch.from_numpy(synth_audio(64, 160000, seed=5)).cuda().contiguous()
+lens = [160000] * 64
+best = 0.0
+for rep in range(3):
+    for _ in range(6): eng.predict_batch_async(a, lens)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40): eng.predict_batch_async(a, lens)
+    torch.cuda.synchronize()
+    best = max(best, 64 * 40 / (time.perf_counter() - t0))
+print(json.dumps({"contexts": eng.contexts, "probe": int(eng.lib.qv_probe_concurrent_streams()), "utt_per_s": best}))
+eng.close()
+"""
+
+
+def test_batches_in_flight_do_not_depend_on_who_initialised_hip_first():
+    """GPU_MAX_HW_QUEUES is read once, when HIP initialises.  A host that touched torch.cuda before importing the package
+    runs on the runtime's default (4 hardware queues), where four context streams share queues and lose ~14 %; qv_create
+    measures how many streams really run side by side (qv_probe_concurrent_streams) and falls back to three batches in
+    flight, the best setting there.  The late-initialised process must stay within a few per cent of the normal one."""
+    prog = _CTX_PROG % (str(ROOT), str(ROOT / "tests"))
+    res = {}
+    for mode in ("early", "late"):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        p = subprocess.run([sys.executable, "-c", prog, mode], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    print("[contexts]", res)
+    assert res["early"]["contexts"] == 4 and res["early"]["probe"] == 6, res
+    assert res["late"]["contexts"] == 3 and res["late"]["probe"] < 6, res
+    assert res["late"]["utt_per_s"] >= 0.92 * res["early"]["utt_per_s"], res

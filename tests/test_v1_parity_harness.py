@@ -34,10 +34,19 @@ def test_compare_rows_flags_differences_and_skips(golden_dir):
     assert rep["compared"] == 53 and rep["differing"] == 0 and rep["skipped"] == 0
     run["per_sample"][3]["predicted"][0]["score"] += 0.02            # beyond the slack
     run["per_sample"][5]["predicted"][0]["ayah"] += 1                 # another verse
-    run["per_sample"][7] = {"id": run["per_sample"][7]["id"], "predicted": [], "latency": 0.0}   # runner's error convention
+    # the runner's error convention (empty prediction, latency 0.0): only an undecodable file is excused ...
+    run["per_sample"][7] = {"id": run["per_sample"][7]["id"], "predicted": [], "latency": 0.0,
+                            "error": "ValueError: x.mp3: not a RIFF/WAVE file (no decoder for compressed audio in this environment)"}
+    # ... an engine / capacity error is a row the reference handled and this path did not
+    run["per_sample"][8] = {"id": run["per_sample"][8]["id"], "predicted": [], "latency": 0.0,
+                            "error": "QvError: qv_predict_batch failed (4): audio longer than engine capacity"}
+    run["per_sample"][11] = {"id": run["per_sample"][11]["id"], "predicted": [], "latency": 0.0}   # (no error text: same)
     del run["per_sample"][9]                                          # file absent from the corpus directory
     rep = v1_parity.compare_rows(doc, "c2c-direct-mixed", run, 1e-2)
-    assert rep["differing"] == 2 and rep["skipped"] == 2 and rep["compared"] == 51
+    assert rep["differing"] == 4 and rep["skipped"] == 2 and rep["compared"] == 51
+    by = {r["id"]: r for r in rep["rows"]}
+    assert by[doc["samples"][8]["id"]]["status"] == "DIFFERS" and "capacity" in by[doc["samples"][8]["id"]]["error"]
+    assert by[doc["samples"][7]["id"]]["status"].startswith("skipped (undecodable audio")
 
 
 def test_harness_skips_cleanly_without_weights():
