@@ -168,13 +168,16 @@ int qv_upfirdn(qv_engine *e, const float *x_dev, int64_t n_in, const float *taps
  * blocks the host only when the context it is about to reuse is still busy.  Results are joined
  * per context: */
 int32_t qv_context_count(const qv_engine *e);      /* may be lower than qv_config.n_contexts, see below */
-/* How many of SIX fresh HIP streams (four contexts + the caller's + one for copies) the runtime runs side by side on this
- * device: 6, 3, 2 or 1 (0 = probe failed).  Six one-wave spin kernels on six streams, elapsed time over spin time (~1 ms,
- * cached per process).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the
- * variable ONCE, when HIP initialises; streams sharing a queue serialise.  qv_create() calls this when n_contexts >= 4 and
- * falls back to 3 contexts -- the best measured setting on the default 4 queues -- unless all six ran concurrently, so
+/* How many of FOUR fresh HIP streams -- what a four-context engine is about to create -- the runtime runs side by side on
+ * this device: 4, 2 or 1 (0 = probe failed).  Four one-wave spin kernels on four streams, elapsed time over spin time
+ * (~1 ms, cached per process).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the
+ * variable ONCE, when HIP initialises; streams sharing a queue serialise.  Measured: with 8 queues 7 fresh streams run
+ * concurrently (4 once RCCL holds its own), on the default 4 queues only 3.  qv_create() calls this when n_contexts >= 4
+ * and falls back to 3 contexts -- the best measured setting on the default queues -- unless all four ran concurrently, so
  * that a host which touched HIP before exporting GPU_MAX_HW_QUEUES=8 loses ~2 % instead of ~14 %. */
 int32_t qv_probe_concurrent_streams(void);
+/* dev tool: the probe's raw figure (elapsed time / spin time) for n_streams fresh streams, not cached */
+double qv_debug_probe_rounds(int32_t n_streams);
 int32_t qv_last_context(const qv_engine *e);     /* context used by the most recent async call */
 /* Host-side join: blocks the calling thread until context `ctx`'s last batch has finished (no-op for an idle
  * context).  A device-side join (qv_packed_results_ctx on a stream) parks a wait on an OLDER batch in that stream's
@@ -279,6 +282,14 @@ int qv_profile_replay_kernel(qv_engine *e, int32_t which, char *name_out, int32_
  * the shape allows, -1 = back to the environment (QVERSE_GEMM_T256) / default.  The tile shape never changes
  * a result: both kernels form the same products in the same accumulation order. */
 int qv_debug_gemm_tiles(int32_t mode);
+
+/* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty
+ * transcript, so the headline workload never sees a recitation the text match recognises.  While log-probs are injected,
+ * qv_predict_batch_async() still runs the WHOLE forward pass on the audio it is given, but its post-logits stages read the
+ * caller's tensor (f32[batch, t_max, 1025] in HBM, t_host[b] valid frames; must stay alive and unchanged) instead of the
+ * forward's output -- e.g. verse-shaped log-probs at the v1 corpus' gate pass / fail ratio.  NULL clears the hook.  Results
+ * are then predictions for the INJECTED log-probs; never use it outside measurements. */
+int qv_profile_inject_logprobs(qv_engine *e, const float *logprobs_dev, int32_t t_max, const int32_t *t_host, int32_t batch);
 
 /* Stage timers -- the device-side counterpart of C2C_DIRECT_MIXED_PROFILE (experiments/c2c-direct-mixed/
  * run.py:34,76-81,117-124: forward= decode= build= rerank= per file).  While enabled, every batch brackets

@@ -20,8 +20,11 @@ static std::string g_create_error;
 // streams that share a queue serialise.  An engine with four batches in flight needs a queue per context stream plus the
 // caller's (14.8 k utt/s on 4 queues against 17.3 k on 8, profiles/r02_h_contexts_hwq_sweep.txt), and a host that touched
 // HIP before the variable was set silently gets the default.  Instead of trusting the environment the library measures:
-// six fresh streams (four contexts + the caller's + one for copies) each run a one-wave kernel that spins for a fixed
-// wall-clock time; the elapsed time over the spin time is how many of them shared a queue.
+// four fresh streams -- what an engine with four contexts is about to create; the caller's stream and RCCL's already
+// exist and hold their queues -- each run a one-wave kernel that spins for a fixed
+// wall-clock time; the elapsed time over the spin time is how many of them shared a queue.  Measured
+// (tools/hwq_probe.py, profiles/r03_c_hwq_probe.txt): with GPU_MAX_HW_QUEUES=8 in place 7 fresh streams run side by side in
+// a plain process and 4 after RCCL has created its own; on the default 4 queues only 3 do.
 namespace {
 __global__ void k_spin(long long ticks) {   // wall_clock64: 100 MHz
     const long long t0 = wall_clock64();
@@ -29,30 +32,37 @@ __global__ void k_spin(long long ticks) {   // wall_clock64: 100 MHz
 }
 }  // namespace
 
-#define QV_PROBE_STREAMS 6
-extern "C" int32_t qv_probe_concurrent_streams(void) {
-    static int cached = 0;
-    if (cached) return cached;
-    constexpr int NS = QV_PROBE_STREAMS;
+#define QV_PROBE_STREAMS 4
+// rounds = elapsed / spin time of `ns` spin kernels on `ns` fresh streams: 1 = all side by side
+static double probe_rounds(int ns) {
     constexpr long long SPIN_TICKS = 40000;   // 400 us
-    hipStream_t st[NS] = {};
-    for (int i = 0; i < NS; ++i)
-        if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) return 0;
-    for (int i = 0; i < NS; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], 1LL);   // warm-up: queue creation, code load
-    for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(st[i]);
+    std::vector<hipStream_t> st(ns, nullptr);
+    for (int i = 0; i < ns; ++i)
+        if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) return 0.0;
+    for (int i = 0; i < ns; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], 1LL);   // warm-up: queue creation, code load
+    for (int i = 0; i < ns; ++i) (void)hipStreamSynchronize(st[i]);
     double best = 1e30;
     for (int rep = 0; rep < 2; ++rep) {
         const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < NS; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], SPIN_TICKS);
-        for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(st[i]);
+        for (int i = 0; i < ns; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], SPIN_TICKS);
+        for (int i = 0; i < ns; ++i) (void)hipStreamSynchronize(st[i]);
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
-    for (int i = 0; i < NS; ++i) (void)hipStreamDestroy(st[i]);
-    // kernels that ran one after the other on the busiest queue: 1 = all six side by side
-    const double rounds = best / (SPIN_TICKS / 100.0);
-    cached = rounds < 1.5 ? NS : rounds < 2.5 ? NS / 2 : rounds < 4.5 ? 2 : 1;
+    for (int i = 0; i < ns; ++i) (void)hipStreamDestroy(st[i]);
+    return best / (SPIN_TICKS / 100.0);
+}
+
+extern "C" int32_t qv_probe_concurrent_streams(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    const double rounds = probe_rounds(QV_PROBE_STREAMS);
+    if (rounds == 0.0) return 0;
+    cached = rounds < 1.5 ? QV_PROBE_STREAMS : rounds < 2.5 ? QV_PROBE_STREAMS / 2 : 1;
     return cached;
 }
+
+// dev tool (tools/hwq_probe.py): the raw figure for any number of streams, not cached
+extern "C" double qv_debug_probe_rounds(int32_t n_streams) { return n_streams >= 1 && n_streams <= 32 ? probe_rounds(n_streams) : 0.0; }
 
 void qv_set_error(qv_engine *e, const std::string &msg) {
     if (e) e->last_error = msg;
@@ -380,7 +390,9 @@ static int alloc_work(qv_engine *eng, int k) {
     QV_TRY(dalloc(eng, Bz * N, &w.cand1));
     QV_TRY(dalloc(eng, Bz * N * 3, &w.lcsf));
     QV_TRY(dalloc(eng, Bz * N * 3, &w.fs));
-    QV_TRY(dalloc(eng, Bz * N, &w.p3));
+    QV_TRY(dalloc(eng, Bz * N, &w.lcs_p3));
+    QV_TRY(dalloc(eng, Bz * N * 3, &w.frag_list));
+    QV_TRY(dalloc(eng, (size_t)2, &w.frag_ctr));
     w.search_sc = nullptr;
     QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.runner_idx));
     QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.runner_score));
@@ -452,6 +464,8 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     eng->n_ctx = cfg->n_contexts < 1 ? 1 : cfg->n_contexts;
     eng->cur_ctx = eng->next_ctx = 0;
     eng->profile_stages = false;
+    eng->inject_lp = nullptr;
+    eng->inject_tmax = eng->inject_batch = 0;
     for (QvCtx &c : eng->ctx) {
         c = QvCtx();
         c.t_host_scratch = nullptr;
@@ -557,6 +571,17 @@ void qv_stage_mark(qv_engine *eng, int i, hipStream_t s) {
     if (hipEventRecord(c.stage_ev[i], s) == hipSuccess && i == 4) c.stage_valid = true;
 }
 
+extern "C" int qv_profile_inject_logprobs(qv_engine *eng, const float *logprobs_dev, int32_t t_max, const int32_t *t_host, int32_t batch) {
+    if (!eng) return QV_ERR_ARG;
+    if (!logprobs_dev) { eng->inject_lp = nullptr; eng->inject_batch = 0; return QV_OK; }
+    if (!t_host || batch < 1 || t_max < 1 || t_max > eng->work.t_cap) { qv_set_error(eng, "qv_profile_inject_logprobs: bad shape"); return QV_ERR_ARG; }
+    eng->inject_t.assign(t_host, t_host + batch);
+    eng->inject_lp = logprobs_dev;
+    eng->inject_tmax = t_max;
+    eng->inject_batch = batch;
+    return QV_OK;
+}
+
 extern "C" int qv_profile_stages(qv_engine *eng, int32_t enable) {
     if (!eng) return QV_ERR_ARG;
     if (enable)
@@ -632,6 +657,10 @@ extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, co
                               t_out.data(), run);
     if (rc) return rc;
     qv_stage_mark(eng, 1, run);
+    if (eng->inject_lp) {
+        if (batch > eng->inject_batch) { qv_set_error(eng, "injected log-probs hold fewer utterances than the batch"); return QV_ERR_ARG; }
+        rc = qv_post_run(eng, eng->inject_lp, eng->inject_tmax, eng->inject_t.data(), batch, run);
+    } else
     rc = qv_post_run(eng, eng->logprobs_ws, t_max, t_out.data(), batch, run);
     if (rc) return rc;
     if (eng->n_ctx > 1) {

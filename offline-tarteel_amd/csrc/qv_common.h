@@ -127,7 +127,9 @@ struct QvWork {
     int32_t *cand1;          // [B][N]
     int16_t *lcsf;           // [B][N][3] full-string LCS(transcript, text) (clean, alt, nobsm)
     double *fs;              // [B][N][3] fragment scores (clean, alt, nobsm)
-    double *p3;              // [B][N]   pass-3 score
+    int16_t *lcs_p3;         // [B][N]   pass 3: LCS(spaceless transcript, clean text) (k_lcs_full mode 1)
+    uint32_t *frag_list;     // [B * N * 3] texts whose fragment score needs the window scan: utterance << 15 | verse << 2 | variant
+    int32_t *frag_ctr;       // [2] entries in frag_list; work-stealing cursor of k_frag
     double *search_sc;       // [B][N]   search score (max over clean/alt)
     int32_t *runner_idx;     // [B][QV_RUNNER_CAP]
     double *runner_score;    // [B][QV_RUNNER_CAP]
@@ -246,6 +248,11 @@ struct qv_engine {
     std::vector<Fir> firs;
     QvTrack track;
     bool profile_stages;
+    // measurement hook (qv_profile_inject_logprobs): caller-owned log-probs the post-logits stages of
+    // qv_predict_batch_async() read INSTEAD of the forward's own output (the forward still runs in full)
+    const float *inject_lp;
+    int inject_tmax, inject_batch;
+    std::vector<int32_t> inject_t;
     // host copies of small table parts used by debug/entry code
     std::vector<uint8_t> h_surah;
     std::vector<uint16_t> h_ayah;

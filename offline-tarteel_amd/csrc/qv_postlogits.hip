@@ -198,8 +198,12 @@ __device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int str
     // and codes outside the alphabet get an all-zero mask, which leaves V unchanged.
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
     constexpr int CH = W <= 4 ? 8 : (W <= 8 ? 4 : 2);
+    // ... and the NEXT 8 codes are requested before this chunk's steps run: the lane's chain used to start every chunk
+    // with an exposed global-load latency, and a kernel lasts as long as its longest text (1,100+ codes = 140 chunks)
+    uint64_t next = n > 0 ? *(const u64_unaligned *)text : 0ull;
     for (int j0 = 0; j0 < n; j0 += 8) {
-        uint64_t chunk = *(const u64_unaligned *)(text + j0);
+        const uint64_t chunk = next;
+        if (j0 + 8 < n) next = *(const u64_unaligned *)(text + j0 + 8);
         const int cnt = n - j0 < 8 ? n - j0 : 8;
 #pragma unroll
         for (int g0 = 0; g0 < 8; g0 += CH) {
@@ -265,39 +269,54 @@ __device__ __forceinline__ void load_pm_lds(uint64_t *spm, const uint64_t *gpm) 
     __syncthreads();
 }
 
-// ------------------------------------------------------------------ 1. argmax ----------
-// one wave per frame; numpy argmax semantics (first maximum).
-__global__ __launch_bounds__(64) void k_argmax(const float *__restrict__ lp, int t_max, const QvUtt *__restrict__ utt,
-                                               int16_t *__restrict__ frame_ids, int t_cap) {
-    int b = blockIdx.y, t = blockIdx.x;
-    if (t >= utt[b].t_frames) return;
-    const float *row = lp + ((size_t)b * t_max + t) * QV_VOCAB;
-    int lane = threadIdx.x;
-    float best = row[lane];
-    int bi = lane;
-    for (int v = lane + 64; v < QV_VOCAB; v += 64) {
-        float x = row[v];
-        if (x > best) { best = x; bi = v; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float b2 = __shfl_xor(best, o);
-        int i2 = __shfl_xor(bi, o);
-        if (b2 > best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
-    }
-    if (lane == 0) frame_ids[(size_t)b * t_cap + t] = (int16_t)bi;
-}
+// ------------------------------------------------------------------ 1. argmax + decode --
+// One 1024-thread block per utterance (three launches in the first version: reset, argmax per frame, decode):
+//   all sixteen waves: per-frame argmax with numpy semantics (first maximum), frame ids kept in LDS;
+//   wave 0 alone:   CTC collapse, piece expansion into normalised codes, whitespace collapse + strip, spaceless copy,
+//                   match masks (c2c-direct/run.py:187-204, shared/normalizer.py) -- a serial, 64-lane job.
+// Within that single wave the LDS / global hand-offs between lanes only need the wave's own memory operations to have
+// completed (QV_WSYNC: workgroup-scope release / acquire fences around a wave barrier), not a block barrier.
+#define QV_WSYNC()                                                  \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
+    } while (0)
+#define QV_TCAP 770   // >= t_cap of any engine (qv_create refuses more than 768 + 2 frames)
 
-// ------------------------------------------------------------------ 2. decode ----------
-// one wave per utterance: collapse, expand pieces into normalised codes, collapse
-// whitespace + strip, spaceless copy, match masks.
-__global__ __launch_bounds__(64) void k_decode(QvTables tab, QvWork wk) {
+#define DEC_WAVES 16
+__global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(QvTables tab, QvWork wk, const float *__restrict__ lp, int t_max,
+                                                          const int32_t *__restrict__ t_dev) {
     __shared__ uint8_t raw[QV_RAW_CAP];
     __shared__ unsigned long long pm[2][QV_NSYM][QV_MAXW];
-    int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int16_t s_fid[QV_TCAP];
+    __shared__ int32_t s_tok[QV_TCAP];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (b == 0 && tid == 0) { *wk.n_fail = 0; wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
     QvUtt &u = wk.utt[b];
-    int T = u.t_frames;
-    const int16_t *fid = wk.frame_ids + (size_t)b * wk.t_cap;
+    const int T = t_dev[b];
+    // a wave takes every 16th frame; the 17 loads of a row are all requested before the first comparison (a frame's
+    // argmax is one memory latency, not seventeen)
+    for (int t = wave; t < T; t += DEC_WAVES) {
+        const float *row = lp + ((size_t)b * t_max + t) * QV_VOCAB;
+        float x[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) x[i] = lane + 64 * i < QV_VOCAB ? row[lane + 64 * i] : -INFINITY;
+        float best = x[0];
+        int bi = lane;
+#pragma unroll
+        for (int i = 1; i < 17; ++i)
+            if (x[i] > best) { best = x[i]; bi = lane + 64 * i; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float b2 = __shfl_xor(best, o);
+            int i2 = __shfl_xor(bi, o);
+            if (b2 > best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+        }
+        if (lane == 0) s_fid[t] = (int16_t)bi;
+    }
+    __syncthreads();
+    if (wave != 0) return;
     int32_t *greedy = wk.greedy + (size_t)b * wk.t_cap;
     int n_tok = 0;
     for (int base = 0; base < T; base += 64) {
@@ -305,22 +324,22 @@ __global__ __launch_bounds__(64) void k_decode(QvTables tab, QvWork wk) {
         int id = -1;
         bool keep = false;
         if (t < T) {
-            id = fid[t];
-            int prev = t > 0 ? fid[t - 1] : -1;
+            id = s_fid[t];
+            int prev = t > 0 ? s_fid[t - 1] : -1;
             keep = id != prev && id != QV_BLANK;
         }
         int tot, r = wave_rank(keep, lane, tot);
-        if (keep) greedy[n_tok + r] = id;
+        if (keep) { s_tok[n_tok + r] = id; greedy[n_tok + r] = id; }
         n_tok += tot;
     }
     for (int t = n_tok + lane; t < wk.t_cap; t += 64) greedy[t] = -1;
-    __syncthreads();
+    QV_WSYNC();
     // piece expansion
     int n_raw = 0;
     bool trunc = false;
     for (int base = 0; base < n_tok; base += 64) {
         int k = base + lane;
-        int id = k < n_tok ? greedy[k] : -1;
+        int id = k < n_tok ? s_tok[k] : -1;
         int len = id >= 0 ? (int)(tab.piece_off[id + 1] - tab.piece_off[id]) : 0;
         int incl = len;
 #pragma unroll
@@ -336,22 +355,33 @@ __global__ __launch_bounds__(64) void k_decode(QvTables tab, QvWork wk) {
     }
     trunc = __any(trunc);
     if (n_raw > QV_RAW_CAP) n_raw = QV_RAW_CAP;
-    __syncthreads();
+    QV_WSYNC();
     int last_ns = -1;
     for (int i = lane; i < n_raw; i += 64)
         if (raw[i] != 0) last_ns = i;
     last_ns = wave_max_i(last_ns);
     uint8_t *q = wk.q + (size_t)b * QV_MAXQ, *qs = wk.qs + (size_t)b * QV_MAXQ;
+    // the collapsed codes go to HBM (every later kernel reads them there) and, for the match masks below, stay in
+    // registers of the lane that produced them
+    unsigned long long *pmf = &pm[0][0][0];
+    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) pmf[i] = 0ull;
+    QV_WSYNC();
     int qn = 0, qsn = 0, spaces = 0;
     for (int base = 0; base < n_raw; base += 64) {
         int i = base + lane;
         int c = i < n_raw ? raw[i] : 0;
         bool keep = i < n_raw && (c != 0 ? true : (i > 0 && raw[i - 1] != 0 && i < last_ns));
         int tot, r = wave_rank(keep, lane, tot);
-        if (keep && qn + r < QV_MAXQ) q[qn + r] = (uint8_t)c;
+        if (keep && qn + r < QV_MAXQ) {
+            q[qn + r] = (uint8_t)c;
+            if (c < QV_NSYM) atomicOr(&pm[0][c][(qn + r) >> 6], 1ull << ((qn + r) & 63));
+        }
         bool ks = keep && c != 0;
         int tots, rs = wave_rank(ks, lane, tots);
-        if (ks && qsn + rs < QV_MAXQ) qs[qsn + rs] = (uint8_t)c;
+        if (ks && qsn + rs < QV_MAXQ) {
+            qs[qsn + rs] = (uint8_t)c;
+            if (c < QV_NSYM) atomicOr(&pm[1][c][(qsn + rs) >> 6], 1ull << ((qsn + rs) & 63));
+        }
         spaces += tot - tots;
         qn += tot;
         qsn += tots;
@@ -360,22 +390,11 @@ __global__ __launch_bounds__(64) void k_decode(QvTables tab, QvWork wk) {
     int flags = 0;
     if (trunc) { flags |= QV_FLAG_TRANSCRIPT_TRUNCATED; qn = 0; qsn = 0; }
     else if (qn == 0) flags |= QV_FLAG_EMPTY_TRANSCRIPT;
-    // match masks
-    unsigned long long *pmf = &pm[0][0][0];
-    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) pmf[i] = 0ull;
-    __syncthreads();
-    for (int i = lane; i < qn; i += 64) {
-        int c = q[i];
-        if (c < QV_NSYM) atomicOr(&pm[0][c][i >> 6], 1ull << (i & 63));
-    }
-    for (int i = lane; i < qsn; i += 64) {
-        int c = qs[i];
-        if (c < QV_NSYM) atomicOr(&pm[1][c][i >> 6], 1ull << (i & 63));
-    }
-    __syncthreads();
+    QV_WSYNC();
     uint64_t *gpm = wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW;
-    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) gpm[i] = pmf[i];
+    for (int i = lane; i < 2 * QV_NSYM * QV_MAXW; i += 64) gpm[i] = trunc ? 0ull : pmf[i];
     if (lane == 0) {
+        u.t_frames = T;
         u.n_tok = n_tok;
         u.q_len = qn;
         u.qs_len = qsn;
@@ -625,6 +644,7 @@ __device__ __forceinline__ TextRef text_of(const QvTables &tab, int v, int varia
 #define FRAG_STEP 4          // anchor spacing of the coarse pass (power of two, >= 4)
 #endif
 #define FRAG_SCRATCH 2112      // int16 per wave: anchors [QV_MAXQ / 4 + 2] + refine list [QV_MAXQ]
+#define FRAG_GRID 1024         // blocks of k_frag (4 waves each): four per CU, the list is consumed by whoever is free
 __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane, int16_t *scratch) {
     const QvUtt &u = wk.utt[b];
     double *out = wk.fs + ((size_t)b * tab.n_verses + v) * 3 + variant;
@@ -726,71 +746,108 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
     }
 }
 
-// full-string LCS(transcript, text), one text per lane, pattern = the transcript's match masks.
-// mode 0: the texts of the pass-1 iteration list; mode 1: clean + alt of every verse for the
-// slow-list utterances (skipped when pass 1 already scanned everything).
+// full-string LCS(transcript, text), one text per lane, pattern = the transcript's match masks, AND everything
+// _fragment_score decides before it looks at a single window (quran_db.py:211-237): the word-boundary substring test,
+// "fewer than 4 query words / fewer than 2 verse words", and the exact bound "no window can lift the blend above the
+// full-string ratio" (frag_job's comment).  Nine texts in ten are final here, one text per LANE; only the rest go on the
+// fragment work list that k_frag's waves consume (one text per WAVE, lanes = windows).  The first version ran one wave
+// per text for all of them: 64 lanes repeating the same scalar decision for 12,472 texts per gate-failed utterance.
+// mode 0: the texts of the pass-1 iteration list; mode 1 (slow-list utterances): clean + alt of every verse for search()
+// (skipped when pass 1 already scanned everything) and, as a third job per verse, pass 3's LCS of the spaceless
+// transcript against the clean text (c2c-direct/run.py:284-297; a space matches nothing in the spaceless pattern, so
+// the spaced text is streamed).
 __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int mode) {
     int b;
     if (mode == 0) b = blockIdx.y;
     else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
     const QvUtt &u = wk.utt[b];
-    if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
-    const int m = u.q_len, W = (m + 63) >> 6, N = tab.n_verses;
+    if (u.q_len == 0) return;
+    const int m = u.q_len, ms = u.qs_len, W = (m + 63) >> 6, N = tab.n_verses, qw = u.q_words;
     __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     const uint64_t *pm = spm;
     const int32_t *cand1 = wk.cand1 + (size_t)b * N;
     int16_t *out = wk.lcsf + (size_t)b * N * 3;
-    const bool short_q = u.q_words < 4;
+    const bool short_q = qw < 4;
     const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
-    const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 2;
+    const int lane = threadIdx.x & 63;
+    const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 3;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < jobs; j += gridDim.x * 256) {
         int v, variant;
-        if (mode == 0) { v = cand1[j / 3]; variant = j % 3; } else { v = tab.len_order[j >> 1]; variant = j & 1; }  // similar lengths per wave
-        double *fs = wk.fs + ((size_t)b * N + v) * 3 + variant;
-        if (variant == 2 && tab.nobsm_len[v] == 0) { if (short_q) *fs = -1.0; continue; }
-        TextRef t = text_of(tab, v, variant);
-        int l = lcs_dispatch(W, pm, QV_PMS, t.p, t.n, m);
-        out[v * 3 + variant] = (int16_t)l;
-        if (short_q) {
-            // fewer than 4 query words: _fragment_score never looks at windows
-            // (quran_db.py:225-226), so the score is final here and k_frag is skipped
-            double fr = ratio_from(l, m, t.n);
-            if (u.q_words >= 3 && m <= t.n) {
-                bool sub = false;
-                for (int i = 0; i + m <= t.n && !sub; ++i) {
-                    if (i > 0 && t.p[i - 1] != 0) continue;
-                    if (i + m < t.n && t.p[i + m] != 0) continue;
-                    bool ok = true;
-                    for (int k = 0; k < m; ++k)
-                        if (q[k] != t.p[i + k] || q[k] >= QV_NSYM) { ok = false; break; }
-                    sub = ok;
-                }
-                if (sub && fr < 0.98) fr = 0.98;
+        if (mode == 0) { v = cand1[j / 3]; variant = j % 3; }
+        else {
+            v = tab.len_order[j / 3];   // similar lengths per wave
+            variant = j % 3;
+            if (variant == 2) {         // pass 3
+                wk.lcs_p3[(size_t)b * N + v] =
+                    (int16_t)lcs_dispatch((ms + 63) >> 6, spm + QV_NSYM * QV_PMS, QV_PMS, tab.clean + tab.clean_off[v], tab.clean_len[v], ms);
+                continue;
             }
-            *fs = fr;
+            if (u.full_scan) continue;  // search(): pass 1 already scored every verse
+        }
+        double *fs = wk.fs + ((size_t)b * N + v) * 3 + variant;
+        if (variant == 2 && tab.nobsm_len[v] == 0) { *fs = -1.0; continue; }
+        TextRef t = text_of(tab, v, variant);
+        const int l = lcs_dispatch(W, pm, QV_PMS, t.p, t.n, m);
+        out[v * 3 + variant] = (int16_t)l;
+        const int n = t.n, vw = t.nw;
+        const double fr = ratio_from(l, m, n);
+        bool sub = false;   // " text " in " verse "  (word-boundary substring)
+        if (qw >= 3 && m <= n) {
+            for (int i = 0; i + m <= n && !sub; ++i) {
+                if (i > 0 && t.p[i - 1] != 0) continue;
+                if (i + m < n && t.p[i + m] != 0) continue;
+                bool ok = true;
+                for (int k = 0; k < m; ++k)
+                    if (q[k] != t.p[i + k] || q[k] >= QV_NSYM) { ok = false; break; }
+                sub = ok;
+            }
+        }
+        bool need = false;
+        if (sub) *fs = fr > 0.98 ? fr : 0.98;
+        else if (short_q || vw < 2) *fs = fr;                 // no windows below 4 query words / 2 verse words
+        else {
+            const int s = m <= n ? m : n;
+            double pen = __ddiv_rn((double)vw, (double)(qw > 1 ? qw : 1));
+            if (pen > 1.0) pen = 1.0;
+            const int ub = l < s ? l : s;                      // no window beats the full string
+            const double frag = ratio_from(ub, s, s);
+            double bl = fr;
+            if (frag > fr) {
+                const double blended = __dadd_rn(__dmul_rn(0.25, fr), __dmul_rn(__dmul_rn(0.75, frag), pen));
+                bl = fr > blended ? fr : blended;
+            }
+            if (bl == fr) *fs = fr;
+            else need = true;
+        }
+        // wave-aggregated append to the work list
+        const unsigned long long mask = __ballot(need);
+        if (need) {
+            const int leader = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&wk.frag_ctr[0], __popcll(mask));
+            base = __shfl(base, leader);
+            wk.frag_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)b << 15) | ((uint32_t)v << 2) | (uint32_t)variant;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk, int mode) {
+// the window scans: one text per wave, taken off the work list k_lcs_full left.  A wave's first item is its own index;
+// further ones come from a shared cursor, so the waves of a launch that finds few items leave without an atomic and a
+// long text (hundreds of windows of a 16-word pattern) does not hold a fixed share of the list hostage.
+__global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk) {
     __shared__ int16_t frag_scratch[4][FRAG_SCRATCH];
     int16_t *scratch = frag_scratch[threadIdx.x >> 6];
-    int lane = threadIdx.x & 63;
-    int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
-    int b;
-    if (mode == 0) b = blockIdx.y;
-    else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
-    const QvUtt &u = wk.utt[b];
-    if (u.q_len == 0 || (mode == 1 && u.full_scan)) return;
-    if (u.q_words < 4) return;  // scores already final (k_lcs_full): no windows below 4 query words
-    if (mode == 0) {
-        const int32_t *cand1 = wk.cand1 + (size_t)b * tab.n_verses;
-        int jobs = u.n_cand1 * 3;
-        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, cand1[j / 3], j % 3, lane, scratch);
-    } else {
-        int jobs = tab.n_verses * 2;  // search(): clean + alt only (quran_db.py:105-110)
-        for (int j = wave; j < jobs; j += nwave) frag_job(tab, wk, b, j >> 1, j & 1, lane, scratch);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    const int n_items = wk.frag_ctr[0];
+    int idx = wave;
+    while (idx < n_items) {
+        const uint32_t it = wk.frag_list[idx];
+        frag_job(tab, wk, (int)(it >> 15), (int)((it >> 2) & 0x1FFFu), (int)(it & 3u), lane, scratch);
+        int nx = 0;
+        if (lane == 0) nx = atomicAdd(&wk.frag_ctr[1], 1);
+        idx = nwave + __shfl(nx, 0);
     }
 }
 
@@ -896,14 +953,19 @@ __global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, Qv
     if (tid == 0) u.n_runners = K < kn.top_text ? K : kn.top_text;
 }
 
+
 // ------------------------------------------------------------------ 6. span pass -------
 // quran_db.py:334-365: every window of 2..max_span ayat of the surahs of the top 20.  One
 // span text per lane; texts are contiguous slices of the padded clean array.  A span is
 // skipped when even LCS = min(m, n) could not beat the pass-1 best (exact pruning).
+__device__ void base_final_one(const QvTables &tab, const QvWork &wk, const QvKnobs &kn, int b, int force_ctc);
+
 __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs kn) {
     __shared__ double sh_s[8];
     __shared__ unsigned long long sh_k[8];
     int b = blockIdx.y, tid = threadIdx.x;
+    // pass 1's window scans are done, search()'s have not started: empty the fragment work list
+    if (blockIdx.x == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
@@ -959,10 +1021,17 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     }
 }
 
-// base = better of pass-1 best and span best; gate; result for the text branch.
+// (Measured and rejected: folding this -- and the candidate assembly, and the final decision -- into the tail of the
+// kernel in front of it with a "last block done" counter.  Publishing a block's results to a block on another XCD takes an
+// agent-scope release, i.e. an L2 write-back per block on this 8-XCD part: k_spans 23 -> 105 us, k_topk 57 -> 108 us,
+// k_ctc 143 -> 601 us.  A kernel boundary is the cheap device-wide synchronisation here.)
 __global__ void k_base_final(QvTables tab, QvWork wk, QvKnobs kn, int batch, int force_ctc) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
+    if (b < batch) base_final_one(tab, wk, kn, b, force_ctc);
+}
+
+// base = better of pass-1 best and span best; gate; result for the text branch.
+__device__ void base_final_one(const QvTables &tab, const QvWork &wk, const QvKnobs &kn, int b, int force_ctc) {
     QvUtt &u = wk.utt[b];
     if (u.q_len == 0) return;
     double best = -1.0;
@@ -1000,27 +1069,8 @@ __global__ void k_base_final(QvTables tab, QvWork wk, QvKnobs kn, int batch, int
 }
 
 // ------------------------------------------------------------------ 7. pass 3 ----------
-// c2c-direct/run.py:284-297: max(ratio(t, clean), ratio(t.spaceless, clean.spaceless)); a
-// space matches nothing in the spaceless pattern, so the spaced text is streamed for both.
-__global__ __launch_bounds__(256) void k_pass3(QvTables tab, QvWork wk) {
-    if ((int)blockIdx.y >= *wk.n_fail) return;
-    int b = wk.fail_list[blockIdx.y];
-    const QvUtt &u = wk.utt[b];
-    if (u.q_len == 0) return;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
-    load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
-    int slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot >= tab.n_verses) return;
-    int v = tab.len_order[slot];  // lanes of a wave stream texts of similar length
-    int m = u.q_len, ms = u.qs_len;
-    const uint8_t *t = tab.clean + tab.clean_off[v];
-    int n = tab.clean_len[v], ns = n - (tab.nw[0][v] - 1);
-    int l1 = wk.lcsf[((size_t)b * tab.n_verses + v) * 3];  // LCS(t, clean) from k_lcs_full
-    int l2 = lcs_dispatch((ms + 63) >> 6, spm + QV_NSYM * QV_PMS, QV_PMS, t, n, ms);
-    double a = ratio_from(l1, m, n), c = ratio_from(l2, ms, ns);
-    wk.p3[(size_t)b * tab.n_verses + v] = a > c ? a : c;
-}
-
+// c2c-direct/run.py:284-297: max(ratio(t, clean), ratio(t.spaceless, clean.spaceless)).  Both LCS values come from
+// k_lcs_full (lcsf / lcs_p3); the two ratios and their maximum are formed where they are consumed, in k_topk.
 // top-k (score desc, verse index asc) of search() and pass 3
 __global__ __launch_bounds__(256) void k_topk(QvTables tab, QvWork wk, QvKnobs kn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1035,8 +1085,13 @@ __global__ __launch_bounds__(256) void k_topk(QvTables tab, QvWork wk, QvKnobs k
         const double *fs = wk.fs + (size_t)b * N * 3;
         for (int v = tid; v < N; v += 256) { double a = fs[v * 3], c = fs[v * 3 + 1]; sc[v] = a > c ? a : c; }
     } else {
-        const double *p3 = wk.p3 + (size_t)b * N;
-        for (int v = tid; v < N; v += 256) sc[v] = p3[v];
+        const QvUtt &u = wk.utt[b];
+        const int m = u.q_len, ms = u.qs_len;
+        for (int v = tid; v < N; v += 256) {
+            const int n = tab.clean_len[v], ns = n - (tab.nw[0][v] - 1);
+            const double a = ratio_from(wk.lcsf[((size_t)b * N + v) * 3], m, n), c = ratio_from(wk.lcs_p3[(size_t)b * N + v], ms, ns);
+            sc[v] = a > c ? a : c;
+        }
     }
     __syncthreads();
     int K = kn.top_text < QV_RUNNER_CAP ? kn.top_text : QV_RUNNER_CAP;
@@ -1048,6 +1103,7 @@ __global__ __launch_bounds__(256) void k_topk(QvTables tab, QvWork wk, QvKnobs k
     uint32_t *scratch = (uint32_t *)(sel_p + QV_RUNNER_CAP);
     block_topk_select(sc, N, K, scratch, sel_p, sel_s, oi, os);
 }
+
 
 // ------------------------------------------------------------------ 8. candidates ------
 // c2c-direct/run.py:251-311: ordered, de-duplicated union + span expansion of the first
@@ -1069,8 +1125,7 @@ __device__ __forceinline__ double py_round3(double x) {
 // Parallel form of the ordered, de-duplicated union: (1) lay out every proposal in reference
 // order, (2) a hash table keeps the FIRST proposal index of each (start, span) key, (3) an
 // ordered compaction of the proposals that are their key's first occurrence.
-__global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvKnobs kn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ void candidates_block(const QvTables &tab, const QvWork &wk, const QvKnobs &kn, int b, unsigned char *smem) {
     double *pscore = (double *)smem;                       // [CAND_PCAP]
     uint32_t *pkey = (uint32_t *)(pscore + CAND_PCAP);     // [CAND_PCAP]
     uint32_t *htk = pkey + CAND_PCAP;                      // [CAND_HT]
@@ -1078,8 +1133,7 @@ __global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvK
     int32_t *refs = (int32_t *)(hti + CAND_HT);            // [128]
     int32_t *roff = refs + 128;                            // [129]
     int32_t *wsum = roff + 132;                            // [8]: 4 wave sums + the leader counter
-    if ((int)blockIdx.x >= *wk.n_fail) return;
-    const int b = wk.fail_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QvUtt &u = wk.utt[b];
     if (u.q_len == 0) return;
     const int N = tab.n_verses;
@@ -1245,6 +1299,12 @@ __global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvK
     if (tid == 0) u.n_lead = *nlead;
 }
 
+__global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvKnobs kn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= *wk.n_fail) return;
+    candidates_block(tab, wk, kn, wk.fail_list[blockIdx.x], smem);
+}
+
 // ------------------------------------------------------------------ 9. CTC -------------
 // ATen LossCTC.cpp float32 alpha recursion (what F.ctc_loss runs on CPU for the reference,
 // c2c-direct/run.py:354-362).  One wave per target; state s = lane*NS + k.
@@ -1272,7 +1332,10 @@ __device__ void ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__
         if (s == 1) a[k] = lp[tok[k]] * LOG2E;
     }
     // the gathers lp[t][tok] do not depend on the recurrence: fetch TCH frames ahead so their
-    // L2 latency overlaps the exp/log chain instead of serialising with it
+    // L2 latency overlaps the exp/log chain instead of serialising with it.  (Requesting the NEXT group before this
+    // one's steps -- two register sets -- was measured: 70 -> 131 VGPRs, 7 -> 3 waves per SIMD, 144 -> 190 us.  The
+    // kernel has ~200 leader waves per utterance and is bound by how many of them a SIMD interleaves, not by one
+    // wave's latency.)
     constexpr int TCH = NS <= 2 ? 8 : (NS <= 6 ? 4 : 2);
     for (int t0 = 1; t0 < T; t0 += TCH) {
         float lpv[TCH][NS];
@@ -1298,10 +1361,14 @@ __device__ void ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__
                 float la3 = k >= 2 ? a[k - 2] : (k == 1 ? p1 : p2);
                 if (NS == 1) la3 = p2;
                 if (!skip_ok[k]) la3 = NEG;
-                float lamax = fmaxf(la1, fmaxf(la2, la3));
+                // log-sum-exp of three: the largest term is exp2(0) = 1 exactly, so only the other two need the
+                // transcendental unit (the kernel is bound by v_exp_f32 / v_log_f32 issue: 4 -> 3 per state and frame)
+                const float lamax = __builtin_fmaxf(la1, __builtin_fmaxf(la2, la3));
+                const float lamin = __builtin_fminf(la1, __builtin_fminf(la2, la3));
+                const float lamed = __builtin_fmaxf(__builtin_fminf(la1, la2), __builtin_fminf(__builtin_fmaxf(la1, la2), la3));
                 // states beyond 2L never feed a lower state, so they are left unmasked
-                na[k] = __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(la1 - lamax) + __builtin_amdgcn_exp2f(la2 - lamax) +
-                                              __builtin_amdgcn_exp2f(la3 - lamax)) + lamax + lpv[j][k];
+                na[k] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lamed - lamax) + __builtin_amdgcn_exp2f(lamin - lamax)) +
+                        lamax + lpv[j][k];
             }
 #pragma unroll
             for (int k = 0; k < NS; ++k) a[k] = na[k];
@@ -1337,6 +1404,8 @@ __device__ void ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L,
     return ctc_wave<12>(lp, T, tgt, L, lane, sa);
 }
 
+// One wave per LEADER candidate (k_candidates' plan): one alpha recursion, then the loss of the leader and of
+// every candidate whose ids are a prefix of its ids.
 // One wave per LEADER candidate (k_candidates' plan): one alpha recursion, then the loss of the leader and of
 // every candidate whose ids are a prefix of its ids.
 template <bool LONG>
@@ -1448,7 +1517,7 @@ __global__ __launch_bounds__(256) void k_result(QvTables tab, QvWork wk, int bat
 
 __global__ void k_init_utts(QvWork wk, const int32_t *__restrict__ t_dev, int batch) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) *wk.n_fail = 0;
+    if (b == 0) { *wk.n_fail = 0; wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
     if (b < batch) wk.utt[b].t_frames = t_dev[b];
 }
 
@@ -1550,15 +1619,14 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
                     QV_MAXQ * 2 + 8 * 4 + 64;
     hipLaunchKernelGGL(k_trigram, dim3(batch), dim3(256), sm_tri, stream, tab, wk);
     hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 0);
-    hipLaunchKernelGGL(k_frag, dim3(64, batch), dim3(256), 0, stream, tab, wk, 0);
+    hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
     hipLaunchKernelGGL(k_pass1_final, dim3(batch), dim3(256), sm_p1, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_base_final, dim3((batch + 63) / 64), dim3(64), 0, stream, tab, wk, kn, batch, force_ctc);
     // gate-failed utterances only (device-side list; blocks past n_fail exit at once)
-    hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 1);
-    hipLaunchKernelGGL(k_frag, dim3(128, batch), dim3(256), 0, stream, tab, wk, 1);
-    hipLaunchKernelGGL(k_pass3, dim3((N + 255) / 256, batch), dim3(256), 0, stream, tab, wk);
+    hipLaunchKernelGGL(k_lcs_full, dim3(74, batch), dim3(256), 0, stream, tab, wk, 1);   // 3 jobs per verse: one round of 74 x 256 lanes
+    hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     hipLaunchKernelGGL(k_topk, dim3(batch, 2), dim3(256), sm_p1, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_candidates, dim3(batch), dim3(256), (size_t)CAND_PCAP * 12 + CAND_HT * 8 + 1200, stream, tab, wk, kn);
     return QV_OK;
@@ -1592,9 +1660,7 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
 #endif
     auto launch_chain = [&]() -> int {
         if (skip & 128) return QV_OK;   // (timing experiments only: no post-logits chain at all)
-        hipLaunchKernelGGL(k_init_utts, dim3((batch + 63) / 64), dim3(64), 0, stream, wk, eng->t_dev, batch);
-        hipLaunchKernelGGL(k_argmax, dim3(t_max, batch), dim3(64), 0, stream, lp, t_max, wk.utt, wk.frame_ids, wk.t_cap);
-        hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64), 0, stream, tab, wk);
+        hipLaunchKernelGGL(k_decode, dim3(batch), dim3(64 * DEC_WAVES), 0, stream, tab, wk, lp, t_max, eng->t_dev);
         qv_stage_mark(eng, 2, stream);
         int rc = launch_retrieval(eng, batch, 0, stream);
         if (rc) return rc;
@@ -1737,8 +1803,8 @@ int qv_post_match_verse(qv_engine *eng, const uint8_t *codes_host, int n, int n_
     size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + TRI_WORDS * 4 +
                     QV_MAXQ * 2 + 8 * 4 + 64;
     hipLaunchKernelGGL(k_trigram, dim3(1), dim3(256), sm_tri, stream, tab, wk);
-    hipLaunchKernelGGL(k_lcs_full, dim3(32, 1), dim3(256), 0, stream, tab, wk, 0);
-    hipLaunchKernelGGL(k_frag, dim3(256, 1), dim3(256), 0, stream, tab, wk, 0);
+    hipLaunchKernelGGL(k_lcs_full, dim3(74, 1), dim3(256), 0, stream, tab, wk, 0);
+    hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     if (n_bonus > 0) hipLaunchKernelGGL(k_hint_sp, dim3(1), dim3(64), 0, stream, tab, wk, 0);
     size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
     hipLaunchKernelGGL(k_pass1_final, dim3(1), dim3(256), sm_p1, stream, tab, wk, kn);

@@ -123,6 +123,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_replay_gemm.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.qv_profile_replay_kernel.argtypes = [vp, i32, C.c_char_p, i32]
     lib.qv_debug_gemm_tiles.argtypes = [i32]
+    lib.qv_profile_inject_logprobs.argtypes = [vp, vp, i32, vp, i32]
     lib.qv_profile_stages.argtypes = [vp, i32]
     lib.qv_stage_times.argtypes = [vp, i32, vp]
     _lib = lib
@@ -382,6 +383,20 @@ class Engine:
                 out.append({"kernel": f"k_gemm256<{epi}>" if tile == 2 else f"k_gemm<{epi},{128 if tile else 64}>",
                             "ms": float(ms[c]), "flops": float(fl[c]), "launches": int(n[c])})
         return out
+
+    def inject_logprobs(self, log_probs=None, t_frames=None):
+        """measurement hook (qv_profile_inject_logprobs): the post-logits stages of predict_batch_async read this cuda
+        tensor [B, t_max, 1025] instead of the forward's output (the forward still runs); None clears it.  The tensor is
+        kept alive by the engine object."""
+        if log_probs is None:
+            self._injected = None
+            self._check(self.lib.qv_profile_inject_logprobs(self.h, None, 0, None, 0), "qv_profile_inject_logprobs")
+            return
+        assert log_probs.is_cuda and log_probs.dtype == self.torch.float32 and log_probs.is_contiguous() and log_probs.shape[2] == 1025
+        t = np.ascontiguousarray(np.asarray(t_frames, dtype=np.int32))
+        self._injected = log_probs
+        self._check(self.lib.qv_profile_inject_logprobs(self.h, C.c_void_p(log_probs.data_ptr()), log_probs.shape[1],
+                                                        t.ctypes.data_as(C.c_void_p), log_probs.shape[0]), "qv_profile_inject_logprobs")
 
     def profile_stages(self, enable: bool):
         """device-side stage timers (the reference's C2C_DIRECT_MIXED_PROFILE split, mixed/run.py:117-124)"""

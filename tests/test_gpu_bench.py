@@ -104,6 +104,6 @@ def test_batches_in_flight_do_not_depend_on_who_initialised_hip_first():
         assert p.returncode == 0, p.stderr[-2000:]
         res[mode] = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
     print("[contexts]", res)
-    assert res["early"]["contexts"] == 4 and res["early"]["probe"] == 6, res
-    assert res["late"]["contexts"] == 3 and res["late"]["probe"] < 6, res
+    assert res["early"]["contexts"] == 4 and res["early"]["probe"] == 4, res
+    assert res["late"]["contexts"] == 3 and res["late"]["probe"] < 4, res
     assert res["late"]["utt_per_s"] >= 0.92 * res["early"]["utt_per_s"], res
