@@ -507,34 +507,44 @@ def main():
     # event/launch gap of each launch, so it reads lower).
     roof = None
     if rank == 0:
-        rep = eng.replay_gemm(0, iters=100)
+        # Dominant kernel by time in rocprofv3's table of this very command (profiles/r0*_kernel_stats.csv): the
+        # RESIDUAL-epilogue GEMM class -- FFN-down [M,2048]x[2048,512] (2 per layer) and the attention out-projection /
+        # second pointwise convolution [M,512]x[512,512] (1 + 1 per layer), one kernel name, 68 launches per step.  It is
+        # timed live with HIP events on the launch stream over back-to-back replays of both shapes on the engine's own
+        # buffers (alpha = 0: the residual stream is left alone) and reported launch-weighted, as rocprofv3 averages it.
+        # The FFN-up GEMM ([M,512]x[512,2048] + Swish, the single shape with the most FLOPs) is kept next to it, and the
+        # in-situ, per-launch event timing of EVERY GEMM class of a few full steps (that one includes the event / launch
+        # gap of each launch, so it reads lower).
+        n_cu = 256
+        r_dn, r_out, rep = eng.replay_gemm(1, iters=60), eng.replay_gemm(3, iters=60), eng.replay_gemm(0, iters=100)
+        cls_flops = 34 * r_dn["flops"] + 34 * r_out["flops"]
+        cls_us = 34 * r_dn["avg_us"] + 34 * r_out["avg_us"]
+        ach_cls = cls_flops / (cls_us * 1e-6) / 1e12
         ach = rep["flops"] / (rep["avg_us"] * 1e-6) / 1e12
-        # HBM traffic of that kernel is NOT measured in this run (PMC counters need rocprofv3): it is quoted
-        # from the newest committed counter summary, and only for the shape that summary was taken at
-        traffic, traffic_source = None, None
-        try:
-            pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
-            doc = json.loads(pmc_file.read_text())
-            if int(doc.get("rows", 8064)) == rows_per_launch and args.precision == "fp16":
-                traffic = doc["kernels"].get(rep["kernel"], {}).get("hbm_bytes_per_launch")
-                traffic_source = (f"profiles/{pmc_file.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                                  f"tools/gemm_bench, same kernel and shape (M = {rows_per_launch}), not collected in this run")
-            else:
-                traffic_source = f"no committed counter summary for M = {rows_per_launch}, weights {args.precision}"
-        except Exception:
-            pass
-        # MFMA utilisation inside the kernel from the committed SQ counter pass (clock-independent: matrix-pipe
-        # busy cycles / SIMD cycles the kernel lasted); likewise quoted, not measured here
-        mfma_util, mfma_source = None, None
-        try:
-            mf = sorted((ROOT / "profiles").glob("r*_mfma_busy.json"))[-1]
-            doc = json.loads(mf.read_text())
-            if int(doc.get("rows", 0)) == rows_per_launch and args.precision == "fp16":
-                mfma_util = doc["kernels"].get(rep["kernel"], {}).get("mfma_util")
-                mfma_source = (f"profiles/{mf.name}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32) over "
-                               f"tools/gemm_bench at M = {rows_per_launch}, not collected in this run")
-        except Exception:
-            pass
+
+        def tiles_of(r, n_cols):   # blocks of that launch: 256 x 256 tiles or 128 x 128 / 128 x 64 ones
+            if r["kernel"].startswith("k_gemm256"):
+                return ((rows_per_launch + 255) // 256) * (n_cols // 256)
+            bn = 64 if ",64" in r["kernel"] else 128
+            return ((rows_per_launch + 127) // 128) * (n_cols // bn)
+
+        cus_dn = min(n_cu, tiles_of(r_dn, 512))
+        # HBM traffic / MFMA utilisation are NOT measured in this run (PMC counters need rocprofv3): they are quoted from
+        # the newest committed counter summary, and only for the kernel and shape that summary was taken at
+        def quoted(pattern, key, kernel):
+            try:
+                f = sorted((ROOT / "profiles").glob(pattern))[-1]
+                doc = json.loads(f.read_text())
+                if int(doc.get("rows", 0)) == rows_per_launch and args.precision == "fp16":
+                    return doc["kernels"].get(kernel, {}).get(key), f"profiles/{f.name} (rocprofv3 --pmc over tools/gemm_bench, same kernel, M = {rows_per_launch}; not collected in this run)"
+                return None, f"no committed counter summary for M = {rows_per_launch}, weights {args.precision}"
+            except Exception:
+                return None, None
+
+        traffic, traffic_source = quoted("r*_pmc_traffic.json", "hbm_bytes_per_launch", r_dn["kernel"])
+        mfma_util, mfma_source = quoted("r*_mfma_busy.json", "mfma_util", r_dn["kernel"])
+        up_traffic, _ = quoted("r*_pmc_traffic.json", "hbm_bytes_per_launch", rep["kernel"])
+        up_util, _ = quoted("r*_mfma_busy.json", "mfma_util", rep["kernel"])
         eng.profile_gemm(True)
         nprof = max(2, min(args.steps, 5))
         for _ in range(nprof):
@@ -543,19 +553,33 @@ def main():
         classes = eng.profile_gemm_read()
         eng.profile_gemm(False)
         gemm_ms = sum(c["ms"] for c in classes)
+        tf = lambda r: round(r["flops"] / (r["avg_us"] * 1e-6) / 1e12, 1)  # noqa: E731
         roof = {
-            "bound": "mfma", "kernel": rep["kernel"], "shape": rep["shape"], "achieved": round(ach, 2),
-            "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "mfma_util_pmc": mfma_util, "mfma_util_source": mfma_source,
-            "flops_per_launch": rep["flops"], "avg_launch_us": round(rep["avg_us"], 2), "launches": rep["launches"],
+            "bound": "mfma", "kernel": r_dn["kernel"],
+            "shape": "residual-epilogue GEMMs, launch-weighted as in the kernel table: 34 x FFN-down [M,2048]x[2048,512] + 34 x "
+                     "attention-out / pointwise-conv-2 [M,512]x[512,512] per step",
+            "achieved": round(ach_cls, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_cls / PEAK_F16_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": traffic_source, "mfma_util_pmc": mfma_util, "mfma_util_source": mfma_source,
+            "flops_per_launch": cls_flops / 68, "avg_launch_us": round(cls_us / 68, 2), "launches": 120,
+            "members": {"ffn_down": {"kernel": r_dn["kernel"], "tflops": tf(r_dn), "avg_launch_us": round(r_dn["avg_us"], 2),
+                                     "blocks": tiles_of(r_dn, 512), "cus_occupied": cus_dn,
+                                     "frac_of_occupied_cus_peak": round(tf(r_dn) / (PEAK_F16_TFLOPS * cus_dn / n_cu), 4)},
+                        "out_proj_pw2": {"kernel": r_out["kernel"], "tflops": tf(r_out), "avg_launch_us": round(r_out["avg_us"], 2),
+                                         "blocks": tiles_of(r_out, 512)}},
+            "note": ("with >= 3 batches in flight the N = 512 GEMMs run as 64 tiles of 256 x 256 on 64 of the 256 CUs (fewest "
+                     "CU-microseconds per GEMM; the other batches' kernels take the idle CUs): `frac` prices them against the "
+                     "WHOLE chip's peak, `frac_of_occupied_cus_peak` against the CUs they hold") if cus_dn < n_cu else
+                    "one batch at a time: 128-wide tiles, 252 blocks",
+            "ffn_up": {"kernel": rep["kernel"], "shape": rep["shape"], "achieved": round(ach, 2), "frac": round(ach / PEAK_F16_TFLOPS, 4),
+                       "avg_launch_us": round(rep["avg_us"], 2), "flops_per_launch": rep["flops"], "traffic": up_traffic,
+                       "mfma_util_pmc": up_util},
             "tile_policy": (f"{n_ctx} batches in flight: 256 x 256 tiles (one block per CU) for every GEMM with N % 256 == 0"
                             + ("" if n_ctx >= 4 else
                                " and >= 128 such tiles, or K >= 2048" if n_ctx >= 3 else " and >= 160 such tiles")
                             + " (with several batches in flight the small-grid GEMMs run on 64-128 CUs: fewer CU-microseconds per GEMM, the "
                               "other batches' kernels take the idle CUs; profiles/r02_f_tile_policy_sweep.txt), 128-wide tiles otherwise; "
                               "other_gemms are stand-alone replays under that policy"),
-            "other_gemms": {eng.REPLAY_SHAPES[w]: round((lambda r: r["flops"] / (r["avg_us"] * 1e-6) / 1e12)(eng.replay_gemm(w, 50)), 1)
-                            for w in (1, 2, 3, 4)},
+            "other_gemms": {eng.REPLAY_SHAPES[w]: tf(eng.replay_gemm(w, 50)) for w in (2, 4)},
             "all_gemm_in_situ_tflops": round(sum(c["flops"] for c in classes) / (gemm_ms * 1e-3) / 1e12, 2),
             "all_gemm_in_situ_ms_per_step": round(gemm_ms / nprof, 3),
             "end_to_end_frac": round(value / world * FLOP_PER_UTT_10S * (args.seconds / 10.0) * (3.0 if tta else 1.0) / 1e12 / PEAK_F16_TFLOPS, 5),

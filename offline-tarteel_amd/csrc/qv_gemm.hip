@@ -945,7 +945,7 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
     if (env_ld == 1) p.nst = 0;
     const int t256 = g_t256 >= 0 ? g_t256 : env_t256;
     p.wide = false;
-    if (t256 > 0 && g.N % 256 == 0 && g.bias && !g.Wi8 && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
+    if (t256 > 0 && g.N % 256 == 0 && g.bias && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
         const int tiles256 = (g.N / 256) * ((g.M + 255) / 256);
         // one batch at a time: a 256 x 256 grid must cover most of the chip (>= 160 tiles) or the 128-wide kernel's
         // 252+ blocks finish sooner; with >= 3 batches in flight the other batches' kernels take the idle CUs and
@@ -968,7 +968,7 @@ const char *qv_gemm_kernel_name(int epi, const GemmArgs &g) {
     static const char *EPI[8] = {"f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv", "f32_relu"};
     static thread_local char buf[64];
     const GemmPlan p = gemm_plan(epi, g);
-    if (g.Wi8) snprintf(buf, sizeof buf, "k_gemm<%s,128,a8w8>", EPI[epi]);
+    if (g.Wi8) snprintf(buf, sizeof buf, p.wide ? "k_gemm256<%s,a8w8>" : "k_gemm<%s,128,a8w8>", EPI[epi]);
     else if (p.wide) snprintf(buf, sizeof buf, "k_gemm256<%s>", EPI[epi]);
     else snprintf(buf, sizeof buf, "k_gemm<%s,%d>", EPI[epi], p.narrow ? 64 : 128);
     return buf;

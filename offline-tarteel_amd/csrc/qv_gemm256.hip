@@ -27,6 +27,8 @@
 
 #include "qv_kernels.h"
 #include "qv_gemm_dequant.h"
+#include "qv_ort.h"
+#include "qv_dev_util.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,10 +56,12 @@ constexpr bool out_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; 
 
 }  // namespace
 
-// WQ: 0 = f16 weights, 4 = W4A16 (block-128 int4), 8 = W8A16 (per-channel int8); layouts in qv_kernels.h (GemmArgs)
+// WQ: 0 = f16 weights, 4 = W4A16 (block-128 int4), 8 = W8A16 (per-channel int8), 88 = A8W8 (QV_PREC_ORT_MIXED: s8
+// activations x s8 weights on v_mfma_i32_32x32x32_i8 -- K counts byte pairs, so staging, LDS image and fragment reads are
+// the f16 kernel's unchanged; only the accumulator type and the epilogue differ); layouts in qv_kernels.h (GemmArgs)
 template <int EPI, int WQ>
 __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
-    constexpr bool W4 = WQ == 4, W8 = WQ == 8;
+    constexpr bool W4 = WQ == 4, W8 = WQ == 8, I8 = WQ == 88;
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : W8 ? BN * BK : BN * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -77,13 +81,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     }
     const int m0 = (wg / gx) * BM, n0 = (wg % gx) * BN;
 
-    f32x16 acc[4][2];
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<I8, i32x16, f32x16>::type acc_t;
+    acc_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
     // ------------------------------------------------------------------ staging ----------
     // piece q of this wave: tile rows wave*32 + q*8 .. +7 of A (and of W), 128 B per row; lane -> (row lane>>3,
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     // ds_read_b128 fragment reads, same image as qv_gemm.hip).
     const int nk = g.K / BK;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
-    const void *bbase = W4 ? (const void *)g.Wq : W8 ? (const void *)g.W8 : (const void *)g.W;
+    const void *bbase = W4 ? (const void *)g.Wq : W8 ? (const void *)g.W8 : I8 ? (const void *)g.Wi8 : (const void *)g.W;
     const size_t bbytes = W4 ? (size_t)g.N * g.K / 2 : W8 ? (size_t)g.N * g.K : (size_t)g.N * g.ldw * 2;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, (int)bbytes, 0x00020000);
     constexpr int stepB = W4 ? 2048 : W8 ? 4096 : BK * 2;   // bytes between consecutive K-tiles of a W piece
@@ -240,9 +247,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
                 // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per register quad
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
+                if constexpr (I8)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, b[j]), __builtin_bit_cast(i32x4, f.a[i]), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
+            }
     };
     // accumulator (i, j), register r: tile row = wm*128 + i*32 + (lane & 31),
     //   tile column = wn*64 + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
@@ -328,6 +339,137 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #endif
     // ------------------------------------------------------------------ epilogue ----------
     unsigned char *sW = smem + wave * 16384;   // this wave's private staging slice
+
+    if constexpr (I8) {
+        // ---- A8W8 epilogue (qv_ort.h; same arithmetic as k_gemm<.., 88, ..>, bit for bit):
+        //   v = float(acc + (128 - zp_x[u]) * wsum[n]) * (s_x[u] * s_w) + bias[n],  u = the row's utterance
+        // wave-private like the f16 epilogues: 32 rows at a time through the wave's own LDS slice.
+        constexpr bool GLU = EPI == EPI_GLU, OUT16 = EPI == EPI_F16_RELU;
+        constexpr bool RELU = EPI == EPI_F16_RELU || EPI == EPI_F32_RELU;
+        constexpr bool FOLD = EPI == EPI_GLU || EPI == EPI_F32_RELU;   // the output feeds another quantiser: track its range
+        constexpr int WO = GLU ? 32 : 64;                               // output columns of this wave
+        constexpr int LDT = WO + 4;
+        float *sO = (float *)sW;
+        const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void *)g.wsum, 0, g.N * 4, 0x00020000);
+        i32x4 wsm[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wsm[j][q] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, (nb + j * 32 + 8 * q + 4 * hi) * 4, 0, 0));
+        auto row_owner = [&](int grow, bool &valid) {
+            valid = true;
+            if (g.row_map) return g.row_map[grow] >> 16;
+            const int u = grow / g.rows_per_utt;
+            valid = (grow - u * g.rows_per_utt) / g.f_per_t < g.len[u];
+            return u;
+        };
+        const int nbo = GLU ? n0 / 2 + wn * 32 : nb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // the tile's rows are rebased per 32-row group: the dense subsampling tensors have millions of 1 KB rows
+            const int r0 = mb + i * 32;
+            const int rows_here = g.M - r0 < 32 ? g.M - r0 : 32;
+            if (rows_here <= 0) break;
+            int grow = r0 + l31;
+            grow = grow < g.M ? grow : g.M - 1;
+            bool valid;
+            const int utt = row_owner(grow, valid);
+            const QParam p = dql_param(g.mm_in + QV_MM_STRIDE * utt);
+            const float srow = p.scale * g.w_scale;
+            const int zc = 128 - (int)p.zp;
+            float mn = INFINITY, mx = -INFINITY;
+            f32x4 old[8];
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+                OUT16 ? (void *)((half_t *)g.out + (size_t)r0 * g.ldo) : (void *)((float *)g.out + (size_t)r0 * g.ldo), 0,
+                rows_here * g.ldo * (OUT16 ? 2 : 4), 0x00020000);
+            if (EPI == EPI_RESID) {
+                const int rr = lane >> 4, cc = (lane & 15) * 4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = k * 4 + rr;
+                    if (r < rows_here) old[k] = ldf4(rs_out, r * g.ldo + nbo + cc);
+                }
+            }
+            if (GLU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 av, gv, o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        av[e] = (float)(acc[i][0][q * 4 + e] + zc * wsm[0][q][e]) * srow + bia[0][q][e];
+                        gv[e] = (float)(acc[i][1][q * 4 + e] + zc * wsm[1][q][e]) * srow + bia[1][q][e];
+                    }
+                    const f32x4 sg = sigmoid4(gv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = av[e] * sg[e]; mn = fminf(mn, o[e]); mx = fmaxf(mx, o[e]); }
+                    *(f32x4 *)(sO + l31 * LDT + 8 * q + 4 * hi) = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = (float)(acc[i][j][q * 4 + e] + zc * wsm[j][q][e]) * srow + bia[j][q][e];
+                            if (RELU) v = v > 0.f ? v : 0.f;
+                            o[e] = v;
+                            mn = fminf(mn, v);
+                            mx = fmaxf(mx, v);
+                        }
+                        *(f32x4 *)(sO + l31 * LDT + j * 32 + 8 * q + 4 * hi) = o;
+                    }
+            }
+            if (FOLD) {
+                // range of each row (both lane halves), then one atomic pair per run of rows of the same utterance
+                mn = fminf(mn, __shfl_xor(mn, 32));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const int u = (valid && r0 + l31 < g.M) ? utt : -1;
+                unsigned long long todo = __ballot(hi == 0 && u >= 0);
+                while (todo) {   // (wave-uniform: one round per distinct utterance among the 32 rows, usually one)
+                    const int first = __ffsll((long long)todo) - 1;
+                    const int uu = __shfl(u, first);
+                    const bool in = hi == 0 && u == uu;
+                    const float a = wave_min(in ? mn : INFINITY), b2 = wave_max(in ? mx : -INFINITY);
+                    if (lane == first) mm_fold(g.mm_out + QV_MM_STRIDE * uu, a, b2);
+                    todo &= ~__ballot(in);
+                }
+            }
+            if (OUT16) {
+                const int rr = lane >> 3, cc = (lane & 7) * 8;    // read-back: 8 rows x 128 B of halves per instruction
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = k * 8 + rr;
+                    const f32x4 a = *(const f32x4 *)(sO + r * LDT + cc), b2 = *(const f32x4 *)(sO + r * LDT + cc + 4);
+                    const half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b2[0], (half_t)b2[1], (half_t)b2[2], (half_t)b2[3]};
+                    if (r < rows_here) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs_out, (r * g.ldo + nbo + cc) * 2, 0, 0);
+                }
+            } else if (GLU) {
+                const int rr = lane >> 3, cc = (lane & 7) * 4;    // read-back: 8 rows x 128 B per instruction
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = k * 8 + rr;
+                    const f32x4 v = *(const f32x4 *)(sO + r * LDT + cc);
+                    if (r < rows_here) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (r * g.ldo + nbo + cc) * 4, 0, 0);
+                }
+            } else {
+                const int rr = lane >> 4, cc = (lane & 15) * 4;   // read-back: 4 rows x 256 B per instruction
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = k * 4 + rr;
+                    f32x4 v = *(const f32x4 *)(sO + r * LDT + cc);
+                    if (EPI == EPI_RESID) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = old[k][e] + g.alpha * v[e];
+                    }
+                    if (r < rows_here) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (r * g.ldo + nbo + cc) * 4, 0, 0);
+                }
+            }
+        }
+        return;
+    }
 
     if (EPI == EPI_QKV && n0 >= 2 * QV_D) {
         // V tile: stored TRANSPOSED, Vt[b][h*64+d][t].  64 frames at a time go through the wave's slice as
@@ -496,6 +638,18 @@ static void launch256(const GemmArgs &g, hipStream_t s) {
 // N % 256 == 0, K % 64 == 0 (int4: K % 128 == 0, K <= 4096 for the scale table in LDS); false = nothing launched
 bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s) {
     if (g.N % 256 != 0 || g.K % 64 != 0 || !g.bias) return false;
+    if (g.Wi8) {
+        // int8 activations x int8 weights (QV_PREC_ORT_MIXED): the GEMM-shaped convolutions
+        switch (epi) {
+            case EPI_GLU: launch256<EPI_GLU, 88>(g, s); break;
+            case EPI_RESID: launch256<EPI_RESID, 88>(g, s); break;
+            case EPI_F32: launch256<EPI_F32, 88>(g, s); break;
+            case EPI_F32_RELU: launch256<EPI_F32_RELU, 88>(g, s); break;
+            case EPI_F16_RELU: launch256<EPI_F16_RELU, 88>(g, s); break;
+            default: return false;
+        }
+        return true;
+    }
     if (g.Wq) {
         // int4 weights: the Linear layers (FFN, QKV, attention out, linear_pos)
         if (g.K % 128 != 0 || g.K > 4096) return false;

@@ -14,10 +14,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["fp16", "int4_int8"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["fp16", "int4_int8", "ort_mixed"])
 def eng(request):
     """precision 0 = f16 weights, 1 = QV_PREC_MIXED_INT4_INT8 (block-128 int4 Linear layers + per-channel int8
-    pointwise convolutions, dequantised inside the MFMA operand fetch of either tile shape)."""
+    pointwise convolutions, dequantised inside the MFMA operand fetch of either tile shape), 2 = QV_PREC_ORT_MIXED
+    (int4 Linear layers + every Conv as uint8 x int8 -> int32 on the i8 MFMA of either tile shape, same epilogue
+    arithmetic and the same per-utterance activation ranges)."""
     import offline_tarteel_amd  # noqa: F401
     from offline_tarteel_amd.engine import Engine
 
