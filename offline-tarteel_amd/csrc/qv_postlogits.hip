@@ -20,6 +20,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -184,55 +185,64 @@ __device__ int block_topk_select(const double *sc, int n, int K, uint32_t *scrat
 // ------------------------------------------------------------------ bit-parallel LCS ---
 // Hyyro/Crochemore: V all ones; per text char U = V & M; V = (V + U) | (V & ~M).
 // pm: match masks [sym][stride] (u64), W words used; text codes >= QV_NSYM match nothing.
+// lcs_chunk advances the recurrence over the first cnt (<= 8) codes packed in `chunk`; lcs_feed continues it over n
+// more text codes (V carries the state); lcs_count reads the LCS length of everything fed so far: LCS(pattern, text[:j]) is
+// available at every j of one walk over the text.
 template <int W>
-__device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int stride, const uint8_t *__restrict__ text,
-                                        int n, int m) {
-    uint64_t V[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) V[w] = ~0ull;
-    // the text is fetched 8 codes per (possibly unaligned) load: one memory access per 8 steps
-    // of the recurrence instead of one per step; every text buffer is padded by >= 8 bytes
+__device__ __forceinline__ void lcs_chunk(uint64_t (&V)[W], const uint64_t *__restrict__ pm, int stride, uint64_t chunk, int cnt) {
     // The match masks of CH consecutive codes are requested TOGETHER, before the dependent add chain
     // of those steps: the recurrence is one serial chain per lane, and a mask load inside every step
-    // (L1/L2 or LDS latency each) used to be most of a step's time.  Codes past the end of the text
+    // (L1/L2 or LDS latency each) used to be most of a step's time.  Codes past cnt
     // and codes outside the alphabet get an all-zero mask, which leaves V unchanged.
-    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-    constexpr int CH = W <= 4 ? 8 : (W <= 8 ? 4 : 2);
+    constexpr int CH = W <= 4 ? 8 : (W <= 8 ? 4 : 1);   // (wider patterns: fewer masks in flight -- mk[CH][W] sets the kernels' VGPR count, i.e. how many waves a SIMD interleaves)
+#pragma unroll
+    for (int g0 = 0; g0 < 8; g0 += CH) {
+        if (g0 >= cnt) break;
+        uint64_t mk[CH][W];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            int c = (int)((chunk >> (8 * (g0 + e))) & 0xFF);
+            const bool valid = g0 + e < cnt && c < QV_NSYM;
+            const uint64_t *M = pm + (size_t)(valid ? c : 0) * stride;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                uint64_t x = M[w];
+                mk[e][w] = valid ? x : 0ull;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            unsigned long long carry = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                uint64_t v = V[w], mm = mk[e][w];
+                // v + (v & mm) + carry with the carry chained through the words (add / addc)
+                uint64_t s2 = __builtin_addcll(v, v & mm, carry, &carry);
+                V[w] = s2 | (v & ~mm);
+            }
+        }
+    }
+}
+
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
+template <int W>
+__device__ __forceinline__ void lcs_feed(uint64_t (&V)[W], const uint64_t *__restrict__ pm, int stride,
+                                         const uint8_t *__restrict__ text, int n) {
+    // the text is fetched 8 codes per (possibly unaligned) load: one memory access per 8 steps
+    // of the recurrence instead of one per step; every text buffer is padded by >= 8 bytes
     // ... and the NEXT 8 codes are requested before this chunk's steps run: the lane's chain used to start every chunk
     // with an exposed global-load latency, and a kernel lasts as long as its longest text (1,100+ codes = 140 chunks)
     uint64_t next = n > 0 ? *(const u64_unaligned *)text : 0ull;
     for (int j0 = 0; j0 < n; j0 += 8) {
         const uint64_t chunk = next;
         if (j0 + 8 < n) next = *(const u64_unaligned *)(text + j0 + 8);
-        const int cnt = n - j0 < 8 ? n - j0 : 8;
-#pragma unroll
-        for (int g0 = 0; g0 < 8; g0 += CH) {
-            if (g0 >= cnt) break;
-            uint64_t mk[CH][W];
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                int c = (int)((chunk >> (8 * (g0 + e))) & 0xFF);
-                const bool valid = g0 + e < cnt && c < QV_NSYM;
-                const uint64_t *M = pm + (size_t)(valid ? c : 0) * stride;
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    uint64_t x = M[w];
-                    mk[e][w] = valid ? x : 0ull;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                unsigned long long carry = 0;
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    uint64_t v = V[w], mm = mk[e][w];
-                    // v + (v & mm) + carry with the carry chained through the words (add / addc)
-                    uint64_t s2 = __builtin_addcll(v, v & mm, carry, &carry);
-                    V[w] = s2 | (v & ~mm);
-                }
-            }
-        }
+        lcs_chunk<W>(V, pm, stride, chunk, n - j0 < 8 ? n - j0 : 8);
     }
+}
+
+template <int W>
+__device__ __forceinline__ int lcs_count(const uint64_t (&V)[W], int m) {
     int zeros = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -242,6 +252,16 @@ __device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int str
         zeros += __popcll(z);
     }
     return zeros;
+}
+
+template <int W>
+__device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int stride, const uint8_t *__restrict__ text,
+                                        int n, int m) {
+    uint64_t V[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) V[w] = ~0ull;
+    lcs_feed<W>(V, pm, stride, text, n);
+    return lcs_count<W>(V, m);
 }
 
 __device__ __forceinline__ int lcs_dispatch(int W, const uint64_t *pm, int stride, const uint8_t *text, int n, int m) {
@@ -654,7 +674,7 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
     const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
     // " text " in " verse "  (word-boundary substring)
     bool sub = false;
-    if (qw >= 3 && m <= n) {
+    if (qw >= 3 && m <= n && wk.lcsf[((size_t)b * tab.n_verses + v) * 3 + variant] == m) {   // (needs LCS == m, see k_lcs_full)
         for (int i = lane; i + m <= n && !sub; i += 64) {
             if (i > 0 && t.p[i - 1] != 0) continue;
             if (i + m < n && t.p[i + m] != 0) continue;
@@ -793,7 +813,8 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
         const int n = t.n, vw = t.nw;
         const double fr = ratio_from(l, m, n);
         bool sub = false;   // " text " in " verse "  (word-boundary substring)
-        if (qw >= 3 && m <= n) {
+        // (a substring is a common subsequence of full length: only texts with LCS == m are scanned at all)
+        if (qw >= 3 && m <= n && l == m) {
             for (int i = 0; i + m <= n && !sub; ++i) {
                 if (i > 0 && t.p[i - 1] != 0) continue;
                 if (i + m < n && t.p[i + m] != 0) continue;
@@ -955,6 +976,12 @@ __global__ __launch_bounds__(256) void k_pass1_final(QvTables tab, QvWork wk, Qv
 
 
 // ------------------------------------------------------------------ 6. span pass -------
+// (Measured and rejected, round 3: one START verse per lane with all its spans read off ONE walk over the longest live
+// span -- the span texts of a start verse are prefixes of one another and the recurrence walks front to back, lcs_feed /
+// lcs_count -- does 3.3x fewer word-steps and reproduces every fixture, but ran 2.4x SLOWER than this kernel at batch 1
+// and batch 64 alike (594 vs 235 us, 2,030 vs 840 us), with per-ayah loops, with one loop cut at the boundaries, and with
+// the span ends held in registers.  Five times fewer lanes, each carrying the longest chain: the pass is bound by the
+// serial add-with-carry chain per lane, and the compiler schedules the plain counted loop below far better.)
 // quran_db.py:334-365: every window of 2..max_span ayat of the surahs of the top 20.  One
 // span text per lane; texts are contiguous slices of the padded clean array.  A span is
 // skipped when even LCS = min(m, n) could not beat the pass-1 best (exact pruning).
@@ -1020,6 +1047,8 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
         wk.span_part_key[(size_t)b * QV_SPAN_BLOCKS + blockIdx.x] = bkey;
     }
 }
+
+__device__ void base_final_one(const QvTables &tab, const QvWork &wk, const QvKnobs &kn, int b, int force_ctc);
 
 // (Measured and rejected: folding this -- and the candidate assembly, and the final decision -- into the tail of the
 // kernel in front of it with a "last block done" counter.  Publishing a block's results to a block on another XCD takes an
