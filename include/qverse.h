@@ -88,7 +88,7 @@ typedef struct {
     int32_t top_span_refs;      /* CTC_DIRECT_TOP_SPAN_REFS    80 */
     int32_t max_span;           /* CTC_DIRECT_MAX_SPAN          6 (table limit 6) */
     double threshold;           /* CTC_DIRECT_THRESHOLD       0.80 */
-    double text_weight;         /* CTC_DIRECT_TEXT_WEIGHT      0.0 (only 0.0 supported on device) */
+    double text_weight;         /* CTC_DIRECT_TEXT_WEIGHT      0.0 (final = -norm_loss + weight * text score - penalty) */
     double span_penalty;        /* CTC_DIRECT_SPAN_PENALTY     0.5 */
     int32_t skip_unused_passes; /* 1: skip search()/pass-3 when the gate passes (their output is
                                    unused by the mixed plugin); 0: literal */

@@ -482,7 +482,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
         return rc;
     };
     if (cfg->max_span < 2 || cfg->max_span > QV_MAX_SPAN) { qv_set_error(eng, "CTC_DIRECT_MAX_SPAN must be in [2,6]"); return fail(QV_ERR_ARG); }
-    if (cfg->text_weight != 0.0) { qv_set_error(eng, "CTC_DIRECT_TEXT_WEIGHT != 0 is not supported on device"); return fail(QV_ERR_ARG); }
+    if (!(cfg->text_weight == cfg->text_weight) || cfg->text_weight < 0.0) { qv_set_error(eng, "CTC_DIRECT_TEXT_WEIGHT must be a non-negative number"); return fail(QV_ERR_ARG); }
     if (cfg->top_text < 1 || cfg->top_text > QV_RUNNER_CAP - 1) { qv_set_error(eng, "CTC_DIRECT_TOP_TEXT must be in [1,127]"); return fail(QV_ERR_ARG); }
     if (cfg->top_span_refs < 0 || cfg->top_span_refs > 128) { qv_set_error(eng, "CTC_DIRECT_TOP_SPAN_REFS must be in [0,128]"); return fail(QV_ERR_ARG); }
     if (cfg->max_batch < 1 || cfg->max_samples < 400) { qv_set_error(eng, "bad capacity"); return fail(QV_ERR_ARG); }

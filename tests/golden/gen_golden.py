@@ -13,6 +13,8 @@ It imports the unmodified reference post-logits code (ref_import.py) and writes
     tests/golden/e2e_cases.json.gz           synthetic log-probs recipe -> greedy decode,
                                              per-candidate ctc_loss, ranking, predict() dict
     tests/golden/scoring_cases.json          runner.score_sequence known answers
+    tests/golden/e2e_textweight_cases.json.gz  (section "textweight") the rerank and the decision with
+                                             CTC_DIRECT_TEXT_WEIGHT = 0.35 / 2.0 on three of the e2e recipes
 
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 PYTHONHASHSEED is pinned because the reference's tie order follows set iteration
@@ -61,6 +63,8 @@ def main():
     tok = cd._model.tokenizer
     rng = random.Random(20260630)
     sections = set(sys.argv[1:]) or {"small", "retrieval", "e2e"}
+    if sections == {"textweight"}:
+        return textweight_section(cd, tok, db)
 
     # ---------------- normalizer -------------------------------------------
     from shared.normalizer import normalize_arabic
@@ -319,6 +323,70 @@ def main():
     e2e.append(run_e2e("long_2_255", corrupt_ids(ids_of(verse(2, 255)["text_clean"]), 0.3, 9), 251, 9, 1.0, 6.0, 2))
     e2e.append(run_e2e("tight_T_103_1", ids_of(verse(103, 1)["text_clean_no_bsm"]), 2 * len(ids_of(verse(103, 1)["text_clean_no_bsm"])) + 1, 10, 1.0, 8.0, 1))
     dump("e2e_cases.json.gz", e2e, gz=True)
+
+
+def textweight_section(cd, tok, db):
+    """CTC_DIRECT_TEXT_WEIGHT != 0 (c2c-direct/run.py:62-74,371-373): final = -norm_loss + TEXT_WEIGHT * text_score -
+    penalty, where text_score is whatever `score` the candidate carries (match_verse's unrounded best, the runners-up
+    rounded to 3 dp, search()'s fragment scores, pass 3's ratios, 0.0 for expanded spans)."""
+    import torch
+
+    def verse(s, a):
+        return db.get_verse(s, a)
+
+    def span_text(s, a0, a1):
+        chunk = [verse(s, a) for a in range(a0, a1 + 1)]
+        first = chunk[0].get("text_clean_no_bsm") or chunk[0]["text_clean"]
+        return " ".join([first] + [v["text_clean"] for v in chunk[1:]])
+
+    def ids_of(text):
+        return [int(i) for i in tok.text_to_ids(text)]
+
+    def corrupt_ids(ids, rate, seed):   # (same recipe as the e2e section)
+        r = random.Random(seed)
+        out = []
+        for i in ids:
+            x = r.random()
+            if x < rate / 2:
+                continue
+            if x < rate:
+                out.append(r.randrange(1, 1024))
+                continue
+            out.append(i)
+        return out
+
+    recipes = [
+        ("corrupt_103_2", corrupt_ids(ids_of(verse(103, 2)["text_clean"]), 0.35, 3), 48, 3, 1.0, 7.0, 2),
+        ("corrupt_36_1_5", corrupt_ids(ids_of(span_text(36, 1, 5)), 0.35, 5), 126, 5, 1.0, 6.0, 3),
+        ("corrupt_55_1_4", corrupt_ids(ids_of(span_text(55, 1, 4)), 0.4, 6), 90, 6, 1.0, 6.0, 3),
+    ]
+    out = []
+    for name, ids_path, T, seed, noise, boost, rep in recipes:
+        logits = synth_logits(ids_path, T, seed=seed, noise=noise, boost=boost, rep=rep)
+        lp = torch.log_softmax(torch.from_numpy(logits), dim=-1).numpy()
+        transcript = cd._greedy_decode(lp)
+        cands, base = cd._build_candidates(transcript)
+        use_ctc = base is None or float(base.get("score", 0.0)) < cd.FALLBACK_THRESHOLD
+        for tw in (0.35, 2.0):
+            keep = cd.TEXT_WEIGHT
+            cd.TEXT_WEIGHT = tw
+            try:
+                ranked = cd._ctc_rerank(lp, [dict(c) for c in cands])
+            finally:
+                cd.TEXT_WEIGHT = keep
+            best = ranked[0]
+            out.append({
+                "name": name, "text_weight": tw,
+                "recipe": {"ids": ids_path, "T": T, "seed": seed, "noise": noise, "boost": boost, "rep": rep},
+                "transcript": transcript, "use_ctc": bool(use_ctc), "n_candidates": len(cands),
+                "ranked_keys": [[c["surah"], c["ayah"], c["ayah_end"]] for c in ranked[:20]],
+                "ranked_final": [float(c["final_score"]) for c in ranked[:20]],
+                "ranked_text_score": [float(c.get("score") or 0.0) for c in ranked[:20]],
+                "winner": [best["surah"], best["ayah"], best["ayah_end"]],
+                "winner_score_raw": float(math.exp(-best["ctc_norm_loss"])),
+            })
+            print(name, tw, out[-1]["winner"], out[-1]["ranked_final"][:3])
+    dump("e2e_textweight_cases.json.gz", out, gz=True)
 
     # ---------------- score_sequence known answers -----------------------------
     # inputs are the six hand cases of tests/test_scoring.py:8-59 (data), outputs

@@ -240,3 +240,27 @@ def test_random_transcripts_vs_oracle(engine, oracle):
         assert r["cand_start"].tolist() == cs.tolist(), it
         assert r["cand_span"].tolist() == cp.tolist(), it
         assert r["cand_score"].tolist() == sc.tolist(), it
+
+
+def test_text_weight_fixtures(golden_dir):
+    """CTC_DIRECT_TEXT_WEIGHT != 0 on the device: the reference's winner (and exp(-norm_loss) score) for weights 0.35 and
+    2.0 -- one of the three recipes changes its winner between the two."""
+    from offline_tarteel_amd.engine import Engine
+
+    cases = json.load(gzip.open(golden_dir / "e2e_textweight_cases.json.gz"))
+    for tw in (0.35, 2.0):
+        eng = Engine(device=0, with_model=False, max_batch=4, max_samples=200000, text_weight=tw)
+        try:
+            sel = [c for c in cases if c["text_weight"] == tw]
+            lps = [lp_of(c["recipe"]) for c in sel]
+            t_max = max(x.shape[0] for x in lps)
+            batch = torch.full((len(lps), t_max, 1025), -50.0)
+            for b, x in enumerate(lps):
+                batch[b, : x.shape[0]] = x
+            res = eng.decode_retrieve_rerank(batch.cuda().contiguous(), [x.shape[0] for x in lps])
+            for c, r in zip(sel, res):
+                assert r["transcript"] == c["transcript"] and r["use_ctc"] and r["n_candidates"] == c["n_candidates"], c["name"]
+                assert [r["surah"], r["ayah"], r["ayah_end"]] == c["winner"] and r["source"] == "ctc", (c["name"], tw, r)
+                assert abs(r["score"] - c["winner_score_raw"]) <= 1e-3 * max(c["winner_score_raw"], 1e-3), (c["name"], tw)
+        finally:
+            eng.close()

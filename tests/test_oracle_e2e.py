@@ -81,3 +81,30 @@ def test_ctc_float64_twin_agrees_with_torch(oracle):
         f = oracle.ctc_score_f64(lp, t)
         assert abs(w / len(t) - f) <= 1e-5 * max(1.0, abs(f))
     assert oracle.ctc_score_f64(lp, list(range(63))) == 1e9      # 2L+1 = 127 > T = 126
+
+
+def test_text_weight_fixtures(golden_dir):
+    """CTC_DIRECT_TEXT_WEIGHT != 0 (c2c-direct/run.py:371-373): final = -norm_loss + weight * text_score - penalty.
+    The unmodified reference's ranking, final scores and winner for weights 0.35 and 2.0."""
+    from oracle.oracle import Oracle
+
+    cases = json.load(gzip.open(golden_dir / "e2e_textweight_cases.json.gz"))
+    assert len(cases) == 6 and {c["text_weight"] for c in cases} == {0.35, 2.0}
+    assert len({tuple(c["winner"]) for c in cases if c["name"] == "corrupt_55_1_4"}) == 2   # the weight changes a winner
+    orcs = {}
+    for c in cases:
+        tw = c["text_weight"]
+        orc = orcs.setdefault(tw, Oracle(text_weight=tw))
+        lp = logprobs_of(c["recipe"])
+        assert orc.greedy_decode(lp) == c["transcript"], c["name"]
+        cs, cp, sc, _ = orc.build_candidates(c["transcript"])
+        assert len(cs) == c["n_candidates"]
+        keys = [list(orc.key_of(int(a), int(b))) for a, b in zip(cs, cp)]
+        win, loss, cl, fs = orc.ctc_rerank(lp, cs, cp, sc)
+        order = sorted((i for i in range(len(cs)) if np.isfinite(loss[i])), key=lambda i: -fs[i])
+        assert [keys[i] for i in order[:20]] == c["ranked_keys"], (c["name"], tw)
+        assert np.allclose([fs[i] for i in order[:20]], c["ranked_final"], atol=1e-6), (c["name"], tw)
+        assert [sc[i] for i in order[:20]] == c["ranked_text_score"], (c["name"], tw)
+        res = orc.predict_logprobs(lp)
+        assert [res["surah"], res["ayah"], res["ayah_end"]] == c["winner"] and res["source"] == "ctc", (c["name"], tw)
+        assert abs(res["score_raw"] - c["winner_score_raw"]) <= 1e-6
