@@ -583,85 +583,100 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 // (64 x 32 keys) and the 32 NEW relative-position rows of the tile: the position rows the four query
 // tiles need form a sliding window of 160 rows that advances by 32 per key tile, kept in a 256-row
 // ring (window of tile kt + the 64 rows prefetched for kt + 1 and kt + 2 never overlap in it).
-#define ATT_RING 256
-#define ATT_NST 3
+// HPB heads share a block (4 consumer waves each; the 4 loader waves stage for all of them): with HPB = 2 every SIMD runs
+// two consumer waves whose serial chains (MFMA -> skew through LDS -> softmax -> MFMA) overlap, and B = 64 x 10 s is one
+// round of 256 blocks instead of two rounds of 512.  LDS then only holds NST = 2 K/V stages (tile kt + 1 is requested
+// when tile kt's barrier frees the other buffer) and a 192-row position ring (160-row window + the 32 rows of the next
+// tile).  The arithmetic of a (head, query tile) is the same wave program in both shapes: outputs are bit-identical.
 __device__ __forceinline__ void att_glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l,
                                      16, 0, 0);
 }
 
-__global__ __launch_bounds__(512) void k_attention_ws(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
-                                                      const half_t *__restrict__ pos, int pos_ld,
-                                                      const float *__restrict__ bias_u, const float *__restrict__ bias_v,
-                                                      const int32_t *__restrict__ len, const int32_t *__restrict__ row_off,
-                                                      half_t *__restrict__ out, int t_max, int t_pad) {
-    __shared__ __attribute__((aligned(16))) half_t sK[ATT_NST][32 * 64];    // [key][d], 16-B chunks swizzled by (key >> 1) & 7
-    __shared__ __attribute__((aligned(16))) half_t sV[ATT_NST][64 * 32];    // [d][key], 16-B chunks swizzled by (d >> 2) & 3
-    __shared__ __attribute__((aligned(16))) half_t sP[ATT_RING * 64];       // ring of position rows, swizzled like sK
-    __shared__ float slab[4][32 * ATT_LDS_LD];
-    const int b = blockIdx.z, h = blockIdx.x, qg = blockIdx.y;
+template <int HPB, int NST, int RING>
+__global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
+                                                                  const half_t *__restrict__ pos, int pos_ld,
+                                                                  const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                  const int32_t *__restrict__ len, const int32_t *__restrict__ row_off,
+                                                                  half_t *__restrict__ out, int t_max, int t_pad) {
+    static_assert(RING % 8 == 0 && RING >= 160 + 32 * (NST - 1), "position ring: window + prefetched rows");
+    __shared__ __attribute__((aligned(16))) half_t sK[HPB][NST][32 * 64];    // [key][d], 16-B chunks swizzled by (key >> 1) & 7
+    __shared__ __attribute__((aligned(16))) half_t sV[HPB][NST][64 * 32];    // [d][key], 16-B chunks swizzled by (d >> 2) & 3
+    __shared__ __attribute__((aligned(16))) half_t sP[HPB][RING * 64];       // ring of position rows, swizzled like sK
+    __shared__ float slab[4 * HPB][32 * ATT_LDS_LD];
+    const int b = blockIdx.z, qg = blockIdx.y;
     const int T = len[b];
     if (qg * 128 >= T) return;                       // whole block: no query of this group exists
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool loader = wave >= 4;
+    const bool loader = wave >= 4 * HPB;
     const int w4 = wave & 3, l31 = lane & 31, hi = lane >> 5;
     const size_t row0 = (size_t)row_off[b];
-    const half_t *kb = qk + row0 * (2 * QV_D) + QV_D + h * QV_DK;
-    const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;
-    const half_t *pb = pos + h * QV_DK;
     const int n_kt = (T + 31) >> 5;
     const int Rb = t_max - 128 * qg - 128;           // first position row of key tile 0's window
 
     if (loader) {
-        // one K, one V and one position load per loader wave and key tile (1 KB each)
+        // per head: one K, one V and one position load per loader wave and key tile (1 KB each)
         auto stage = [&](int kt) {
-            const int j0 = kt * 32, buf = kt % ATT_NST;
-            {   // K: 8 keys x 128 B per wave
-                int r = w4 * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-                int kj = j0 + r;
-                kj = kj < T ? kj : T - 1;
-                att_glds16(kb + (size_t)kj * (2 * QV_D) + c * 8, sK[buf] + w4 * 512);
-            }
-            {   // V^T: 16 d rows x 64 B per wave (keys j0 .. j0 + 31 < t_pad)
-                int r = w4 * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
-                att_glds16(vb + (size_t)r * t_pad + j0 + c * 8, sV[buf] + w4 * 512);
+            const int j0 = kt * 32, buf = kt % NST;
+#pragma unroll
+            for (int hh = 0; hh < HPB; ++hh) {
+                const int h = blockIdx.x * HPB + hh;
+                const half_t *kb = qk + row0 * (2 * QV_D) + QV_D + h * QV_DK;
+                const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;
+                {   // K: 8 keys x 128 B per wave
+                    int r = w4 * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+                    int kj = j0 + r;
+                    kj = kj < T ? kj : T - 1;
+                    att_glds16(kb + (size_t)kj * (2 * QV_D) + c * 8, sK[hh][buf] + w4 * 512);
+                }
+                {   // V^T: 16 d rows x 64 B per wave (keys j0 .. j0 + 31 < t_pad)
+                    int r = w4 * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+                    att_glds16(vb + (size_t)r * t_pad + j0 + c * 8, sV[hh][buf] + w4 * 512);
+                }
             }
         };
         auto pos_rows = [&](int first, int n8) {   // n8 chunks of 8 rows starting at window row `first`, this wave's share
             for (int q = w4; q < n8; q += 4) {
                 int wr = first + q * 8 + (lane >> 3);                 // row relative to Rb
-                int ring = wr % ATT_RING;
+                int ring = wr % RING;
                 int c = (lane & 7) ^ ((ring >> 1) & 7);
                 int rr = Rb + wr;
                 rr = rr < 0 ? 0 : (rr > 2 * t_max - 2 ? 2 * t_max - 2 : rr);
-                att_glds16(pb + (size_t)rr * pos_ld + c * 8, sP + (size_t)((first + q * 8) % ATT_RING) * 64);
+#pragma unroll
+                for (int hh = 0; hh < HPB; ++hh)
+                    att_glds16(pos + (blockIdx.x * HPB + hh) * QV_DK + (size_t)rr * pos_ld + c * 8,
+                               sP[hh] + (size_t)((first + q * 8) % RING) * 64);
             }
         };
-        // per wave: unit(0) = 5 position chunks + K + V, unit(kt >= 1) = K + V + 1 position chunk (3 loads)
+        // per wave: unit(0) = HPB x (5 position chunks + K + V), unit(kt >= 1) = HPB x (K + V + 1 position chunk)
         pos_rows(0, 20);        // rows 0 .. 159: the window of tile 0
         stage(0);
-        if (n_kt > 1) {
+        if (NST == 3 && n_kt > 1) {
             stage(1);
             pos_rows(32 + 128, 4);
         }
         for (int kt = 0; kt < n_kt; ++kt) {
-            // unit(kt) has landed once only unit(kt + 1) may still be in flight
-            if (kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // unit(kt) has landed once only the units requested after it may still be in flight
+            if (NST == 3 && kt + 1 < n_kt) {
+                if (HPB == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // tile kt visible; the buffers of tile kt - 1 are free
-            if (kt + 2 < n_kt) {
-                stage(kt + 2);
-                pos_rows(32 * (kt + 2) + 128, 4);   // the 32 new rows of tile kt + 2
+            if (kt + NST - 1 < n_kt) {
+                stage(kt + NST - 1);
+                pos_rows(32 * (kt + NST - 1) + 128, 4);   // the 32 new rows of that tile
             }
         }
         return;
     }
 
     // ---------------------------------------------------------------- consumers ----------
+    const int hh = wave >> 2, h = blockIdx.x * HPB + hh;
     const int i0 = qg * 128 + w4 * 32;
     const bool active = i0 < T;
     const half_t *qb = qk + row0 * (2 * QV_D) + h * QV_DK;
-    float *sl = slab[w4];
+    float *sl = slab[wave];
+    const half_t *sPh = sP[hh];
     half8 qu[4], qv[4];
     {
         int qi = i0 + l31;
@@ -685,19 +700,20 @@ __global__ __launch_bounds__(512) void k_attention_ws(const half_t *__restrict__
     for (int kt = 0; kt < n_kt; ++kt) {
         __builtin_amdgcn_s_barrier();
         if (!active) continue;
-        const int j0 = kt * 32, buf = kt % ATT_NST;
+        const int j0 = kt * 32, buf = kt % NST;
+        const half_t *sKb = sK[hh][buf], *sVb = sV[hh][buf];
         // window-relative position rows of this wave: 32 kt + 96 - 32 w4 + c, c in [0, 64)
         const int wr0 = 32 * kt + 96 - 32 * w4 + l31;
-        const int ring0 = wr0 % ATT_RING, ring1 = (wr0 + 32) % ATT_RING;
+        const int ring0 = wr0 % RING, ring1 = (wr0 + 32) % RING;
         f32x16 st, r0, r1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; r0[r] = 0.f; r1[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + hi;
-            half8 kf = *(const half8 *)(sK[buf] + l31 * 64 + ((c ^ ((l31 >> 1) & 7)) << 3));
-            half8 p0 = *(const half8 *)(sP + ring0 * 64 + ((c ^ ((ring0 >> 1) & 7)) << 3));
-            half8 p1 = *(const half8 *)(sP + ring1 * 64 + ((c ^ ((ring1 >> 1) & 7)) << 3));
+            half8 kf = *(const half8 *)(sKb + l31 * 64 + ((c ^ ((l31 >> 1) & 7)) << 3));
+            half8 p0 = *(const half8 *)(sPh + ring0 * 64 + ((c ^ ((ring0 >> 1) & 7)) << 3));
+            half8 p1 = *(const half8 *)(sPh + ring1 * 64 + ((c ^ ((ring1 >> 1) & 7)) << 3));
             st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);
             r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);
             r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);
@@ -743,10 +759,10 @@ __global__ __launch_bounds__(512) void k_attention_ws(const half_t *__restrict__
             for (int e = 0; e < 8; ++e) pbf[e] = (half_t)p[8 * ks + e];
             // V^T pieces: keys 16 ks + 4 hi + {0..3} and + 8 -> 16-B chunks 2 ks and 2 ks + 1, 8-byte half `hi`
             const int da = l31, dc = 32 + l31;
-            half4 a0 = *(const half4 *)(sV[buf] + da * 32 + (((2 * ks) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
-            half4 a1 = *(const half4 *)(sV[buf] + da * 32 + (((2 * ks + 1) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
-            half4 c0 = *(const half4 *)(sV[buf] + dc * 32 + (((2 * ks) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
-            half4 c1 = *(const half4 *)(sV[buf] + dc * 32 + (((2 * ks + 1) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+            half4 a0 = *(const half4 *)(sVb + da * 32 + (((2 * ks) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
+            half4 a1 = *(const half4 *)(sVb + da * 32 + (((2 * ks + 1) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
+            half4 c0 = *(const half4 *)(sVb + dc * 32 + (((2 * ks) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+            half4 c1 = *(const half4 *)(sVb + dc * 32 + (((2 * ks + 1) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
             half8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             half8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pbf, o0, 0, 0, 0);
@@ -922,8 +938,13 @@ void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int
                            t_max, t_pad);
         return;
     }
-    hipLaunchKernelGGL(k_attention_ws, dim3(QV_H, (t_max + 127) / 128, batch), dim3(512), 0, s, qk, vt, pos, pos_ld, bu, bv,
-                       len, row_off, out, t_max, t_pad);
+    const char *v1 = getenv("QVERSE_ATT_HPB");     // cross-check path: one head per block (3 K/V stages, 256-row ring)
+    if (!(v1 && v1[0] == '1'))
+        hipLaunchKernelGGL((k_attention_ws<2, 2, 192>), dim3(QV_H / 2, (t_max + 127) / 128, batch), dim3(768), 0, s, qk, vt, pos,
+                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad);
+    else
+        hipLaunchKernelGGL((k_attention_ws<1, 3, 256>), dim3(QV_H, (t_max + 127) / 128, batch), dim3(512), 0, s, qk, vt, pos,
+                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad);
 }
 
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,

@@ -324,6 +324,18 @@ def test_specialised_attention_equals_one_wave_per_tile_kernel(setup, monkeypatc
         assert torch.equal(lp[i, :n], setup["lp"][i, :n])
 
 
+def test_two_heads_per_block_attention_equals_one_head_per_block(setup, monkeypatch):
+    """k_attention_ws<2 heads, 2 stages, 192-row ring> (the default) against <1 head, 3 stages, 256-row ring>
+    (QVERSE_ATT_HPB=1): the same wave program per (head, query tile), bit-identical log-probs on a ragged batch."""
+    monkeypatch.setenv("QVERSE_ATT_HPB", "1")
+    eng = setup["eng"]
+    lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
+    torch.cuda.synchronize()
+    assert t == setup["t"]
+    for i, n in enumerate(t):
+        assert torch.equal(lp[i, :n], setup["lp"][i, :n])
+
+
 def test_tiny_and_long_utterances_share_a_packed_batch(setup):
     """shortest legal clip (400 samples -> 1 encoder frame) next to long ones: packed rows of very
     different lengths, reference parity on every valid frame and exact batch invariance."""
