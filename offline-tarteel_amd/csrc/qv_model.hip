@@ -46,6 +46,19 @@ struct HostWeights {
         if (it == t.end()) { fprintf(stderr, "qverse: missing weight %s\n", n.c_str()); abort(); }
         return it->second;
     }
+    // A file converted from the reference's quantised ONNX (tools/convert_weights.py --onnx) says so with the marker
+    // tensor "qv.prequantised": its Linear weights are the dequantised MatMulNBits values (zero points included) and
+    // each int8 Conv weight comes with "<key>#int8_scale", the scale onnxruntime stored.  Such weights are never
+    // re-quantised: Linear layers run the values as they are (f16), precision 2 puts the Conv weights back on their
+    // integers with the FILE's scale.
+    bool prequantised() const {
+        auto it = t.find("qv.prequantised");
+        return it != t.end() && !it->second.empty() && it->second[0] != 0.f;
+    }
+    float int8_scale(const std::string &n) const {   // 0: none given (derive max|w| / 127)
+        auto it = t.find(n + "#int8_scale");
+        return it != t.end() && it->second.size() == 1 ? it->second[0] : 0.f;
+    }
 };
 
 struct Shape { std::string name; std::vector<int> dims; };
@@ -251,6 +264,7 @@ struct QvModel : QvActs {
     const float *zero_bias;
     bool w4;             // QV_PREC_MIXED_INT4_INT8 / QV_PREC_ORT_MIXED: Linear-layer weights are block-128 int4
     bool ort;            // QV_PREC_ORT_MIXED: every Conv runs DynamicQuantizeLinear -> ConvInteger (qv_ort.h)
+    bool prequant;       // the weight file is marked pre-quantised (HostWeights::prequantised): nothing is re-quantised
     OrtDw o_c0, o_dw2, o_dw5;
     OrtConv o_pw3, o_pw6, o_head;
     const float *o_dw2_b, *o_dw5_b;
@@ -307,7 +321,7 @@ std::vector<half_t> to_half(const std::vector<float> &v) {
 
 // upload a Linear weight [N][K]: f16, or int4 nibbles + scales when the model runs W4A16
 int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K, WMat *out) {
-    if (!m->w4) return up(eng, m, to_half(w), &out->w);
+    if (!m->w4 || m->prequant) return up(eng, m, to_half(w), &out->w);
     std::vector<uint8_t> q((size_t)N * K / 2, 0);
     std::vector<half_t> sc((size_t)N * (K / 128) * 2);
     qv_pack_w4(w.data(), N, K, q.data(), sc.data());
@@ -318,7 +332,7 @@ int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K
 // upload a pointwise-convolution weight [N][K]: f16, or per-channel int8 when the model runs mixed
 int up_mat8(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K, WMat *out) {
     if (m->ort) return QV_OK;   // (the A8W8 operands are prepared by up_ort_conv)
-    if (!m->w4) return up(eng, m, to_half(w), &out->w);
+    if (!m->w4 || m->prequant) return up(eng, m, to_half(w), &out->w);
     std::vector<uint8_t> q((size_t)N * K, 0);
     std::vector<float> sc((size_t)N);
     qv_pack_w8(w.data(), N, K, q.data(), sc.data());
@@ -348,10 +362,11 @@ void int4_quant_dequant(std::vector<float> &w, int N, int K) {
 
 // quantize_dynamic(weight_type = QInt8) on one Conv weight tensor: scale = max|w| / 127 (the division in double, the
 // result rounded to float32), q = saturate(round-half-even(w / scale)) -- oracle/fastconformer_ref.py::quantize_weight_int8
-float quant_w8_tensor(const std::vector<float> &w, std::vector<int8_t> &q) {
+// `given` > 0: the scale a pre-quantised file stored for this tensor (w = q * given exactly, so q comes back verbatim).
+float quant_w8_tensor(const std::vector<float> &w, std::vector<int8_t> &q, float given = 0.f) {
     float amax = 0.f;
     for (float v : w) amax = std::max(amax, fabsf(v));
-    const float sw = amax > 0.f ? (float)((double)amax / 127.0) : 1.0f;
+    const float sw = given > 0.f ? given : amax > 0.f ? (float)((double)amax / 127.0) : 1.0f;
     q.resize(w.size());
     for (size_t i = 0; i < w.size(); ++i) {
         float t = nearbyintf(w[i] / sw);   // default rounding mode: half to even
@@ -362,9 +377,10 @@ float quant_w8_tensor(const std::vector<float> &w, std::vector<int8_t> &q) {
 }
 
 // GEMM-shaped convolution weight [N][K] (rows past n_valid are zero padding): s8 row-major, row sums, scale
-int up_ort_conv(qv_engine *eng, QvModel *m, const std::vector<float> &w, int n_valid, int N, int K, OrtConv *out) {
+int up_ort_conv(qv_engine *eng, QvModel *m, const std::vector<float> &w, int n_valid, int N, int K, OrtConv *out,
+                float given = 0.f) {
     std::vector<int8_t> q;
-    out->scale = quant_w8_tensor(w, q);
+    out->scale = quant_w8_tensor(w, q, given);
     std::vector<int8_t> qp((size_t)N * K, 0);
     std::vector<int32_t> ws(N, 0);
     for (int n = 0; n < n_valid; ++n) {
@@ -377,9 +393,9 @@ int up_ort_conv(qv_engine *eng, QvModel *m, const std::vector<float> &w, int n_v
 }
 
 // depthwise weight [C][9]: integer-valued floats, tap-major [9][C]
-int up_ort_dw(qv_engine *eng, QvModel *m, const std::vector<float> &w, int C, OrtDw *out) {
+int up_ort_dw(qv_engine *eng, QvModel *m, const std::vector<float> &w, int C, OrtDw *out, float given = 0.f) {
     std::vector<int8_t> q;
-    out->scale = quant_w8_tensor(w, q);
+    out->scale = quant_w8_tensor(w, q, given);
     std::vector<float> t((size_t)C * 9);
     for (int c = 0; c < C; ++c)
         for (int k = 0; k < 9; ++k) t[(size_t)k * C + c] = (float)q[(size_t)c * 9 + k];
@@ -444,18 +460,19 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
     TRY(up(eng, m, to_half(hw.get(pe + "conv.6.weight")), &m->pw6_w));
     TRY(up(eng, m, hw.get(pe + "conv.6.bias"), &m->pw6_b));
     if (m->ort) {
-        TRY(up_ort_dw(eng, m, hw.get(pe + "conv.0.weight"), QV_SUBC, &m->o_c0));
-        TRY(up_ort_dw(eng, m, hw.get(pe + "conv.2.weight"), QV_SUBC, &m->o_dw2));
-        TRY(up_ort_dw(eng, m, hw.get(pe + "conv.5.weight"), QV_SUBC, &m->o_dw5));
-        TRY(up_ort_conv(eng, m, hw.get(pe + "conv.3.weight"), QV_SUBC, QV_SUBC, QV_SUBC, &m->o_pw3));
-        TRY(up_ort_conv(eng, m, hw.get(pe + "conv.6.weight"), QV_SUBC, QV_SUBC, QV_SUBC, &m->o_pw6));
-        TRY(up_ort_conv(eng, m, hw.get("ctc_decoder.decoder_layers.0.weight"), QV_VOCAB, HEAD_N, QV_D, &m->o_head));
+        TRY(up_ort_dw(eng, m, hw.get(pe + "conv.0.weight"), QV_SUBC, &m->o_c0, hw.int8_scale(pe + "conv.0.weight")));
+        TRY(up_ort_dw(eng, m, hw.get(pe + "conv.2.weight"), QV_SUBC, &m->o_dw2, hw.int8_scale(pe + "conv.2.weight")));
+        TRY(up_ort_dw(eng, m, hw.get(pe + "conv.5.weight"), QV_SUBC, &m->o_dw5, hw.int8_scale(pe + "conv.5.weight")));
+        TRY(up_ort_conv(eng, m, hw.get(pe + "conv.3.weight"), QV_SUBC, QV_SUBC, QV_SUBC, &m->o_pw3, hw.int8_scale(pe + "conv.3.weight")));
+        TRY(up_ort_conv(eng, m, hw.get(pe + "conv.6.weight"), QV_SUBC, QV_SUBC, QV_SUBC, &m->o_pw6, hw.int8_scale(pe + "conv.6.weight")));
+        TRY(up_ort_conv(eng, m, hw.get("ctc_decoder.decoder_layers.0.weight"), QV_VOCAB, HEAD_N, QV_D, &m->o_head,
+                        hw.int8_scale("ctc_decoder.decoder_layers.0.weight")));
     }
     {
         // Linear(2560 -> 512): NeMo flattens [C=256][F=10] as c*10+f; activations here are
         // channels-last [F][C], so permute K to f*256+c
         std::vector<float> w = hw.get(pe + "out.weight");
-        if (m->ort) {
+        if (m->ort && !m->prequant) {
             // MatMulNBits quantises along the ORIGINAL K order (blocks of 128 consecutive c*10+f); the permuted layout
             // no longer has those blocks, so this one Linear is quantised -> dequantised here and runs as an f16 GEMM
             // on exactly the values (q - 8) * scale
@@ -534,7 +551,7 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
             TRY(up_mat8(eng, m, pwm, 2 * QV_D, QV_D, &L.pw1_w));
             TRY(up(eng, m, pb, &L.pw1_b));
             // (one scale per tensor: the row permutation changes neither the scale nor the codes)
-            if (m->ort) TRY(up_ort_conv(eng, m, pwm, 2 * QV_D, 2 * QV_D, QV_D, &L.o_pw1));
+            if (m->ort) TRY(up_ort_conv(eng, m, pwm, 2 * QV_D, 2 * QV_D, QV_D, &L.o_pw1, hw.int8_scale(p + "conv.pointwise_conv1.weight")));
         }
         {
             // fold eval-mode BatchNorm into the depthwise conv
@@ -559,14 +576,16 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
                     al[c] = g[c] * (1.0f / sqrtf(var[c] + 1e-5f));
                     bt[c] = fmaf(-mu[c], al[c], be[c]);
                 }
-                TRY(up_ort_dw(eng, m, w, QV_D, &L.o_dw));
+                TRY(up_ort_dw(eng, m, w, QV_D, &L.o_dw, hw.int8_scale(p + "conv.depthwise_conv.weight")));
                 TRY(up(eng, m, b, &L.o_dw_b));
                 TRY(up(eng, m, al, &L.bn_alpha));
                 TRY(up(eng, m, bt, &L.bn_beta));
             }
         }
         TRY(up_mat8(eng, m, hw.get(p + "conv.pointwise_conv2.weight"), QV_D, QV_D, &L.pw2_w));
-        if (m->ort) TRY(up_ort_conv(eng, m, hw.get(p + "conv.pointwise_conv2.weight"), QV_D, QV_D, QV_D, &L.o_pw2));
+        if (m->ort)
+            TRY(up_ort_conv(eng, m, hw.get(p + "conv.pointwise_conv2.weight"), QV_D, QV_D, QV_D, &L.o_pw2,
+                            hw.int8_scale(p + "conv.pointwise_conv2.weight")));
         TRY(up(eng, m, hw.get(p + "conv.pointwise_conv2.bias"), &L.pw2_b));
     }
     TRY(up_mat(eng, m, posw, N_LAYERS * QV_D, QV_D, &m->pos_w));
@@ -684,6 +703,7 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out) {
     HostWeights hw;
     if (cfg->weights_path && cfg->weights_path[0]) TRY(load_weight_file(eng, cfg->weights_path, hw));
     else init_random(hw, cfg->random_weights_seed);
+    m->prequant = hw.prequantised();
     TRY(build_frontend(eng, m));
     TRY(prepare_weights(eng, m, hw));
     int B = cfg->max_batch;

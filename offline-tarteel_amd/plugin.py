@@ -29,6 +29,10 @@ CONFIDENCE_SKIP_THRESHOLD = 0.5  # c2c-direct-mixed-tta/run.py:57
 MAX_SAMPLES = int(os.getenv("QVERSE_MAX_SAMPLES", str(16000 * 60)))
 MAX_BATCH = int(os.getenv("QVERSE_MAX_BATCH", "16"))
 
+# QVERSE_PRECISION: "fp16" (default), "mixed" (the engine's own W4A16 / W8A16 kernels) or "ort" -- the arithmetic
+# onnxruntime runs on the reference's fastconformer_full_mixed.onnx (include/qverse.h QV_PREC_ORT_MIXED); with a weight
+# file converted from that ONNX (marked pre-quantised) "ort" computes on the file's own integers
+_PRECISIONS = {"fp16": 0, "mixed": 1, "ort": 2}
 _engine = None
 _last_raw: list[dict] = []   # engine-level dicts of the most recent predict_arrays() call (profile line)
 
@@ -53,8 +57,11 @@ def _ensure_engine():
     if wp is not None and not wp.exists():
         raise FileNotFoundError(f"No weight file at {wp}. Run `python tools/convert_weights.py` first.")
     device = int(os.getenv("LOCAL_RANK", "0"))
-    print(f"[c2c-direct-mixed/qverse] loading {'synthetic weights' if wp is None else wp.name} on cuda:{device}...")
-    _engine = Engine(device=device, with_model=True, weights_path=str(wp) if wp else None,
+    prec_name = os.getenv("QVERSE_PRECISION", "fp16")
+    if prec_name not in _PRECISIONS:
+        raise ValueError(f"QVERSE_PRECISION={prec_name!r}: expected one of {sorted(_PRECISIONS)}")
+    print(f"[c2c-direct-mixed/qverse] loading {'synthetic weights' if wp is None else wp.name} on cuda:{device} ({prec_name})...")
+    _engine = Engine(device=device, with_model=True, weights_path=str(wp) if wp else None, precision=_PRECISIONS[prec_name],
                      max_batch=MAX_BATCH, max_samples=MAX_SAMPLES)
     if _PROFILE:
         _engine.profile_stages(True)

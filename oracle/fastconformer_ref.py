@@ -268,9 +268,13 @@ def quantize_weight_int8(wt: torch.Tensor):
 class OrtMixed:
     """Routing of the model's Linear / Conv calls through the onnxruntime arithmetic above."""
 
-    def __init__(self, int4_linears: bool = True, int8_convs="all"):
+    def __init__(self, int4_linears: bool = True, int8_convs="all", conv_scales: dict | None = None):
+        """int4_linears=False + conv_scales={weight name: float32 scale}: the weights handed to forward() are the
+        DEQUANTISED contents of an already quantised model file (MatMulNBits values used as they are; each Conv weight
+        put back on its integers with the file's own scale) -- what tools/convert_weights.py --onnx produces."""
         self.int4_linears = int4_linears
         self.int8_convs = int8_convs          # "all", or a tuple of weight-name suffixes, or ()
+        self.conv_scales = dict(conv_scales or {})
         self._w4 = {}
         self._w8 = {}
 
@@ -294,7 +298,11 @@ class OrtMixed:
         if not self._is_conv8(name):
             return fn(x, wt, bias, **kw)
         if name not in self._w8:
-            self._w8[name] = quantize_weight_int8(wt)
+            if name in self.conv_scales:
+                sw = np.float32(self.conv_scales[name])
+                self._w8[name] = (torch.clamp(torch.round(wt / float(sw)), -127, 127).to(torch.float64), sw)
+            else:
+                self._w8[name] = quantize_weight_int8(wt)
         wq, sw = self._w8[name]
         outs = []
         for b in range(x.shape[0]):

@@ -1,6 +1,6 @@
 """tools/onnx_reader.py + the --onnx leg of tools/convert_weights.py on synthetic ONNX models.
 
-The models are written by the small protobuf encoder below (independent of the reader: it only
+The models are written by the small protobuf encoder in tests/synth_onnx.py (independent of the reader: it only
 shares the public onnx.proto field numbers), in the storage forms the reference's
 fastconformer_full_mixed.onnx is described to use: MatMulNBits int4 blocks (with default and with
 packed zero points), int8 tensors behind DequantizeLinear, ConvInteger weights written by dynamic
@@ -25,81 +25,7 @@ def _load(name):
     return mod
 
 
-# ------------------------------------------------------------------ tiny protobuf writer --
-def vint(v):
-    v &= (1 << 64) - 1
-    out = bytearray()
-    while True:
-        b = v & 0x7F
-        v >>= 7
-        out.append(b | (0x80 if v else 0))
-        if not v:
-            return bytes(out)
-
-
-def key(num, wt):
-    return vint(num << 3 | wt)
-
-
-def ld(num, payload):
-    return key(num, 2) + vint(len(payload)) + payload
-
-
-def tensor(name, arr, how="raw"):
-    code = {np.dtype(np.float32): 1, np.dtype(np.uint8): 2, np.dtype(np.int8): 3, np.dtype(np.float16): 10,
-            np.dtype(np.int64): 7}[arr.dtype]
-    out = b"".join(key(1, 0) + vint(d) for d in arr.shape) + key(2, 0) + vint(code)
-    if how == "raw":
-        out += ld(9, arr.astype(arr.dtype.newbyteorder("<")).tobytes())
-    elif how == "float_data":                       # packed repeated float
-        out += ld(4, arr.astype("<f4").tobytes())
-    elif how == "int32_data":                       # fp16 bit patterns / small ints, packed varints
-        vals = arr.view(np.uint16).ravel() if arr.dtype == np.float16 else arr.ravel()
-        out += ld(5, b"".join(vint(int(v)) for v in vals))
-    return out + ld(8, name.encode())
-
-
-def attr_t(name, tensor_bytes):
-    return ld(1, name.encode()) + ld(5, tensor_bytes) + key(20, 0) + vint(4)
-
-
-def attr_i(name, v):
-    return ld(1, name.encode()) + key(3, 0) + vint(v) + key(20, 0) + vint(2)
-
-
-def node(op, name, inputs, outputs, attrs=()):
-    out = b"".join(ld(1, i.encode()) for i in inputs) + b"".join(ld(2, o.encode()) for o in outputs)
-    out += ld(3, name.encode()) + ld(4, op.encode())
-    return out + b"".join(ld(5, a) for a in attrs)
-
-
-def model(nodes, inits):
-    graph = b"".join(ld(1, n) for n in nodes) + ld(2, b"g") + b"".join(ld(5, t) for t in inits)
-    return key(1, 0) + vint(8) + ld(2, b"test") + ld(7, graph)
-
-
-def pack_nbits(w, bs, with_zp):
-    """block-wise 4-bit quantisation in MatMulNBits layout; returns (B, scales, zp_packed | None, dequantised)."""
-    N, K = w.shape
-    nb = K // bs
-    blocks = w.reshape(N, nb, bs)
-    if with_zp:
-        lo, hi = blocks.min(-1, keepdims=True), blocks.max(-1, keepdims=True)
-        scale = np.maximum((hi - lo) / 15.0, 1e-8).astype(np.float32)
-        zp = np.clip(np.rint(-lo / scale), 0, 15)
-    else:
-        scale = np.maximum(np.abs(blocks).max(-1, keepdims=True) / 7.0, 1e-8).astype(np.float32)
-        zp = np.full_like(scale, 8.0)
-    q = np.clip(np.rint(blocks / scale + zp), 0, 15).astype(np.uint8)
-    B = (q[:, :, 0::2] | (q[:, :, 1::2] << 4)).astype(np.uint8)
-    deq = ((q.astype(np.float32) - zp) * scale).reshape(N, K)
-    zpp = None
-    if with_zp:
-        z = zp.reshape(N, nb).astype(np.uint8)
-        if nb % 2:
-            z = np.concatenate([z, np.zeros((N, 1), np.uint8)], 1)
-        zpp = (z[:, 0::2] | (z[:, 1::2] << 4)).astype(np.uint8)
-    return B, scale.reshape(-1), zpp, deq
+from synth_onnx import attr_i, attr_t, key, ld, model, node, pack_nbits, tensor, vint  # noqa: E402,F401  (the protobuf writer)
 
 
 def test_wire_primitives_and_tensor_encodings(tmp_path):
@@ -279,3 +205,53 @@ def test_dynamic_quantised_conv_with_bias_behind_add_and_valueless_attribute(tmp
     assert np.array_equal(sd[L + "conv.pointwise_conv2.bias"], bias)
     # Gemm without transB holds [in, out]: transposed to the state-dict's [out, in]
     assert np.array_equal(sd[L + "feed_forward1.linear1.weight"], gw) and np.array_equal(sd[L + "feed_forward1.linear1.bias"], gb)
+
+
+def test_export_like_model_keeps_the_files_own_quantisation(tmp_path):
+    """A model written the way the reference's export is described (tests/synth_onnx.py::export_like_model: torch-export
+    scopes, anonymous MatMulNBits operands WITH zero points, DynamicQuantizeLinear -> ConvInteger -> Cast -> Mul -> Add
+    chains with the bias behind the Add, the STFT front-end baked in) through the converter: every tensor placed, the
+    values are the file's integers multiplied out, the int8 scales travel verbatim, the file is marked pre-quantised,
+    and the oracle's precision-2 routing puts a Conv weight back on exactly the file's integers."""
+    import torch
+    from synth_onnx import LINEAR_TAILS, export_like_model
+
+    C = _load("convert_weights")
+    lib = C._lib()
+    full = C.weight_shapes(lib)
+    w_all = C.random_weights(lib, full, 11)
+    keep = [k for k in full if "encoder.layers." not in k or ".layers.0." in k or ".layers.16." in k]
+    shapes = {k: full[k] for k in keep}
+    p = tmp_path / "export_like.onnx"
+    deq, scales = export_like_model({k: w_all[k] for k in keep}, p)
+    sd, meta = C.onnx_state_dict(str(p), shapes, verbose=False, with_meta=True)
+    assert set(sd) == set(shapes)
+    for k in shapes:
+        assert np.array_equal(sd[k], deq[k].reshape(shapes[k])), k
+    lin = [k for k in shapes if k.endswith(LINEAR_TAILS)]
+    conv = [k for k in shapes if k.endswith(".weight") and (len(shapes[k]) >= 3 or k.startswith("ctc_decoder"))]
+    assert len(lin) == 2 * 9 + 1 and len(conv) == 5 + 2 * 3 + 1
+    assert all(meta[k]["kind"] == "int4" for k in lin)
+    assert all(meta[k]["kind"] == "int8" and meta[k]["scale"] == scales[k] and meta[k]["zero_point"] == 0 for k in conv)
+    assert set(meta) == set(lin) | set(conv)
+    # the int4 blocks really are asymmetric: the engine's own symmetric packing could not hold them
+    from oracle import fastconformer_ref as R
+    k0 = "encoder.layers.0.feed_forward1.linear1.weight"
+    assert np.abs(R.quant_dequant_int4_f32scale(deq[k0]) - deq[k0]).max() > 1e-4
+    extra = C.prequantised_extras(meta)
+    assert extra[C.PREQUANT_KEY].tolist() == [1.0] and len(extra) == 1 + len(conv)
+    out = tmp_path / "w.qvw"
+    C.write_qvw(out, {k: sd[k] for k in shapes}, extra)
+    raw = out.read_bytes()
+    assert struct.unpack("<I", raw[8:12])[0] == len(shapes) + len(extra)
+    for k in conv:
+        assert (k + C.SCALE_SUFFIX).encode() in raw
+    # oracle: with the file's scale the weight integers come back verbatim (and without it they need not)
+    ops = R.OrtMixed(int4_linears=False, conv_scales=scales)
+    kc = "encoder.layers.0.conv.pointwise_conv1.weight"
+    wt = {kc: torch.from_numpy(deq[kc])}
+    ops.conv(wt, kc, torch.zeros(1, 512, 4), None, torch.nn.functional.conv1d)
+    q_file = np.rint(deq[kc] / scales[kc])
+    assert np.array_equal(ops._w8[kc][0].numpy(), q_file) and ops._w8[kc][1] == scales[kc]
+    x = torch.ones(2, 512)
+    assert torch.equal(ops.linear({k0: torch.from_numpy(deq[k0])}, k0, x, None), torch.nn.functional.linear(x, torch.from_numpy(deq[k0])))

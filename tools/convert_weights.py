@@ -16,9 +16,11 @@ ctc_decoder.decoder_layers.0.*), the same the engine's seeded init uses
 
 ``--onnx`` reads the reference's own weight format without onnx/onnxruntime (tools/onnx_reader.py):
 MatMulNBits int4 blocks, DequantizeLinear'ed and ConvInteger/MatMulInteger int8 tensors are
-dequantised to float32 (the engine then stores them as fp16, or re-quantises the Linear layers to
-its own block-128 int4 with ``precision=1``); ORT's dynamic activation quantisation of the Conv
-nodes stays a documented numerical difference.  Tensors are matched to the NeMo state-dict keys by
+dequantised to float32 and the file is MARKED pre-quantised (``qv.prequantised`` plus one
+``<key>#int8_scale`` per int8 Conv weight): the engine then never re-quantises -- with
+``precision=2`` (the reference's onnxruntime arithmetic) the Conv weights go back onto the file's
+own integers with the file's own scale, and the Linear weights run as the dequantised values
+(MatMulNBits zero points included); ``precision=0/1`` run the same values in fp16.  Tensors are matched to the NeMo state-dict keys by
 initializer name, else by the scope of the node that consumes them
 ("/encoder/layers.0/feed_forward1/linear1/MatMul" -> encoder.layers.0.feed_forward1.linear1.weight);
 ``--map`` ({"nemo key": "onnx key"}) overrides, ``--list`` prints every candidate with its shape.
@@ -42,7 +44,12 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def write_qvw(path, tensors: dict):
+PREQUANT_KEY = "qv.prequantised"       # marker tensor: the file's weights already sit on their quantisation grids
+SCALE_SUFFIX = "#int8_scale"           # "<NeMo key>#int8_scale": the per-tensor scale of an int8 Conv weight, verbatim
+
+
+def write_qvw(path, tensors: dict, extra: dict | None = None):
+    tensors = dict(tensors, **(extra or {}))
     with open(path, "wb") as f:
         f.write(b"QVWT0001")
         f.write(struct.pack("<I", len(tensors)))
@@ -113,15 +120,16 @@ def _fit(arr: np.ndarray, shape):
     return None
 
 
-def onnx_state_dict(path, shapes: dict, name_map: dict | None = None, verbose: bool = True) -> dict:
-    """NeMo-keyed float32 tensors from an ONNX file (see the module docstring)."""
+def onnx_state_dict(path, shapes: dict, name_map: dict | None = None, verbose: bool = True, with_meta: bool = False):
+    """NeMo-keyed float32 tensors from an ONNX file (see the module docstring).  with_meta: also
+    {NeMo key: onnx_reader meta} for the tensors that came out of a quantised storage form."""
     sys.path.insert(0, str(Path(__file__).resolve().parent))
     import onnx_reader as O
 
     nodes, inits = O.read_model(path)
     fw = O.float_weights(nodes, inits)
     name_map = name_map or {}
-    out, missing = {}, []
+    out, missing, meta = {}, [], {}
     for name, shape in shapes.items():
         cands = []
         if name in name_map:
@@ -145,6 +153,8 @@ def onnx_state_dict(path, shapes: dict, name_map: dict | None = None, verbose: b
             if c in fw:
                 got = _fit(fw[c][0], shape)
                 if got is not None:
+                    if fw[c][2] is not None:
+                        meta[name] = fw[c][2]
                     break
         if got is None:
             missing.append(name)
@@ -162,7 +172,19 @@ def onnx_state_dict(path, shapes: dict, name_map: dict | None = None, verbose: b
     if missing:
         raise SystemExit("cannot place these tensors (use --list and --map):\n  " + "\n  ".join(missing[:40]) +
                          (f"\n  ... and {len(missing) - 40} more" if len(missing) > 40 else ""))
-    return out
+    return (out, meta) if with_meta else out
+
+
+def prequantised_extras(meta: dict) -> dict:
+    """The extra tensors that tell the engine the file's weights are ALREADY quantised (precision 1 / 2 then never
+    re-quantise them: Linear weights run as the dequantised values -- MatMulNBits blocks may carry zero points the
+    engine's own symmetric int4 packing cannot express --, int8 Conv weights are put back on their integers with the
+    file's scale instead of a re-derived max|w| / 127)."""
+    extra = {PREQUANT_KEY: np.ones(1, np.float32)}
+    for name, m in meta.items():
+        if m.get("kind") == "int8":
+            extra[name + SCALE_SUFFIX] = np.array([m["scale"]], np.float32)
+    return extra
 
 
 def main():
@@ -182,8 +204,9 @@ def main():
         import onnx_reader as O
 
         nodes, inits = O.read_model(args.onnx)
-        for k, (a, how) in sorted(O.float_weights(nodes, inits).items()):
-            print(f"{k}  {tuple(a.shape)}  [{how}]")
+        for k, (a, how, meta) in sorted(O.float_weights(nodes, inits).items()):
+            q = "" if meta is None else ("  int4 blocks" if meta["kind"] == "int4" else f"  int8 scale {meta['scale']:.9g} zp {meta['zero_point']}")
+            print(f"{k}  {tuple(a.shape)}  [{how}]{q}")
         ops = {}
         for n in nodes:
             ops[n.op] = ops.get(n.op, 0) + 1
@@ -194,9 +217,13 @@ def main():
     if args.onnx:
         import json
 
-        sd_np = onnx_state_dict(args.onnx, shapes, json.loads(Path(args.map).read_text()) if args.map else None)
-        write_qvw(args.out, {k: sd_np[k] for k in shapes})
-        print(f"wrote {args.out}: {len(shapes)} tensors from {args.onnx}")
+        sd_np, meta = onnx_state_dict(args.onnx, shapes, json.loads(Path(args.map).read_text()) if args.map else None,
+                                      with_meta=True)
+        extra = prequantised_extras(meta) if meta else {}
+        write_qvw(args.out, {k: sd_np[k] for k in shapes}, extra)
+        n4 = sum(1 for m in meta.values() if m["kind"] == "int4")
+        print(f"wrote {args.out}: {len(shapes)} tensors from {args.onnx}" +
+              (f" ({n4} int4 MatMulNBits, {len(extra) - 1} int8 tensors with their scales; marked pre-quantised)" if extra else ""))
         return
     if args.random is not None:
         write_qvw(args.out, random_weights(lib, shapes, args.random))

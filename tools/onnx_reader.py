@@ -224,7 +224,10 @@ def dequant_linear(x: np.ndarray, scale: np.ndarray, zp, axis: int = 1) -> np.nd
 
 def float_weights(nodes, inits):
     """Every weight-like tensor of the graph as float32, keyed by a name that identifies its
-    module: {key: (array, how)}.  Keys are the initializer names for float initializers (with the
+    module: {key: (array, how, meta)}; meta is None for float tensors, {"kind": "int4"} for MatMulNBits blocks and
+    {"kind": "int8", "scale": float32, "zero_point": int} for a per-tensor int8 tensor (what onnxruntime's
+    quantize_dynamic writes for Conv weights) -- the converter hands these to the engine so that its precision-2 path
+    reproduces the file's integers instead of re-deriving a scale.  Keys are the initializer names for float initializers (with the
     quantisation suffixes stripped for dequantised ones) and additionally the scope of the
     consuming node ("/encoder/layers.0/feed_forward1/linear1/MatMul" -> "encoder.layers.0.
     feed_forward1.linear1") for anonymous MatMul operands."""
@@ -235,7 +238,7 @@ def float_weights(nodes, inits):
             inits.setdefault(n.outputs[0], n.attrs["value"])
     for name, a in inits.items():
         if a.dtype in (np.float32, np.float16, np.float64):
-            out[name] = (a.astype(np.float32), "float initializer")
+            out[name] = (a.astype(np.float32), "float initializer", None)
     named = _named(out)
     for n in nodes:
         scope = n.name.strip("/").rsplit("/", 1)[0].replace("/", ".") if "/" in n.name.strip("/") else ""
@@ -246,18 +249,18 @@ def float_weights(nodes, inits):
                 a = w[0]
                 if n.op == "Gemm" and not int(n.attrs.get("transB", 0)):
                     a = a.T                                   # Gemm without transB holds [in, out]
-                out[scope + ".weight"] = (a, f"{n.op} operand named by its node scope")
+                out[scope + ".weight"] = (a, f"{n.op} operand named by its node scope", w[2])
             if len(n.inputs) > 2 and n.inputs[2] in out and n.inputs[2] not in named:
-                out[scope + ".bias"] = (out[n.inputs[2]][0], f"{n.op} bias named by its node scope")
+                out[scope + ".bias"] = (out[n.inputs[2]][0], f"{n.op} bias named by its node scope", None)
         if n.op == "MatMulNBits":
             w = dequant_matmul_nbits(n, inits)
             for key in {scope, _strip(n.inputs[1])} - {""}:
-                out[key] = (w, "MatMulNBits [out, in]")
+                out[key] = (w, "MatMulNBits [out, in]", {"kind": "int4"})
         elif n.op == "DequantizeLinear" and n.inputs[0] in inits:
             zp = inits.get(n.inputs[2]) if len(n.inputs) > 2 and n.inputs[2] else None
             w = dequant_linear(inits[n.inputs[0]], inits[n.inputs[1]], zp, int(n.attrs.get("axis", 1)))
             for key in {_strip(n.inputs[0]), n.outputs[0]}:
-                out[key] = (w, "DequantizeLinear")
+                out[key] = (w, "DequantizeLinear", None)
         elif n.op in ("ConvInteger", "MatMulInteger") and n.inputs[1] in inits:
             base = _strip(n.inputs[1])
             scale = inits.get(base + "_scale")
@@ -265,9 +268,14 @@ def float_weights(nodes, inits):
                 continue
             zp = inits.get(n.inputs[3]) if len(n.inputs) > 3 and n.inputs[3] else inits.get(base + "_zero_point")
             w = dequant_linear(inits[n.inputs[1]], scale, zp, 0 if n.op == "ConvInteger" else 1)
+            meta = None
+            if np.asarray(scale).size == 1:
+                meta = {"kind": "int8", "scale": np.float32(np.asarray(scale, np.float32).reshape(-1)[0]),
+                        "zero_point": int(np.asarray(zp).reshape(-1)[0]) if zp is not None else 0}
             keys = {base} | ({scope, scope + ".weight"} if scope else set())
             for key in keys:
-                out[key] = (w if n.op == "ConvInteger" else w.T, n.op + (" (transposed to [out, in])" if n.op != "ConvInteger" else ""))
+                out[key] = (w if n.op == "ConvInteger" else w.T,
+                            n.op + (" (transposed to [out, in])" if n.op != "ConvInteger" else ""), meta)
             # the bias of a dynamically quantised Conv / MatMul is an anonymous initializer added AFTER the
             # integer op and its rescaling: ConvInteger -> Cast -> Mul(scales) -> Add(bias).  Follow the single-
             # consumer chain of cheap elementwise nodes to that Add and name its constant operand.
@@ -283,13 +291,13 @@ def float_weights(nodes, inits):
                         if other and other[0] in inits and np.asarray(inits[other[0]]).dtype in (np.float32, np.float16, np.float64):
                             b = np.asarray(inits[other[0]], np.float32).reshape(-1)
                             if b.size == w.shape[0] or (n.op == "MatMulInteger" and b.size == w.shape[1]):
-                                out[scope + ".bias"] = (b, f"bias added behind {n.op} (Add operand named by the node scope)")
+                                out[scope + ".bias"] = (b, f"bias added behind {n.op} (Add operand named by the node scope)", None)
                         break
                     if u.op not in ("Cast", "Mul", "Reshape", "Identity"):
                         break
                     cur, hops = u.outputs[0], hops + 1
         elif n.op == "MatMul" and scope and len(n.inputs) > 1 and n.inputs[1] in out and n.inputs[1] not in _named(out):
-            out[scope] = (out[n.inputs[1]][0].T, "MatMul operand [in, out] transposed to [out, in]")
+            out[scope] = (out[n.inputs[1]][0].T, "MatMul operand [in, out] transposed to [out, in]", None)
     return out
 
 

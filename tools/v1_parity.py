@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """v1-corpus parity of the drop-in plugins against the reference's published per-sample outputs.
 
-    QVERSE_WEIGHTS=/path/to/weights.qvwt python tools/v1_parity.py --corpus /path/to/benchmark/test_corpus \
+    python tools/convert_weights.py --onnx fastconformer_full_mixed.onnx --out weights.qvwt
+    QVERSE_WEIGHTS=weights.qvwt python tools/v1_parity.py --corpus /path/to/benchmark/test_corpus \
         [--experiment c2c-direct-mixed | c2c-direct-mixed-tta] [--batch 1] [--score-slack 1e-2] [--out report.json]
+
+(QVERSE_PRECISION defaults to "ort" here: onnxruntime's arithmetic on the file's own integers.)
 
 Runs this repo's runner (offline-tarteel_amd/benchmark/runner.py, the reference's CLI and scoring) on the
 53-sample v1 manifest and compares every row with tests/golden/v1_expected.json (the reference's
@@ -83,6 +86,8 @@ def main(argv=None) -> int:
     if corpus is None or not (corpus / "manifest.json").exists():
         print("v1_parity: SKIPPED -- --corpus / QVERSE_CORPUS_DIR must point at the reference's benchmark/test_corpus")
         return SKIP
+    # the published rows came out of onnxruntime on the quantised file: compare with that arithmetic unless told otherwise
+    os.environ.setdefault("QVERSE_PRECISION", "ort")
     import offline_tarteel_amd  # noqa: F401
     from offline_tarteel_amd.benchmark import runner
 
