@@ -8,12 +8,14 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final
 mkdir -p "$O"
 cd "$R"
-timeout 900 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; tail -n 2 "$O/tests.log"
+timeout 1200 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; tail -n 2 "$O/tests.log"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -n 1 "$O/smoke.log"
-timeout 400 python bench.py > "$O/bench.json" 2> "$O/bench.err"; cut -c1-170 "$O/bench.json"
+timeout 600 python bench.py > "$O/bench.json" 2> "$O/bench.err"; cut -c1-170 "$O/bench.json"
 timeout 300 python bench.py --contexts 1 --no-cpu-baseline > "$O/bench_contexts1.json" 2>/dev/null; cut -c1-170 "$O/bench_contexts1.json"
 timeout 300 python bench.py --batch 256 --precision mixed --steps 20 --no-cpu-baseline > "$O/bench_cfg2_b256_mixed.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_mixed.json"
 timeout 300 python bench.py --batch 256 --steps 20 --no-cpu-baseline > "$O/bench_b256_fp16.json" 2>/dev/null; cut -c1-170 "$O/bench_b256_fp16.json"
+timeout 300 python bench.py --precision ort --steps 30 --no-cpu-baseline --no-extra > "$O/bench_b64_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_b64_ort.json"
+timeout 300 python bench.py --batch 256 --precision ort --steps 12 --no-cpu-baseline --no-extra > "$O/bench_cfg2_b256_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_ort.json"
 timeout 300 python bench.py --workload tta30 --steps 6 --warmup 2 --no-cpu-baseline > "$O/bench_tta30.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30.json"
 timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; tail -n 3 "$O/sweep.log" | cut -c1-200
 timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench.jsonl"
@@ -23,6 +25,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof3" -o p -- python "$R/bench.py" --steps 20 --no-cpu-baseline --no-post-logits > "$O/bench_under_rocprof.json" 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof1" -o p -- python "$R/bench.py" --steps 20 --contexts 1 --no-cpu-baseline --no-post-logits > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/profpost" -o p -- python "$R/tools/post_bench.py" --steps 5 > /dev/null 2>&1
+for prec in fp16 mixed ort; do   # B = 256 (configs[2] / the per-rank slice of configs[3]), one batch at a time: which kernels the step is made of
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b256_$prec" -o p -- python "$R/bench.py" --precision $prec --batch 256 --steps 8 --warmup 2 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
+done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b64_ort" -o p -- python "$R/bench.py" --precision ort --steps 16 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 cd "$R"
 find "$O" -name "*_kernel_trace.csv" -path "*prof*" -delete   # the traces are large; the stats are what is kept
 bash tools/pmc_round.sh ${1:-final} 8064 > /dev/null 2>&1
