@@ -236,13 +236,21 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
                                                const float *__restrict__ b0, const int32_t *__restrict__ len1,
                                                const float *__restrict__ w1t, const float *__restrict__ b1,
                                                half_t *__restrict__ out, int t2_max) {
-    __shared__ float rows[SUB_RM][QV_NMEL + 2];
+    __shared__ __attribute__((aligned(16))) float rows[SUB_RM][QV_NMEL + 2];
     __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
     __shared__ __attribute__((aligned(16))) half_t tile[SUB_R1][40][SUB_CG];
     const int b = blockIdx.z, t2_0 = blockIdx.y * SUB_TT, cg = blockIdx.x * SUB_CG, tid = threadIdx.x;
     const int tin = len_mel[b], l1 = len1[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
     if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
+    // the second convolution's taps + bias (10 x 64 floats) are requested now, one quad per thread, and parked in the
+    // mel-row buffer once conv0 has finished with it: fetched after conv0 they were a global latency in the middle of
+    // every block (and a buffer of their own would cost the third block per CU)
+    static_assert(10 * (SUB_CG / 4) <= 256 - 96 && 10 * SUB_CG <= SUB_RM * (QV_NMEL + 2), "w1 staging");
+    float (*w1s)[SUB_CG] = (float (*)[SUB_CG]) & rows[0][0];
+    f32x4 w1q = {0.f, 0.f, 0.f, 0.f};
+    const int w1k = (tid - 96) / (SUB_CG / 4), w1c = ((tid - 96) % (SUB_CG / 4)) * 4;
+    if (tid >= 96) w1q = *(const f32x4 *)((w1k < 9 ? w1t + w1k * QV_SUBC : b1) + cg + w1c);
     __syncthreads();
     const int t1_0 = 2 * t2_0 - 1;         // first c0 row of the tile
     const int tm_0 = 2 * t1_0 - 1;         // first mel row
@@ -289,8 +297,20 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
         }
         *(half8 *)&tile[r][f1][c8] = o;
     }
-    load_w(w1t, b1);
+    __syncthreads();            // conv0 done: the tile is complete, the mel rows are dead
+    if (tid >= 96) *(f32x4 *)&w1s[w1k][w1c] = w1q;
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const f32x4 wa = *(const f32x4 *)&w1s[k][c8], wb = *(const f32x4 *)&w1s[k][c8 + 4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = wa[c]; w[k][4 + c] = wb[c]; }
+    }
+    {
+        const f32x4 ba = *(const f32x4 *)&w1s[9][c8], bb = *(const f32x4 *)&w1s[9][c8 + 4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
+    }
     // ---- depthwise 3x3 stride 2 over the tile
     for (int p = pl; p < SUB_TT * 20; p += 32) {
         int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
