@@ -221,7 +221,7 @@ struct QvCtx {
     // stage timers (qv_profile_stages): start, forward done, decode done, build done, rerank done
     hipEvent_t stage_ev[5];
     bool stage_valid;
-    // the post-logits chain (k_init_utts .. k_result, 15 kernels) as ONE hipGraph launch, keyed by what the kernel
+    // the post-logits chain (k_decode .. k_result, 13 kernels) as ONE hipGraph launch, keyed by what the kernel
     // arguments depend on; captured the first time a key is seen on this context
     struct PostGraph { const float *lp; int batch, t_max; hipGraphExec_t exec; } post_graph[4];
     int n_post_graph;

@@ -1703,7 +1703,7 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
     };
     // One graph launch for the whole chain when its arguments are the ones a graph was captured with: the
     // engine's own log-prob workspace (qv_predict_batch*), same batch and frame count -- the steady state of a
-    // serving loop.  Everything the 15 kernels decide per utterance (gate, candidate counts, leaders) is read
+    // serving loop.  Everything the 13 kernels decide per utterance (gate, candidate counts, leaders) is read
     // from device memory, so a replay is the same work as the launches it was captured from.  Caller-owned
     // log-prob tensors (pointer changes per call), profiled runs and single-context engines (the chain then runs
     // on the CALLER's stream, which may be the legacy default stream -- not capturable) take the plain launches.
