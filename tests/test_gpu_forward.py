@@ -385,3 +385,21 @@ def test_post_logits_chain_as_one_graph_launch_is_identical():
         assert p.returncode == 0, p.stderr[-2000:]
         res.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert res[0] == res[1] and all(r == res[0][0] for r in res[0])
+
+
+def test_digital_silence_is_finite_and_batch_invariant(setup):
+    """An all-zero clip: every mel frame is the same constant, the per-feature std is 0 and the normalisation divides
+    by 0 + 1e-5.  The device keeps the statistics in f64, so x - mean is exactly 0 and the features are zeros (a float32
+    sum leaves O(1) rounding noise there instead -- no oracle comparison is meaningful on this input); what must hold:
+    finite log-probs that sum to one, the same bits alone and inside a batch, and a result from the whole path."""
+    eng = setup["eng"]
+    lens = [32000, 32000]
+    a = torch.from_numpy(synth_audio(2, 32000, seed=3))
+    a[1] = 0
+    lp, t = eng.forward(a.cuda().contiguous(), lens)
+    assert bool(torch.isfinite(lp[1, : t[1]]).all())
+    assert torch.allclose(lp[1, : t[1]].exp().sum(-1).cpu(), torch.ones(t[1]), atol=1e-4)
+    one, t1 = eng.forward(a[1:2].cuda().contiguous(), [lens[1]])
+    assert t1[0] == t[1] and torch.equal(one[0, : t1[0]], lp[1, : t[1]])
+    res = eng.predict_batch(a.cuda().contiguous(), lens)
+    assert len(res) == 2 and res[1]["t_frames"] == t[1]

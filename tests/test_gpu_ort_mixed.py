@@ -264,3 +264,45 @@ def test_prequantised_file_in_the_export_form_runs_on_its_own_integers(tmp_path)
     print(f"[ort-prequant] marked file vs oracle: max {mx:.4f} rms {rms:.5f}; unmarked (re-quantised): max {mx_p:.4f} rms {rms_p:.5f}")
     assert mx <= 0.2 and rms <= 0.03, (mx, rms)
     assert rms_p > 1.5 * rms, (rms_p, rms)
+
+
+def test_edge_shapes_one_frame_thirty_seconds_and_silence():
+    """precision 2 on the shapes the fp16 path is tested on: the shortest legal clip (400 samples -> 1 encoder frame:
+    every per-utterance range is taken over a handful of values), a 30 s clip (T = 376: several query groups, the long
+    CTC kernel), an all-zero clip (degenerate ranges: scale 0 -> the ONNX rule x_q = 0, zero point 0) and a near-silent
+    one -- ragged in one batch, against each utterance run alone (exact) and against the oracle (noise-floor bound).
+    Exact digital silence is NOT compared with the oracle: every mel frame is the same constant, the per-feature std is 0
+    and (x - mean) / (0 + 1e-5) amplifies the rounding of the MEAN by 1e5 -- zero here (f64 statistics), O(1) noise in
+    the oracle's float32 sum; no two implementations agree there, the reference's included."""
+    from offline_tarteel_amd.engine import Engine
+    from oracle import fastconformer_ref as R
+
+    lens = [400, 480000, 16000, 48000, 16000]
+    audio = torch.from_numpy(synth_audio(5, 480000, seed=91))
+    for b, n in enumerate(lens):
+        audio[b, n:] = 0
+    audio[2] = 0                                         # silence
+    audio[4, :16000] *= 1e-3                             # near silence
+    eng = Engine(device=0, with_model=True, seed=SEED, precision=2, max_batch=5, max_samples=480000)
+    try:
+        a = audio.cuda().contiguous()
+        lp, T = eng.forward(a, lens)
+        torch.cuda.synchronize()
+        assert T == [1, 376, 13, 38, 13]
+        assert all(bool(torch.isfinite(lp[b, : T[b]]).all()) for b in range(5))
+        for b in range(5):
+            one, t1 = eng.forward(a[b: b + 1, : lens[b]].contiguous(), [lens[b]])
+            assert t1[0] == T[b] and torch.equal(one[0, : T[b]], lp[b, : T[b]]), b
+        w = R.random_weights(SEED)
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        for b in (0, 4, 3, 1):
+            ref, tr = R.forward(w, audio[b: b + 1, : lens[b]].contiguous(), [lens[b]], ort=R.OrtMixed())
+            assert int(tr[0]) == T[b]
+            d = lp[b, : T[b]].cpu() - ref[0, : T[b]]
+            mx, rms = float(d.abs().max()), float(d.pow(2).mean().sqrt())
+            print(f"[ort-edge] utt {b} (T = {T[b]}): max {mx:.4f} rms {rms:.5f}")
+            assert mx <= 0.25 and rms <= 0.04, (b, mx, rms)
+        res = eng.predict_batch(a, lens)
+        assert [r["t_frames"] for r in res] == T
+    finally:
+        eng.close()
