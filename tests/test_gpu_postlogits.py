@@ -264,3 +264,86 @@ def test_text_weight_fixtures(golden_dir):
                 assert abs(r["score"] - c["winner_score_raw"]) <= 1e-3 * max(c["winner_score_raw"], 1e-3), (c["name"], tw)
         finally:
             eng.close()
+
+
+def _fuzz_recipe(rng, oracle):
+    """token ids of a random verse / span, corrupted in one of several ways, plus the frame count and noise level."""
+    n_verses = 6236
+    v = int(rng.integers(0, n_verses))
+    span = int(rng.choice([1, 1, 1, 2, 3]))
+    ids = oracle.token_ids(v, span).tolist() if v + span <= n_verses else oracle.token_ids(v, 1).tolist()
+    mode = int(rng.integers(0, 9))
+    if mode == 1:                                   # tokens dropped
+        keep = rng.random(len(ids)) > rng.uniform(0.1, 0.5)
+        ids = [t for t, k in zip(ids, keep) if k]
+    elif mode == 2:                                 # tokens replaced
+        rate = rng.uniform(0.1, 0.4)
+        ids = [int(rng.integers(1, 1024)) if rng.random() < rate else t for t in ids]
+    elif mode == 3:                                 # random insertions
+        out = []
+        for t in ids:
+            out.append(t)
+            if rng.random() < 0.2:
+                out.append(int(rng.integers(1, 1024)))
+        ids = out
+    elif mode == 4:                                 # a middle fragment
+        a = int(rng.integers(0, max(1, len(ids) // 2)))
+        ids = ids[a: a + max(2, len(ids) // 2)]
+    elif mode == 5:                                 # two unrelated verses glued together
+        ids = ids[: max(2, len(ids) // 2)] + oracle.token_ids(int(rng.integers(0, n_verses)), 1).tolist()[:40]
+    elif mode == 6:                                 # garbage
+        ids = [int(x) for x in rng.integers(1, 1024, size=int(rng.integers(3, 60)))]
+    elif mode == 7:                                 # very short
+        ids = ids[: int(rng.integers(1, 4))]
+    ids = ids[:180] or [5]
+    T = int(min(376, max(12, round(len(ids) * rng.uniform(2.05, 2.6)) + 1)))
+    return {"ids": ids, "T": T, "seed": int(rng.integers(0, 1 << 30)), "noise": float(rng.choice([0.5, 1.0, 2.0, 3.0])),
+            "boost": float(rng.choice([4.0, 6.0, 8.0])), "rep": 2}
+
+
+def test_fuzz_batched_path_against_the_oracle(oracle):
+    """Random corrupted recitations through the BATCHED path (ragged batches of 32: the fragment job list, the work
+    stealing and the leader assignment see many utterances at once) against the CPU oracle one utterance at a time:
+    greedy ids, winner, source, candidate count, score.  QVERSE_FUZZ_CASES scales it up (default 128)."""
+    import os
+
+    from offline_tarteel_amd.engine import Engine
+
+    n_cases = int(os.getenv("QVERSE_FUZZ_CASES", "128"))
+    rng = np.random.default_rng(int(os.getenv("QVERSE_FUZZ_SEED", "20260927")))
+    eng = Engine(device=0, with_model=False, max_batch=32, max_samples=480000)
+    try:
+        done = withheld = 0
+        while done < n_cases:
+            recipes = [_fuzz_recipe(rng, oracle) for _ in range(min(32, n_cases - done))]
+            lps = [lp_of(r) for r in recipes]
+            t_max = max(x.shape[0] for x in lps)
+            batch = torch.full((len(lps), t_max, 1025), -50.0)
+            for b, x in enumerate(lps):
+                batch[b, : x.shape[0]] = x
+            res = eng.decode_retrieve_rerank(batch.cuda().contiguous(), [x.shape[0] for x in lps])
+            for rcp, lp, got in zip(recipes, lps, res):
+                want = oracle.predict_logprobs(lp.numpy())
+                tag = (rcp["seed"], len(rcp["ids"]), rcp["T"])
+                assert got["greedy_ids"] == want["greedy_ids"], tag
+                if len(want["transcript"]) > 1024:
+                    # documented deviation (DESIGN 2): a transcript of more than 1,024 normalised characters -- only
+                    # noise decodes to one -- is withheld on the hot path; the reference would still match it
+                    assert got["surah"] == 0, tag
+                    withheld += 1
+                    continue
+                assert (got["surah"], got["ayah"], got["ayah_end"], got["source"]) == (
+                    want["surah"], want["ayah"], want["ayah_end"], want["source"]), (tag, got, want)
+                if want["source"] is None:
+                    continue
+                assert got["use_ctc"] == want["use_ctc"], tag
+                if want["use_ctc"]:
+                    assert got["n_candidates"] == want["n_candidates"], tag
+                if want["source"] == "text":
+                    assert got["score"] == want["score_raw"], tag
+                else:
+                    assert abs(got["score"] - want["score_raw"]) <= 1e-3 * max(want["score_raw"], 1e-3), tag
+            done += len(recipes)
+        assert withheld <= n_cases // 50
+    finally:
+        eng.close()
