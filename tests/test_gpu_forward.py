@@ -403,3 +403,48 @@ def test_digital_silence_is_finite_and_batch_invariant(setup):
     assert t1[0] == t[1] and torch.equal(one[0, : t1[0]], lp[1, : t[1]])
     res = eng.predict_batch(a.cuda().contiguous(), lens)
     assert len(res) == 2 and res[1]["t_frames"] == t[1]
+
+
+def _samples_for_frames(T):
+    """smallest sample count whose three stride-2 stages leave exactly T encoder frames"""
+    sl = lambda x: (x + 2 - 3) // 2 + 1  # noqa: E731
+    n = 400
+    while sl(sl(sl(n // 160 + 1))) < T:
+        n += 160
+    assert sl(sl(sl(n // 160 + 1))) == T
+    return n
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
+    """Encoder frame counts on and around the tile edges of the attention kernel (32-key tiles, 128-query groups, two
+    heads per block) and of the GEMM row tiles, ragged in one batch: every utterance equals itself run alone, bit for
+    bit, in all three precisions; in fp16 the one-head-per-block and one-wave-per-tile attention kernels give the same
+    bits for the whole batch."""
+    from offline_tarteel_amd.engine import Engine
+
+    frames = [1, 31, 32, 33, 64, 65, 127, 128, 129, 160, 255, 256, 257]
+    lens = [_samples_for_frames(t) for t in frames]
+    a = torch.from_numpy(synth_audio(len(lens), max(lens), seed=123))
+    for b, n in enumerate(lens):
+        a[b, n:] = 0
+    eng = Engine(device=0, with_model=True, seed=SEED, precision=precision, max_batch=len(lens), max_samples=max(lens))
+    try:
+        dev = a.cuda().contiguous()
+        lp, t = eng.forward(dev, lens)
+        torch.cuda.synchronize()
+        assert t == frames
+        lp = lp.clone()
+        for b, n in enumerate(lens):
+            assert bool(torch.isfinite(lp[b, : t[b]]).all()), frames[b]
+            one, t1 = eng.forward(dev[b: b + 1, :n].contiguous(), [n])
+            assert t1[0] == t[b] and torch.equal(one[0, : t[b]], lp[b, : t[b]]), frames[b]
+        if precision == 0:
+            for var in ("QVERSE_ATT_HPB", "QVERSE_ATT_OLD"):
+                monkeypatch.setenv(var, "1")
+                lp2, _ = eng.forward(dev, lens)
+                for b in range(len(lens)):
+                    assert torch.equal(lp2[b, : t[b]], lp[b, : t[b]]), (var, frames[b])
+                monkeypatch.delenv(var)
+    finally:
+        eng.close()
