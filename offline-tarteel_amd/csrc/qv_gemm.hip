@@ -764,15 +764,14 @@ static void launch_one(const GemmArgs &g, hipStream_t s) {
 // tile width BN in {64, 128} and LDS stage count NST in {2, 3, 4} (see launch_gemm)
 template <int EPI, int WQ>
 static void launch_shape(const GemmArgs &g, hipStream_t s, bool narrow, int nst) {
-    if (nst == 0) {   // register-staged loaders (2-stage LDS ring)
-        if constexpr (WQ == 8) launch_one<EPI, 128, 8, 2, 1>(g, s);
-        else if (narrow) launch_one<EPI, 64, WQ, 2, 1>(g, s);
+    if constexpr (WQ == 8) {
+        // int8 weights (the two pointwise-convolution shapes) only exist with register-staged loaders: their direct-to-LDS
+        // variants (QVERSE_GEMM_LD=0) needed 4-12 spilled VGPRs at the 128-register budget, i.e. scratch traffic inside a
+        // loop whose vmcnt waits are counted by hand (tests/test_capi_load.py keeps the binary free of such kernels)
+        launch_one<EPI, 128, 8, 2, 1>(g, s);
+    } else if (nst == 0) {   // register-staged loaders (2-stage LDS ring)
+        if (narrow) launch_one<EPI, 64, WQ, 2, 1>(g, s);
         else launch_one<EPI, 128, WQ, 2, 1>(g, s);
-        return;
-    }
-    if constexpr (WQ == 8) {   // the two pointwise-convolution shapes: 128-wide tiles, 2 or 3 stages
-        if (nst == 2) launch_one<EPI, 128, 8, 2>(g, s);
-        else launch_one<EPI, 128, 8, 3>(g, s);
     } else if (narrow) {
         if (nst == 2) launch_one<EPI, 64, WQ, 2>(g, s);
         else launch_one<EPI, 64, WQ, 3>(g, s);

@@ -132,3 +132,47 @@ def test_weight_spec_and_seeded_init_match_the_oracle_mirror():
     mine, theirs = cw.random_weights(lib, shapes, 20260630), R.random_weights(20260630)
     for k in list(shapes)[:40] + list(shapes)[-8:]:
         assert np.array_equal(mine[k], theirs[k].numpy()), k
+
+
+def test_no_product_kernel_spills_or_uses_scratch(tmp_path):
+    """Every gfx950 kernel in libqverse.so: no VGPR / SGPR spills, no private (scratch) segment, at most 256 VGPRs.
+    The GEMM loaders issue `buffer_load_dwordx4` from inline asm and release the data with hand-counted `s_waitcnt
+    vmcnt(N)`: a spill or a scratch access inside those loops would add vector-memory operations the counts do not know
+    about.  Read from the code objects' AMDGPU metadata (llvm-objdump --offloading, llvm-readelf --notes)."""
+    import re
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "llvm-objdump").exists() or not (llvm / "llvm-readelf").exists():
+        import pytest
+
+        pytest.skip("ROCm llvm tools not present")
+    lib = Path(__file__).resolve().parent.parent / "offline-tarteel_amd" / "libqverse.so"
+    shutil.copy(lib, tmp_path / "libqverse.so")
+    subprocess.run([str(llvm / "llvm-objdump"), "--offloading", "libqverse.so"], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(tmp_path.glob("libqverse.so.*gfx950"))
+    assert objs, "no gfx950 code object found in libqverse.so"
+    kernels = {}
+    for o in objs:
+        notes = subprocess.run([str(llvm / "llvm-readelf"), "--notes", str(o)], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
+                             for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+    assert len(kernels) >= 60 and any("k_gemm256" in k for k in kernels) and any("k_attention_ws" in k for k in kernels)
+    # no kernel spills vector registers or needs more than 256 of them
+    bad = {k: v for k, v in kernels.items() if v["vgpr_spill_count"] or v["vgpr_count"] > 256}
+    assert not bad, bad
+    # the hand-scheduled families (inline-asm loads + counted waits, or counted direct-to-LDS loads): no scratch at all
+    counted = {k: v for k, v in kernels.items() if "k_gemm" in k or "k_attention" in k}
+    assert len(counted) >= 30
+    bad = {k: v for k, v in counted.items() if v["private_segment_fixed_size"] or v["sgpr_spill_count"]}
+    assert not bad, bad
+    # elsewhere a private segment only where a kernel indexes a small local array dynamically (the long-utterance CTC
+    # variants), and SGPR spills (lane writes, no memory) only in the integer text kernels
+    scratch = {k for k, v in kernels.items() if v["private_segment_fixed_size"]}
+    assert all("k_ctc" in k for k in scratch), scratch
+    sgpr = {k: v["sgpr_spill_count"] for k, v in kernels.items() if v["sgpr_spill_count"]}
+    assert all(any(t in k for t in ("k_lcs_full", "k_frag", "k_spans", "k_track")) for k in sgpr), sgpr
