@@ -29,6 +29,7 @@ int main(int argc, char **argv) {
         {"pw1      glu   N1024 K512 ", EPI_GLU, 1024, 512, 512, 1.f},
         {"head     f32   N1152 K512 ", EPI_F32, 1152, 512, 1152, 1.f},
         {"sub_out  f32   N512 K2560 ", EPI_F32, 512, 2560, 512, 1.f},
+        {"ff_up shape, ReLU epilogue", EPI_F16_RELU, 2048, 512, 2048, 1.f},   // ablation: what the Swish costs
     };
     uint64_t seed = 1;
     size_t maxA = (size_t)M * 2560, maxW = (size_t)2048 * 2560, maxO = (size_t)M * 2048;
@@ -54,7 +55,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double tot_ms = 0, tot_fl = 0;
-    const double per_layer[] = {2, 2, 1, 2, 1, 0, 0};
+    const double per_layer[] = {2, 2, 1, 2, 1, 0, 0, 0};
     for (auto &sh : shapes) {
         GemmArgs g = {};
         g.A = dA; g.W = dW; g.bias = db; g.out = dO; g.out2 = dV;
