@@ -176,3 +176,31 @@ def test_no_product_kernel_spills_or_uses_scratch(tmp_path):
     assert all("k_ctc" in k for k in scratch), scratch
     sgpr = {k: v["sgpr_spill_count"] for k, v in kernels.items() if v["sgpr_spill_count"]}
     assert all(any(t in k for t in ("k_lcs_full", "k_frag", "k_spans", "k_track")) for k in sgpr), sgpr
+
+
+def test_integration_md_stub_matches_the_abi():
+    """INTEGRATION.md section 1 is the binding a maintainer would copy: its qv_config / qv_result structures must be
+    field for field what offline-tarteel_amd/engine.py binds (which the GPU tests exercise against the library), and
+    every entry point the document names must exist in include/qverse.h (the stub had drifted)."""
+    import ctypes as C
+    import re
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    text = (root / "INTEGRATION.md").read_text(encoding="utf-8")
+    block = text.split("```python", 1)[1].split("```", 1)[0]
+    src = block.split("cfg = QvConfig()")[0]                       # the two structure definitions only
+    src = src.replace('lib = C.CDLL("libqverse.so")', "lib = None")
+    ns = {}
+    exec(compile(src.replace("import ctypes as C, numpy as np, torch", "import ctypes as C"), "INTEGRATION.md", "exec"), ns)
+    import offline_tarteel_amd  # noqa: F401
+    from offline_tarteel_amd import engine as E
+
+    for doc_cls, eng_cls in ((ns["QvConfig"], E.QvConfig), (ns["QvResult"], E.QvResult)):
+        assert [(n, t) for n, t in doc_cls._fields_] == [(n, t) for n, t in eng_cls._fields_], doc_cls.__name__
+        assert C.sizeof(doc_cls) == C.sizeof(eng_cls)
+    header = (root / "include" / "qverse.h").read_text(encoding="utf-8")
+    named = set(re.findall(r"\b(qv_[a-z0-9_]+)\s*\(", text)) | set(re.findall(r"`(qv_[a-z0-9_]+)`", text))
+    named -= {"qv_config", "qv_result"}
+    missing = sorted(n for n in named if not re.search(rf"\b{n}\s*\(", header))
+    assert not missing, missing
