@@ -23,9 +23,12 @@
  *   - every function returns 0 on success or a QV_ERR_* code; qv_last_error() gives text.
  *     The Python binding turns non-zero into an exception, so the runner's per-sample
  *     try/except (benchmark/runner.py:322-325) yields the reference's empty prediction.
- *   - one engine per process per GPU; calls on one engine must not overlap in time unless
- *     they are enqueued on the same stream (the TTA plugin batches its 0.9x/1.1x passes into
- *     one call instead of calling from two threads, cf. c2c-direct-mixed-tta/run.py:129-130).
+ *   - one engine per process per GPU.  Host calls on one engine are serialised by the library (a
+ *     per-engine lock held for the duration of each call), so calling from several threads is safe --
+ *     the reference's TTA plugin runs its 0.9x / 1.1x passes from two threads
+ *     (c2c-direct-mixed-tta/run.py:129-130) -- but gains nothing: batching the work into one call
+ *     (what plugin.predict_tta does) or keeping batches in flight (qv_predict_batch_async) is the
+ *     GPU-native form.  Results of a context must be fetched before that context is reused.
  */
 #ifndef QVERSE_H
 #define QVERSE_H

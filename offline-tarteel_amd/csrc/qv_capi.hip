@@ -52,6 +52,27 @@ static double probe_rounds(int ns) {
     return best / (SPIN_TICKS / 100.0);
 }
 
+// host calls on one engine are serialised (qv_engine::mu); a null engine falls through to the entry point's own check
+#define QV_SERIALISE(e) std::unique_lock<std::recursive_mutex> qv_lock_; if (e) qv_lock_ = std::unique_lock<std::recursive_mutex>((e)->mu)
+
+// Device-side order between consecutive calls on different caller streams (two host threads, each with its own stream,
+// share the engine's workspace): wait for the previous call's tail on entry, leave a new tail on exit.
+namespace {
+struct QvStreamOrder {
+    qv_engine *e;
+    hipStream_t s;
+    QvStreamOrder(qv_engine *e_, hipStream_t s_) : e(e_), s(s_) {
+        if (e && e->tail_valid && e->tail_stream != s) (void)hipStreamWaitEvent(s, e->tail_ev, 0);
+    }
+    ~QvStreamOrder() {
+        if (!e) return;
+        if (!e->tail_ev && hipEventCreateWithFlags(&e->tail_ev, hipEventDisableTiming) != hipSuccess) { e->tail_ev = nullptr; return; }
+        if (hipEventRecord(e->tail_ev, s) == hipSuccess) { e->tail_stream = s; e->tail_valid = true; }
+    }
+};
+}  // namespace
+#define QV_ORDERED(e, stream) QvStreamOrder qv_order_((e), (hipStream_t)(stream))
+
 extern "C" int32_t qv_probe_concurrent_streams(void) {
     static int cached = 0;
     if (cached) return cached;
@@ -531,6 +552,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
 }
 
 extern "C" void qv_destroy(qv_engine *e) {
+    if (e && e->tail_ev) { (void)hipEventDestroy(e->tail_ev); e->tail_ev = nullptr; }
     if (!e) return;
     (void)hipDeviceSynchronize();
     if (e->model) qv_model_destroy(e->model);
@@ -549,6 +571,8 @@ extern "C" void qv_destroy(qv_engine *e) {
 
 extern "C" int qv_forward(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
                           int64_t n_max, float *logprobs_dev, int32_t t_max, int32_t *t_out_host, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model (with_model = 0)"); return QV_ERR_NO_MODEL; }
     return qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, logprobs_dev, t_max, t_out_host,
@@ -557,6 +581,8 @@ extern "C" int qv_forward(qv_engine *eng, const float *audio_dev, const int64_t 
 
 extern "C" int qv_decode_retrieve_rerank_async(qv_engine *eng, const float *lp, const int32_t *t_host, int32_t batch,
                                                int32_t t_max, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng || !lp || !t_host || batch < 1) return QV_ERR_ARG;
     qv_stage_mark(eng, 0, (hipStream_t)stream);   // no forward in this call: forward = 0
     qv_stage_mark(eng, 1, (hipStream_t)stream);
@@ -572,6 +598,7 @@ void qv_stage_mark(qv_engine *eng, int i, hipStream_t s) {
 }
 
 extern "C" int qv_profile_inject_logprobs(qv_engine *eng, const float *logprobs_dev, int32_t t_max, const int32_t *t_host, int32_t batch) {
+    QV_SERIALISE(eng);
     if (!eng) return QV_ERR_ARG;
     if (!logprobs_dev) { eng->inject_lp = nullptr; eng->inject_batch = 0; return QV_OK; }
     if (!t_host || batch < 1 || t_max < 1 || t_max > eng->work.t_cap) { qv_set_error(eng, "qv_profile_inject_logprobs: bad shape"); return QV_ERR_ARG; }
@@ -583,6 +610,7 @@ extern "C" int qv_profile_inject_logprobs(qv_engine *eng, const float *logprobs_
 }
 
 extern "C" int qv_profile_stages(qv_engine *eng, int32_t enable) {
+    QV_SERIALISE(eng);
     if (!eng) return QV_ERR_ARG;
     if (enable)
         for (int k = 0; k < eng->n_ctx; ++k)
@@ -593,6 +621,7 @@ extern "C" int qv_profile_stages(qv_engine *eng, int32_t enable) {
 }
 
 extern "C" int qv_stage_times(qv_engine *eng, int32_t k, float *ms4) {
+    QV_SERIALISE(eng);
     if (!eng || !ms4 || k < 0 || k >= eng->n_ctx) return QV_ERR_ARG;
     QvCtx &c = eng->ctx[k];
     if (!c.stage_valid) { qv_set_error(eng, "qv_stage_times: no profiled batch on this context (qv_profile_stages first)"); return QV_ERR_ARG; }
@@ -603,6 +632,8 @@ extern "C" int qv_stage_times(qv_engine *eng, int32_t k, float *ms4) {
 
 extern "C" int qv_fetch_results(qv_engine *eng, int32_t batch, int32_t t_max, qv_result *res, int32_t *greedy_host,
                                 void *stream_) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream_);
     hipStream_t stream = (hipStream_t)stream_;
     if (!eng || !res || batch < 1 || batch > eng->work.max_batch) return QV_ERR_ARG;
     QV_HIP(hipMemcpyAsync(res, eng->work.results, sizeof(qv_result) * batch, hipMemcpyDeviceToHost, stream));
@@ -624,6 +655,7 @@ extern "C" int qv_fetch_results(qv_engine *eng, int32_t batch, int32_t t_max, qv
 
 extern "C" int qv_decode_retrieve_rerank(qv_engine *eng, const float *lp, const int32_t *t_host, int32_t batch,
                                          int32_t t_max, qv_result *res, int32_t *greedy_host, void *stream) {
+    QV_SERIALISE(eng);
     int rc = qv_decode_retrieve_rerank_async(eng, lp, t_host, batch, t_max, stream);
     if (rc) return rc;
     return qv_fetch_results(eng, batch, t_max, res, greedy_host, stream);
@@ -631,6 +663,8 @@ extern "C" int qv_decode_retrieve_rerank(qv_engine *eng, const float *lp, const 
 
 extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host,
                                       int32_t batch, int64_t n_max, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model (with_model = 0)"); return QV_ERR_NO_MODEL; }
     if (batch > eng->work.max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
@@ -673,6 +707,7 @@ extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, co
 
 extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
                                 int64_t n_max, qv_result *res, int32_t *greedy_host, void *stream) {
+    QV_SERIALISE(eng);
     int rc = qv_predict_batch_async(eng, audio_dev, lengths_host, batch, n_max, stream);
     if (rc) return rc;
     if (eng->n_ctx > 1) return qv_fetch_results_ctx(eng, eng->cur_ctx, batch, eng->last_tmax, res, greedy_host);
@@ -681,6 +716,8 @@ extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const in
 
 extern "C" int qv_upfirdn(qv_engine *eng, const float *x_dev, int64_t n_in, const float *taps, int32_t n_taps, int32_t up,
                           int32_t down, int64_t m0, int64_t n_out, float *y_dev, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng || !x_dev || !taps || !y_dev || n_in < 1 || n_taps < 1 || up < 1 || down < 1 || m0 < 0 || n_out < 0) return QV_ERR_ARG;
     const qv_engine::Fir *fir = nullptr;
     for (const auto &f : eng->firs)
@@ -711,6 +748,7 @@ extern "C" int32_t qv_context_count(const qv_engine *eng) { return eng ? eng->n_
 extern "C" int32_t qv_last_context(const qv_engine *eng) { return eng ? eng->cur_ctx : -1; }
 
 extern "C" int qv_wait_ctx(qv_engine *eng, int32_t k) {
+    QV_SERIALISE(eng);
     if (!eng || k < 0 || k >= eng->n_ctx) return QV_ERR_ARG;
     QvCtx &c = eng->ctx[k];
     if (eng->n_ctx > 1) {
@@ -722,6 +760,7 @@ extern "C" int qv_wait_ctx(qv_engine *eng, int32_t k) {
 }
 
 extern "C" const int32_t *qv_packed_results_ctx(qv_engine *eng, int32_t k, void *stream) {
+    QV_SERIALISE(eng);
     if (!eng || k < 0 || k >= eng->n_ctx) return nullptr;
     QvCtx &c = eng->ctx[k];
     if (eng->n_ctx > 1 && c.busy && hipStreamWaitEvent((hipStream_t)stream, c.done, 0) != hipSuccess) return nullptr;
@@ -730,6 +769,7 @@ extern "C" const int32_t *qv_packed_results_ctx(qv_engine *eng, int32_t k, void 
 
 extern "C" int qv_fetch_results_ctx(qv_engine *eng, int32_t k, int32_t batch, int32_t t_max, qv_result *res,
                                     int32_t *greedy_host) {
+    QV_SERIALISE(eng);
     if (!eng || k < 0 || k >= eng->n_ctx) return QV_ERR_ARG;
     int keep = eng->cur_ctx;
     if (eng->n_ctx == 1) QV_HIP(hipDeviceSynchronize());  // the batch ran on a caller stream we were not given
@@ -744,6 +784,8 @@ extern "C" int qv_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int3
                                  int32_t *base_span, double *base_score, int32_t *cand_start, int32_t *cand_span,
                                  double *cand_score, int32_t cand_cap, int32_t *n_cand, int32_t *runner_idx,
                                  double *runner_score, int32_t *n_runners, void *stream_) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream_);
     hipStream_t stream = (hipStream_t)stream_;
     if (!eng) return QV_ERR_ARG;
     int rc = qv_post_debug_retrieve(eng, codes_host, n_codes, stream);
@@ -769,6 +811,8 @@ extern "C" int qv_debug_retrieve(qv_engine *eng, const uint8_t *codes_host, int3
 extern "C" int qv_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32_t *offsets_host,
                                 const int32_t *n_words_host, const int32_t *bonus_verse_host, int32_t batch,
                                 qv_track_match *out_host, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng) return QV_ERR_ARG;
     if (batch < 0 || !offsets_host || !n_words_host || !bonus_verse_host || !out_host || (batch > 0 && !codes_host)) {
         qv_set_error(eng, "qv_tracker_match: null argument");
@@ -798,6 +842,8 @@ static int quiesce_contexts(qv_engine *eng) {
 extern "C" int qv_match_verse(qv_engine *eng, const uint8_t *codes_host, int32_t n_codes, int32_t n_bonus,
                               const int32_t *bonus_verse, const double *bonus_value, int32_t max_span, int32_t *start,
                               int32_t *span, double *score, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng) return QV_ERR_ARG;
     if (n_codes < 0 || (n_codes > 0 && !codes_host) || n_bonus < 0 || n_bonus > 3 || (n_bonus > 0 && (!bonus_verse || !bonus_value)) ||
         max_span < 2 || max_span > 8 || !start || !span || !score) {
@@ -818,11 +864,15 @@ extern "C" int qv_match_verse(qv_engine *eng, const uint8_t *codes_host, int32_t
 
 extern "C" int qv_debug_ctc_loss(qv_engine *eng, const float *lp, int32_t T, const uint16_t *tg, const int32_t *lens,
                                  int32_t n, float *loss_host, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng || n < 1) return QV_ERR_ARG;
     return qv_post_debug_ctc(eng, lp, T, tg, lens, n, loss_host, (hipStream_t)stream);
 }
 
 extern "C" int qv_debug_forward_tap(qv_engine *eng, int32_t what, int32_t layer, float *out_dev, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
     if (!eng) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
     return qv_model_tap(eng, eng->model, what, layer, out_dev, (hipStream_t)stream);
@@ -844,6 +894,7 @@ extern "C" int qv_profile_gemm_read(qv_engine *eng, double *ms21, double *flops2
 }
 
 extern "C" int qv_profile_replay_kernel(qv_engine *eng, int32_t which, char *name_out, int32_t name_cap) {
+    QV_SERIALISE(eng);
     if (!eng || !name_out || name_cap < 8) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
     return qv_model_replay_kernel(eng, eng->model, which, name_out, name_cap);
@@ -857,6 +908,7 @@ extern "C" int qv_debug_gemm_tiles(int32_t mode) {
 
 extern "C" int qv_profile_replay_gemm(qv_engine *eng, int32_t which, int32_t iters, double *avg_us, double *flops_per_launch,
                                       void *stream) {
+    QV_SERIALISE(eng);
     if (!eng || !avg_us || !flops_per_launch) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
     return qv_model_replay_gemm(eng, eng->model, which, iters, avg_us, flops_per_launch, (hipStream_t)stream);

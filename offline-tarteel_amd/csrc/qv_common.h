@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -228,6 +229,15 @@ struct QvCtx {
 };
 
 struct qv_engine {
+    // every entry point that touches the engine takes this lock for the duration of the HOST call (entry points call
+    // one another, hence recursive): calls from several host threads are serialised instead of corrupting the shared
+    // host-side state (current context, staging slots); the device work they enqueue stays asynchronous
+    std::recursive_mutex mu;
+    // ... and consecutive calls that enqueue on DIFFERENT caller streams are ordered on the device as well (they share
+    // the current context's workspace): each such call waits for the event the previous one left behind (QvStreamOrder)
+    hipEvent_t tail_ev = nullptr;
+    hipStream_t tail_stream = nullptr;
+    bool tail_valid = false;
     qv_config cfg;
     QvKnobs knobs;
     int device;

@@ -448,3 +448,46 @@ def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
                 monkeypatch.delenv(var)
     finally:
         eng.close()
+
+
+def test_two_host_threads_on_one_engine_are_serialised(setup):
+    """The reference's TTA plugin calls predict from two threads (c2c-direct-mixed-tta/run.py:129-130).  ctypes drops
+    the GIL during a call, so two Python threads really are inside the library at once: the per-engine lock must make
+    that equivalent to calling one after the other."""
+    import threading
+
+    eng = setup["eng"]
+    a = setup["audio"].cuda().contiguous()
+    want = eng.predict_batch(a, LENS)
+    key = lambda r: (r["surah"], r["ayah"], r["ayah_end"], r["source"], r["score"], r["t_frames"])  # noqa: E731
+    want_k = [key(r) for r in want]
+    errors, out = [], {}
+
+    def worker(tag):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for i in range(12):
+                    if (i + tag) % 2:
+                        res = eng.predict_batch(a, LENS)
+                        out[(tag, i)] = [key(r) for r in res]
+                    else:
+                        lp, t = eng.forward(a, LENS)
+                        s.synchronize()
+                        out[(tag, i)] = ("fwd", t, [bool(torch.equal(lp[b, :n], setup["lp"][b, :n])) for b, n in enumerate(t)])
+        except Exception as e:  # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    assert len(out) == 24
+    for k, v in out.items():
+        if v[0] == "fwd":
+            assert v[1] == setup["t"] and all(v[2]), k
+        else:
+            assert v == want_k, k
