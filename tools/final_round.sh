@@ -10,13 +10,15 @@ mkdir -p "$O"
 cd "$R"
 timeout 1200 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; tail -n 2 "$O/tests.log"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -n 1 "$O/smoke.log"
-timeout 600 python bench.py > "$O/bench.json" 2> "$O/bench.err"; cut -c1-170 "$O/bench.json"
+s0=$SECONDS; timeout 600 python bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "default bench.py wall $((SECONDS - s0)) s" | tee "$O/bench_wall.txt"; cut -c1-170 "$O/bench.json"
 timeout 300 python bench.py --contexts 1 --no-cpu-baseline > "$O/bench_contexts1.json" 2>/dev/null; cut -c1-170 "$O/bench_contexts1.json"
 timeout 300 python bench.py --batch 256 --precision mixed --steps 20 --no-cpu-baseline > "$O/bench_cfg2_b256_mixed.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_mixed.json"
 timeout 300 python bench.py --batch 256 --steps 20 --no-cpu-baseline > "$O/bench_b256_fp16.json" 2>/dev/null; cut -c1-170 "$O/bench_b256_fp16.json"
 timeout 300 python bench.py --precision ort --steps 30 --no-cpu-baseline --no-extra > "$O/bench_b64_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_b64_ort.json"
 timeout 300 python bench.py --batch 256 --precision ort --steps 12 --no-cpu-baseline --no-extra > "$O/bench_cfg2_b256_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_ort.json"
 timeout 300 python bench.py --workload tta30 --steps 6 --warmup 2 --no-cpu-baseline > "$O/bench_tta30.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30.json"
+timeout 300 python bench.py --workload tta30 --precision ort --steps 4 --warmup 2 --no-cpu-baseline --no-extra > "$O/bench_tta30_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30_ort.json"
+timeout 300 python bench.py --workload tta30 --precision ort --steps 4 --warmup 2 --no-cpu-baseline --no-extra > "$O/bench_tta30_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30_ort.json"
 timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; tail -n 3 "$O/sweep.log" | cut -c1-200
 timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench.jsonl"
 timeout 200 python tools/tracker_bench.py --cpu-texts 4 > "$O/tracker_bench.jsonl" 2>/dev/null; tail -n 2 "$O/tracker_bench.jsonl"
