@@ -208,15 +208,19 @@ def realistic_mix_leg(eng, audio, lengths, B: int, T: int, steps: int, headline:
         for _ in range(4):
             eng.predict_batch_async(audio, lengths)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.predict_batch_async(audio, lengths)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        runs = []
+        for _ in range(3):                      # a 130 ms region is at the mercy of one host hiccup: three of them, all reported
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.predict_batch_async(audio, lengths)
+            torch.cuda.synchronize()
+            runs.append(time.perf_counter() - t0)
+        dt = min(runs)
     finally:
         eng.inject_logprobs(None)
     v = B * steps / dt
     return {"value": round(v, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "runs_utt_per_s": [round(B * steps / r, 1) for r in runs],
             "gate_failed_utterances_per_batch": used, "batch": B,
             "vs_headline_workload": round(v / headline, 4),
             "what": f"full forward on the synthetic clips + post-logits on verse-shaped log-probs, {B - n_fail} that pass the "

@@ -18,7 +18,6 @@ timeout 300 python bench.py --precision ort --steps 30 --no-cpu-baseline --no-ex
 timeout 300 python bench.py --batch 256 --precision ort --steps 12 --no-cpu-baseline --no-extra > "$O/bench_cfg2_b256_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_ort.json"
 timeout 300 python bench.py --workload tta30 --steps 6 --warmup 2 --no-cpu-baseline > "$O/bench_tta30.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30.json"
 timeout 300 python bench.py --workload tta30 --precision ort --steps 4 --warmup 2 --no-cpu-baseline --no-extra > "$O/bench_tta30_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30_ort.json"
-timeout 300 python bench.py --workload tta30 --precision ort --steps 4 --warmup 2 --no-cpu-baseline --no-extra > "$O/bench_tta30_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30_ort.json"
 timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; tail -n 3 "$O/sweep.log" | cut -c1-200
 timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench.jsonl"
 timeout 200 python tools/tracker_bench.py --cpu-texts 4 > "$O/tracker_bench.jsonl" 2>/dev/null; tail -n 2 "$O/tracker_bench.jsonl"
