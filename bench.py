@@ -483,11 +483,16 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    import gc
+
+    gc.collect()
+    gc.disable()          # the timed region is tens of milliseconds of host-driven launches: no collector pause inside it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     dt = time.perf_counter() - t0
+    gc.enable()
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
