@@ -39,6 +39,12 @@ def build(force: bool = False, verbose: bool = False, dev_hooks: bool = False) -
     """dev_hooks: compile the timing experiments (QVERSE_SKIP / QVERSE_DUP: drop or duplicate kernel classes) into
     the forward schedule -- never in the product build."""
     OBJ.mkdir(exist_ok=True)
+    # the objects of a --dev-hooks build must never be linked into a product build (and vice versa): a flavour stamp
+    # forces a full rebuild when the flavour changes (tests/test_capi_load.py also checks the library for the hook names)
+    stamp = OBJ / "flavour.txt"
+    flavour = "dev-hooks" if dev_hooks else "product"
+    if not stamp.exists() or stamp.read_text().strip() != flavour:
+        force = True
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "qverse.h"]
     jobs = []
     for src in sources():
@@ -61,6 +67,7 @@ def build(force: bool = False, verbose: bool = False, dev_hooks: bool = False) -
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
+    stamp.write_text(flavour + "\n")
     objs = [OBJ / (s.stem + ".o") for s in sources()]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

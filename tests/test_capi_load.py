@@ -204,3 +204,12 @@ def test_integration_md_stub_matches_the_abi():
     named -= {"qv_config", "qv_result"}
     missing = sorted(n for n in named if not re.search(rf"\b{n}\s*\(", header))
     assert not missing, missing
+
+
+def test_product_library_carries_no_dev_hooks():
+    """QVERSE_SKIP / QVERSE_DUP (drop or duplicate kernel classes, results meaningless) exist only in a
+    `build.py --dev-hooks` build; the library the tests and the benchmark load must not know those names."""
+    from pathlib import Path
+
+    blob = (Path(__file__).resolve().parent.parent / "offline-tarteel_amd" / "libqverse.so").read_bytes()
+    assert b"QVERSE_SKIP" not in blob and b"QVERSE_DUP" not in blob
