@@ -177,11 +177,15 @@ __global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, 
 
 // depthwise Conv2d(256, 3x3, s2, p1, groups=256) on channels-last f16; rows t >= len_in[b] read as 0.
 // Same ownership as conv0: 8 channels per thread, weights [9][256] in registers.
+#define DW2_TT 4
 __global__ __launch_bounds__(256) void k_dwconv2d(const half_t *__restrict__ in, int tin_max, int fin,
                                                   const int32_t *__restrict__ len_in, const float *__restrict__ wt,
                                                   const float *__restrict__ bias, half_t *__restrict__ out, int tout_max,
                                                   int fout) {
-    const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
+    // a block owns DW2_TT consecutive output frames: the 80 weights a thread fetches serve DW2_TT x fout / 8 outputs
+    // instead of fout / 8 (they were most of the block's L2 traffic), and with fout = 10 the 8 position slots of a
+    // channel group are all busy (40 positions / 8) instead of 10 of 16
+    const int b = blockIdx.z, to0 = blockIdx.y * DW2_TT, tid = threadIdx.x;
     const int tin = len_in[b];
     const int c0 = (tid & 31) * 8, fl = tid >> 5;
     float w[9][8], bs[8];
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(256) void k_dwconv2d(const half_t *__restrict__ in,
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
     }
-    for (int fo = fl; fo < fout; fo += 8) {
+    for (int p = fl; p < DW2_TT * fout; p += 8) {
+        const int to = to0 + p / fout, fo = p % fout;
+        if (to >= tout_max) break;
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = bs[c];
@@ -921,8 +927,8 @@ void launch_sub01(const float *feats, int tm_max, const int32_t *len_mel, const 
 
 void launch_dwconv2d(const half_t *in, int tin_max, int fin, const int32_t *len_in, const float *w, const float *bias,
                      half_t *out, int tout_max, int fout, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_dwconv2d, dim3(1, tout_max, batch), dim3(256), 0, s, in, tin_max, fin, len_in, w, bias, out,
-                       tout_max, fout);
+    hipLaunchKernelGGL(k_dwconv2d, dim3(1, (tout_max + DW2_TT - 1) / DW2_TT, batch), dim3(256), 0, s, in, tin_max, fin, len_in, w,
+                       bias, out, tout_max, fout);
 }
 
 void launch_pack_rows(const half_t *x, int t_max, int row_elems, const int32_t *len, const int32_t *row_off, half_t *y,
