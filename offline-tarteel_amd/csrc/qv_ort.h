@@ -33,21 +33,29 @@ static __host__ __device__ __forceinline__ float fdec(uint32_t e) {
     return __builtin_bit_cast(float, u);
 }
 
-struct QParam { float scale, zp; };   // zp: integer-valued, 0..255
+struct QParam { float scale, zp, inv; };   // zp: integer-valued, 0..255; inv = 1 / scale (IEEE division, once)
 
 // DynamicQuantizeLinear's parameters from one {min, max} key pair (float32 arithmetic, IEEE division)
 static __device__ __forceinline__ QParam dql_param(const uint32_t *__restrict__ mm) {
     const float mn = fdec(mm[0]), mx = fdec(mm[1]);
     QParam p;
     p.scale = (mx - mn) / 255.0f;
-    if (p.scale == 0.f) { p.scale = 1.0f; p.zp = 0.f; return p; }
+    if (p.scale == 0.f) { p.scale = 1.0f; p.zp = 0.f; p.inv = 1.0f; return p; }
     const float z = rintf(-mn / p.scale);
     p.zp = fminf(fmaxf(z, 0.f), 255.f);
+    p.inv = 1.0f / p.scale;
     return p;
 }
-// x -> x_q (0..255, as float): saturate(rne(x / scale) + zp)
+// x -> x_q (0..255, as float): saturate(rne(x / scale) + zp), THE IEEE quotient's rounding, at a third of its cost.
+// q = x * (1 / scale) is within 1.5 ulp of the true quotient (both factors correctly rounded); wherever the quotient lands
+// it only matters which integer rne() picks, and q can pick another one than x / scale only if a rounding boundary
+// k + 0.5 lies between them -- i.e. within 1.5 ulp(q) of q.  Those elements (2 in 1,000) take the division; the guard
+// (1e-3 absolute + 1e-6 relative) is > 1.5 ulp for every |q| that survives the saturation and far beyond it.
 static __device__ __forceinline__ float quant_u8(float x, const QParam &p) {
-    return fminf(fmaxf(rintf(x / p.scale) + p.zp, 0.f), 255.f);
+    const float q = x * p.inv;
+    float t = rintf(q);
+    if (fabsf(fabsf(q - t) - 0.5f) < 1e-3f + 1e-6f * fabsf(q)) t = rintf(x / p.scale);
+    return fminf(fmaxf(t + p.zp, 0.f), 255.f);
 }
 
 // fold one value range into a site's pair; the plain read first drops most atomics (keys only ever move outwards)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_rows_minmax(const float *__restrict__ x
 //   out = z * sigmoid(z)
 // Frames t >= len read as zero point (real 0), as the reference's padding does.  Same ownership as k_dwconv1d: a lane
 // owns 8 channels and slides over DWQ_TT consecutive frames.
-#define DWQ_TT 4
+#define DWQ_TT 8
 __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ x, const float *__restrict__ wq, float w_scale,
                                                       const float *__restrict__ bias, const float *__restrict__ bn_alpha,
                                                       const float *__restrict__ bn_beta, const int32_t *__restrict__ len,
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     load_w(w0q, b0);
     __syncthreads();
     const float s0 = pm.scale * w0_scale;
-    QParam p0 = {1.f, 0.f};
+    QParam p0 = {1.f, 0.f, 1.f};
     if (PASS == 1) p0 = dql_param(mm_c0 + QV_MM_STRIDE * b);
     float mn = INFINITY, mx = -INFINITY;
     // ---- conv.0 + ReLU (rows outside [0, l1) are the depthwise conv's zero padding)
@@ -386,14 +386,15 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
 
 // conv.5: depthwise Conv2d(256, 3x3, s2, p1) as ConvInteger on the quantised f32 input (channels-last); rows
 // t >= len_in[b] read as the zero point.  Same ownership as k_dwconv2d: 8 channels per thread.
+#define DWQ2_TT 4
 __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ in, int tin_max, int fin,
                                                       const int32_t *__restrict__ len_in, const float *__restrict__ wq, float w_scale,
                                                       const float *__restrict__ bias, const int32_t *__restrict__ len_out,
                                                       const uint32_t *__restrict__ mm_in, uint32_t *__restrict__ mm_out,
                                                       float *__restrict__ out, int tout_max, int fout) {
     __shared__ float s_fold[8];
-    const int b = blockIdx.z, to = blockIdx.y, tid = threadIdx.x;
-    const int tin = len_in[b];
+    const int b = blockIdx.z, to0 = blockIdx.y * DWQ2_TT, tid = threadIdx.x;   // DWQ2_TT output frames per block (see k_dwconv2d)
+    const int tin = len_in[b], lout = len_out[b];
     const int c0 = (tid & 31) * 8, fl = tid >> 5;
     const QParam p = dql_param(mm_in + QV_MM_STRIDE * b);
     const float sxw = p.scale * w_scale;
@@ -409,9 +410,11 @@ __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ 
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
     }
-    const bool valid = to < len_out[b];
     float mn = INFINITY, mx = -INFINITY;
-    for (int fo = fl; fo < fout; fo += 8) {
+    for (int pp = fl; pp < DWQ2_TT * fout; pp += 8) {
+        const int to = to0 + pp / fout, fo = pp % fout;
+        if (to >= tout_max) break;
+        const bool valid = to < lout;
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
@@ -502,6 +505,6 @@ void launch_sub01_ort(int pass, const float *feats, int tm_max, const int32_t *l
 void launch_dwconv2d_ort(const float *in, int tin_max, int fin, const int32_t *len_in, const float *wq, float w_scale,
                          const float *bias, const int32_t *len_out, const uint32_t *mm_in, uint32_t *mm_out, float *out,
                          int tout_max, int fout, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_dwconv2d_ort, dim3(1, tout_max, batch), dim3(256), 0, s, in, tin_max, fin, len_in, wq, w_scale, bias,
+    hipLaunchKernelGGL(k_dwconv2d_ort, dim3(1, (tout_max + DWQ2_TT - 1) / DWQ2_TT, batch), dim3(256), 0, s, in, tin_max, fin, len_in, wq, w_scale, bias,
                        len_out, mm_in, mm_out, out, tout_max, fout);
 }
