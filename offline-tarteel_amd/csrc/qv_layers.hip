@@ -26,10 +26,13 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
                                                 float *__restrict__ feats, int tm_max) {
     __shared__ float2 buf[4][2][256];
     __shared__ float pw[4][264];
+    __shared__ float2 tw[256];   // the twiddle table: every FFT pass fetched its factors from global memory (waves parked 79 %)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y, t = blockIdx.x * 4 + wave;
     const int n = n_samples[b];
     const int tm = n / 160 + 1;
+    tw[threadIdx.x] = ft.twiddle[threadIdx.x];
+    __syncthreads();
     if (t >= tm) return;  // frames past the utterance are zeroed by the normalisation kernel
     const float *x = audio + (size_t)b * n_max;
     float2 *A = buf[wave][0], *Bf = buf[wave][1];
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
             int k = i & (len - 1), j = i >> p;  // j: group, k: index within group
             float2 u = src[j * len + k], v = src[j * len + k + 128];
             // twiddle w = exp(-2 pi i * k / (2 len)) from the 512-point table
-            float2 w = ft.twiddle[k * (256 >> p)];
+            float2 w = tw[k * (256 >> p)];
             float2 vw = make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
             dst[j * 2 * len + k] = make_float2(u.x + vw.x, u.y + vw.y);
             dst[j * 2 * len + k + len] = make_float2(u.x - vw.x, u.y - vw.y);
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
             float2 zk = src[k], zc = src[256 - k];
             float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
             float2 O = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
-            float2 w = ft.twiddle[k];
+            float2 w = tw[k];
             float2 P = make_float2(__builtin_fmaf(w.x, O.x, -(w.y * O.y)), __builtin_fmaf(w.x, O.y, w.y * O.x));
             X = make_float2(E.x + P.y, E.y - P.x);
         }
