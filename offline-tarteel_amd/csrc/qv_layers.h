@@ -8,7 +8,7 @@ struct FrontendTab {
     const float2 *twiddle;  // [256] exp(-2 pi i m / 512)
     const int32_t *mel_lo;  // [80] first FFT bin of each filter
     const int32_t *mel_cnt; // [80] number of bins (<= 32)
-    const float *mel_w;     // [80][32]
+    const float *mel_w;     // [32][80]: tap-major (tap k of filter m at k * 80 + m), zero beyond a filter's mel_cnt
 };
 
 void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,

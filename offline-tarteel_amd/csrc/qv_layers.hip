@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
     float *out = feats + ((size_t)b * tm_max + t) * QV_NMEL;
     for (int m = lane; m < QV_NMEL; m += 64) {
         int lo = ft.mel_lo[m], cnt = ft.mel_cnt[m];
-        const float *w = ft.mel_w + m * 32;
+        const float *w = ft.mel_w + m;        // tap-major [32][80]
         float acc = 0.f;
-        for (int k = 0; k < cnt; ++k) acc += w[k] * pw[wave][lo + k];
+        for (int k = 0; k < cnt; ++k) acc += w[k * QV_NMEL] * pw[wave][lo + k];
         out[m] = logf(acc + 5.9604644775390625e-08f);
     }
 }

@@ -437,7 +437,9 @@ int build_frontend(qv_engine *eng, QvModel *m) {
         if (first < 0) { first = 0; last = 0; }
         if (last - first + 1 > 32) { qv_set_error(eng, "mel filter wider than 32 bins"); return QV_ERR_ARG; }
         lo[i] = first; cnt[i] = last - first + 1;
-        for (int k = first; k <= last; ++k) w[i * 32 + (k - first)] = row[k];
+        // tap-major [32][80]: the lanes of k_logmel's projection are consecutive filters reading the same tap, so a
+        // wave's load is 320 contiguous bytes (filter-major, every lane hit its own cache line: 64 lines per load)
+        for (int k = first; k <= last; ++k) w[(size_t)(k - first) * QV_NMEL + i] = row[k];
     }
     TRY(up(eng, m, win, &m->ft.window));
     TRY(up(eng, m, tw, &m->ft.twiddle));
