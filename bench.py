@@ -205,7 +205,7 @@ def realistic_mix_leg(eng, audio, lengths, B: int, T: int, steps: int, headline:
     used = sum(r["use_ctc"] for r in res)
     eng.inject_logprobs(lp, [T] * B)
     try:
-        for _ in range(4):
+        for _ in range(12):
             eng.predict_batch_async(audio, lengths)
         torch.cuda.synchronize()
         runs = []
