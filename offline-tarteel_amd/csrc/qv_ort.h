@@ -51,12 +51,15 @@ static __device__ __forceinline__ QParam dql_param(const uint32_t *__restrict__ 
 // it only matters which integer rne() picks, and q can pick another one than x / scale only if a rounding boundary
 // k + 0.5 lies between them -- i.e. within 1.5 ulp(q) of q.  Those elements (2 in 1,000) take the division; the guard
 // (1e-3 absolute + 1e-6 relative) is > 1.5 ulp for every |q| that survives the saturation and far beyond it.
-static __device__ __forceinline__ float quant_u8(float x, const QParam &p) {
+// (the centred form x_q - zp = clamp(rne(x / scale), -zp, 255 - zp) is what the integer convolutions consume: exact
+// integers either way, two operations fewer per value)
+static __device__ __forceinline__ float quant_c(float x, const QParam &p) {
     const float q = x * p.inv;
     float t = rintf(q);
     if (fabsf(fabsf(q - t) - 0.5f) < 1e-3f + 1e-6f * fabsf(q)) t = rintf(x / p.scale);
-    return fminf(fmaxf(t + p.zp, 0.f), 255.f);
+    return __builtin_amdgcn_fmed3f(t, -p.zp, 255.f - p.zp);
 }
+static __device__ __forceinline__ float quant_u8(float x, const QParam &p) { return quant_c(x, p) + p.zp; }
 
 // fold one value range into a site's pair; the plain read first drops most atomics (keys only ever move outwards)
 static __device__ __forceinline__ void mm_fold(uint32_t *__restrict__ mm, float mn, float mx) {

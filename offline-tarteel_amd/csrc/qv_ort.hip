@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_quant_rows(const float *__restrict__ x,
         uint32_t u = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int q = (int)quant_u8(v[k][e], p) - 128;
+            const int q = (int)(quant_c(v[k][e], p) + (p.zp - 128.f));
             u |= ((uint32_t)q & 0xFFu) << (8 * e);
         }
         w[k] = u;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, con
             uint32_t w[2] = {0, 0};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int q = (int)quant_u8(o[i], p) - 128;
+                const int q = (int)(quant_c(o[i], p) + (p.zp - 128.f));
                 w[i >> 2] |= ((uint32_t)q & 0xFFu) << (8 * (i & 3));
             }
             *(uint2 *)(y8 + (size_t)row * QV_D + lane * 8) = make_uint2(w[0], w[1]);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
         const f32x4 v0 = *(const f32x4 *)px, v1 = *(const f32x4 *)(px + 4);
         float vf[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { vf[c] = quant_u8(v0[c], p) - p.zp; vf[4 + c] = quant_u8(v1[c], p) - p.zp; }
+        for (int c = 0; c < 4; ++c) { vf[c] = quant_c(v0[c], p); vf[4 + c] = quant_c(v1[c], p); }
 #pragma unroll
         for (int j = 0; j < DWQ_TT; ++j) {
             const int k = i - j;  // tap index: tt = (t0 + j) + k - 4
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     for (int i = tid; i < SQ_RM * (QV_NMEL + 2); i += 256) {
         int r = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = tm_0 + r;
         // frames past the utterance and the conv padding are real zeros = the zero point
-        rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_u8((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) - pm.zp : 0.f;
+        rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_c((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) : 0.f;
     }
     const int c8 = (tid & 7) * 8, pl = tid >> 3;   // 8 channels per thread, 32 positions per pass
     float w[9][8], bs[8];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
                 float yv = acc[c] * s0 + bs[c];
                 yv = yv > 0.f ? yv : 0.f;
                 if (PASS == 0) { mn = fminf(mn, yv); mx = fmaxf(mx, yv); }
-                else o[c] = (half_t)(quant_u8(yv, p0) - p0.zp);
+                else o[c] = (half_t)quant_c(yv, p0);
             }
         }
         if (PASS == 1) *(half8 *)&tile[r][f1][c8] = o;
@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256) void k_dwconv2d_ort(const float *__restrict__ 
                 const f32x4 v0 = *(const f32x4 *)px, v1 = *(const f32x4 *)(px + 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    acc[c] = __builtin_fmaf(w[dt * 3 + df][c], quant_u8(v0[c], p) - p.zp, acc[c]);
-                    acc[4 + c] = __builtin_fmaf(w[dt * 3 + df][4 + c], quant_u8(v1[c], p) - p.zp, acc[4 + c]);
+                    acc[c] = __builtin_fmaf(w[dt * 3 + df][c], quant_c(v0[c], p), acc[c]);
+                    acc[4 + c] = __builtin_fmaf(w[dt * 3 + df][4 + c], quant_c(v1[c], p), acc[4 + c]);
                 }
             }
         }
