@@ -491,3 +491,17 @@ def test_two_host_threads_on_one_engine_are_serialised(setup):
             assert v[1] == setup["t"] and all(v[2]), k
         else:
             assert v == want_k, k
+
+
+def test_randomised_soak_of_batches_in_flight():
+    """tools/soak.py, short form: 60 ragged batches (1-64 clips of 0.05-30 s) through a four-context engine, every batch
+    bit for bit what a one-context engine returns (races between contexts, staging-slot reuse, shape-dependent paths);
+    196 k utterances in the three precisions ran clean in the round's long form (profiles/r03_i_*)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "soak.py"), "--batches", "60", "--seed", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatching batches" in r.stdout, (r.stdout[-400:], r.stderr[-400:])
