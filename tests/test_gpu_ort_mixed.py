@@ -261,6 +261,18 @@ def test_prequantised_file_in_the_export_form_runs_on_its_own_integers(tmp_path)
 
     mx, rms = run(marked)
     mx_p, rms_p = run(plain)
+    # precisions 0 and 1 on a marked file: nothing is re-quantised, so both run the file's values as f16 operands -- the
+    # same bits (precision 1 on an UNMARKED file packs its own int4 / int8 grids and differs)
+    outs = {}
+    for prec, path in ((0, marked), (1, marked), (1, plain)):
+        eng = Engine(device=0, with_model=True, weights_path=str(path), precision=prec, max_batch=2, max_samples=32000)
+        try:
+            lp, t = eng.forward(audio.cuda().contiguous(), lens)
+            outs[(prec, path.name)] = lp.cpu()
+        finally:
+            eng.close()
+    assert torch.equal(outs[(0, "marked.qvw")], outs[(1, "marked.qvw")])
+    assert not torch.equal(outs[(1, "plain.qvw")], outs[(1, "marked.qvw")])
     print(f"[ort-prequant] marked file vs oracle: max {mx:.4f} rms {rms:.5f}; unmarked (re-quantised): max {mx_p:.4f} rms {rms_p:.5f}")
     assert mx <= 0.2 and rms <= 0.03, (mx, rms)
     assert rms_p > 1.5 * rms, (rms_p, rms)
