@@ -29,6 +29,9 @@
  *     (c2c-direct-mixed-tta/run.py:129-130) -- but gains nothing: batching the work into one call
  *     (what plugin.predict_tta does) or keeping batches in flight (qv_predict_batch_async) is the
  *     GPU-native form.  Results of a context must be fetched before that context is reused.
+ *     The ASYNC protocol (qv_predict_batch_async -> qv_last_context -> qv_fetch_results_ctx) is one logical sequence:
+ *     drive it from ONE thread per engine (or under the caller's own lock) -- another thread's call in between moves
+ *     qv_last_context().  qv_last_error() returns a copy private to the calling thread.
  */
 #ifndef QVERSE_H
 #define QVERSE_H
@@ -91,7 +94,8 @@ typedef struct {
     int32_t top_span_refs;      /* CTC_DIRECT_TOP_SPAN_REFS    80 */
     int32_t max_span;           /* CTC_DIRECT_MAX_SPAN          6 (table limit 6) */
     double threshold;           /* CTC_DIRECT_THRESHOLD       0.80 */
-    double text_weight;         /* CTC_DIRECT_TEXT_WEIGHT      0.0 (final = -norm_loss + weight * text score - penalty) */
+    double text_weight;         /* CTC_DIRECT_TEXT_WEIGHT      0.0 (final = -norm_loss + weight * text score - penalty);
+                                   any finite value, negative included, as c2c-direct/run.py:67 */
     double span_penalty;        /* CTC_DIRECT_SPAN_PENALTY     0.5 */
     int32_t skip_unused_passes; /* 1: skip search()/pass-3 when the gate passes (their output is
                                    unused by the mixed plugin); 0: literal */
@@ -127,7 +131,8 @@ int32_t qv_frames_for_samples(int64_t n_samples);
 
 /* Acoustic model.  audio_dev: f32[B, n_max] row-major, rows zero-padded past lengths_host[b].
  * logprobs_dev: f32[B, t_max, 1025] with t_max >= qv_frames_for_samples(max length); rows
- * t >= T[b] are left untouched.  t_out_host[b] receives T[b] (computed on the host, no sync). */
+ * t >= T[b] are ZEROED (onnxruntime hands the reference exactly [1, T, 1025], mixed/run.py:59-63: a padded batch tensor
+ * never exposes uninitialised memory).  t_out_host[b] receives T[b] (computed on the host, no sync). */
 int qv_forward(qv_engine *e, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
                int64_t n_max, float *logprobs_dev, int32_t t_max, int32_t *t_out_host, void *stream);
 
@@ -285,6 +290,10 @@ int qv_profile_replay_kernel(qv_engine *e, int32_t which, char *name_out, int32_
  * the shape allows, -1 = back to the environment (QVERSE_GEMM_T256) / default.  The tile shape never changes
  * a result: both kernels form the same products in the same accumulation order. */
 int qv_debug_gemm_tiles(int32_t mode);
+/* Process-wide attention kernel variant, for the tests that compare them bit for bit: 0 = two heads per block (default),
+ * 1 = one head per block, 2 = the one-wave-per-query-tile kernel, -1 = back to the environment (QVERSE_ATT_HPB=1 /
+ * QVERSE_ATT_OLD=1, read once per process) / default.  The variant never changes a result. */
+int qv_debug_attention_variant(int32_t mode);
 
 /* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty
  * transcript, so the headline workload never sees a recitation the text match recognises.  While log-probs are injected,

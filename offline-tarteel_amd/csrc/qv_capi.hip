@@ -74,7 +74,11 @@ struct QvStreamOrder {
 #define QV_ORDERED(e, stream) QvStreamOrder qv_order_((e), (hipStream_t)(stream))
 
 extern "C" int32_t qv_probe_concurrent_streams(void) {
+    // one probe per process, also when two threads create engines at once: the mutex covers the measurement itself (two
+    // probes side by side would halve each other's figure), and a failed probe (0) is not cached
+    static std::mutex mu;
     static int cached = 0;
+    std::lock_guard<std::mutex> lk(mu);
     if (cached) return cached;
     const double rounds = probe_rounds(QV_PROBE_STREAMS);
     if (rounds == 0.0) return 0;
@@ -85,13 +89,24 @@ extern "C" int32_t qv_probe_concurrent_streams(void) {
 // dev tool (tools/hwq_probe.py): the raw figure for any number of streams, not cached
 extern "C" double qv_debug_probe_rounds(int32_t n_streams) { return n_streams >= 1 && n_streams <= 32 ? probe_rounds(n_streams) : 0.0; }
 
+static std::mutex g_create_error_mu;
 void qv_set_error(qv_engine *e, const std::string &msg) {
-    if (e) e->last_error = msg;
-    else g_create_error = msg;
+    if (e) e->last_error = msg;   // callers hold e->mu (every entry point takes it before it can fail)
+    else { std::lock_guard<std::mutex> lk(g_create_error_mu); g_create_error = msg; }
 }
 
+// The text is copied into a buffer of the CALLING thread under the engine's lock: another thread's call may replace
+// (and free) the engine's string at any time, the returned pointer stays valid until this thread asks again.
 extern "C" const char *qv_last_error(const qv_engine *e) {
-    return e ? e->last_error.c_str() : g_create_error.c_str();
+    static thread_local std::string mine;
+    if (e) {
+        std::lock_guard<std::recursive_mutex> lk(const_cast<qv_engine *>(e)->mu);
+        mine = e->last_error;
+    } else {
+        std::lock_guard<std::mutex> lk(g_create_error_mu);
+        mine = g_create_error;
+    }
+    return mine.c_str();
 }
 
 extern "C" int qv_debug_int4_roundtrip(const float *w, int32_t N, int32_t K, float *out) {
@@ -498,12 +513,14 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
         c.n_post_graph = 0;
     }
     auto fail = [&](int rc) {
-        g_create_error = eng->last_error;
+        { std::lock_guard<std::mutex> lk(g_create_error_mu); g_create_error = eng->last_error; }
         qv_destroy(eng);
         return rc;
     };
     if (cfg->max_span < 2 || cfg->max_span > QV_MAX_SPAN) { qv_set_error(eng, "CTC_DIRECT_MAX_SPAN must be in [2,6]"); return fail(QV_ERR_ARG); }
-    if (!(cfg->text_weight == cfg->text_weight) || cfg->text_weight < 0.0) { qv_set_error(eng, "CTC_DIRECT_TEXT_WEIGHT must be a non-negative number"); return fail(QV_ERR_ARG); }
+    // c2c-direct/run.py:67 takes any float (negative weights included); only a non-finite one is refused here: inf * 0.0
+    // text scores would put NaNs into the final scores and leave the winner undefined
+    if (!std::isfinite(cfg->text_weight)) { qv_set_error(eng, "CTC_DIRECT_TEXT_WEIGHT must be a finite number"); return fail(QV_ERR_ARG); }
     if (cfg->top_text < 1 || cfg->top_text > QV_RUNNER_CAP - 1) { qv_set_error(eng, "CTC_DIRECT_TOP_TEXT must be in [1,127]"); return fail(QV_ERR_ARG); }
     if (cfg->top_span_refs < 0 || cfg->top_span_refs > 128) { qv_set_error(eng, "CTC_DIRECT_TOP_SPAN_REFS must be in [0,128]"); return fail(QV_ERR_ARG); }
     if (cfg->max_batch < 1 || cfg->max_samples < 400) { qv_set_error(eng, "bad capacity"); return fail(QV_ERR_ARG); }
@@ -576,7 +593,7 @@ extern "C" int qv_forward(qv_engine *eng, const float *audio_dev, const int64_t 
     if (!eng) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model (with_model = 0)"); return QV_ERR_NO_MODEL; }
     return qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, logprobs_dev, t_max, t_out_host,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, /*zero_pad_rows=*/true);
 }
 
 extern "C" int qv_decode_retrieve_rerank_async(qv_engine *eng, const float *lp, const int32_t *t_host, int32_t batch,
@@ -744,8 +761,12 @@ extern "C" int qv_upfirdn(qv_engine *eng, const float *x_dev, int64_t n_in, cons
 
 extern "C" const int32_t *qv_packed_results_dev(qv_engine *eng) { return eng ? eng->work.packed : nullptr; }
 
-extern "C" int32_t qv_context_count(const qv_engine *eng) { return eng ? eng->n_ctx : 0; }
-extern "C" int32_t qv_last_context(const qv_engine *eng) { return eng ? eng->cur_ctx : -1; }
+extern "C" int32_t qv_context_count(const qv_engine *eng) { return eng ? eng->n_ctx : 0; }   // fixed at qv_create
+extern "C" int32_t qv_last_context(const qv_engine *eng) {
+    if (!eng) return -1;
+    std::lock_guard<std::recursive_mutex> lk(const_cast<qv_engine *>(eng)->mu);
+    return eng->cur_ctx;
+}
 
 extern "C" int qv_wait_ctx(qv_engine *eng, int32_t k) {
     QV_SERIALISE(eng);
@@ -898,6 +919,12 @@ extern "C" int qv_profile_replay_kernel(qv_engine *eng, int32_t which, char *nam
     if (!eng || !name_out || name_cap < 8) return QV_ERR_ARG;
     if (!eng->model) { qv_set_error(eng, "engine created without a model"); return QV_ERR_NO_MODEL; }
     return qv_model_replay_kernel(eng, eng->model, which, name_out, name_cap);
+}
+
+extern "C" int qv_debug_attention_variant(int32_t mode) {
+    if (mode < -1 || mode > 2) return QV_ERR_ARG;
+    qv_attention_set_variant(mode);
+    return QV_OK;
 }
 
 extern "C" int qv_debug_gemm_tiles(int32_t mode) {

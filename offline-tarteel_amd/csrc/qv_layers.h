@@ -31,8 +31,11 @@ void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s);
 void launch_to_float(const half_t *x, float *y, size_t n, hipStream_t s);
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_pad, int batch, hipStream_t s);
+void qv_attention_set_variant(int mode);   // -1 environment / default, 0 two heads per block, 1 one head, 2 old kernel
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,
                      int t_max, int batch, hipStream_t s);
 void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_map, int t_out, hipStream_t s);
+// zeros rows [len[b], t_out) of every utterance of a dense [B][t_out][1025] tensor; t_min = the shortest utterance's frames
+void launch_zero_pad_rows(float *out, const int32_t *len, int t_out, int t_min, int batch, hipStream_t s);
 void launch_upfirdn(const float *x, int64_t n_in, const float *hflip, int P, int up, int down, int64_t m0, int64_t n_out,
                     float *y, hipStream_t s);

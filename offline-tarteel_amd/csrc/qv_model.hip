@@ -754,7 +754,7 @@ void qv_model_destroy(QvModel *m) {
 }
 
 int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64_t *len_host, int batch, int64_t n_max,
-                     float *logprobs, int t_max_out, int32_t *t_out_host, hipStream_t s) {
+                     float *logprobs, int t_max_out, int32_t *t_out_host, hipStream_t s, bool zero_pad_rows) {
     if (batch < 1 || batch > m->max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
     int B = batch, MB = m->max_batch;
     int tm_max = 0, t1m = 0, t2m = 0, t3m = 0, rows = 0;
@@ -949,6 +949,11 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     }
     // packed logits -> the caller's dense [B][t_max_out][1025] log-prob tensor (valid frames only)
     launch_logsoftmax(m->logits, HEAD_N, logprobs, M, m->row_map, t_max_out, s);
+    if (zero_pad_rows) {
+        int t_min = t_max_out;
+        for (int b = 0; b < B; ++b) t_min = std::min(t_min, (int)t_out_host[b]);
+        launch_zero_pad_rows(logprobs, d_l3, t_max_out, t_min, B, s);
+    }
     QV_HIP(hipGetLastError());
     m->last_batch = B; m->last_tmax = T; m->last_tm_max = tm_max; m->last_rows = M; m->last_t2m = t2m;
     return QV_OK;

@@ -123,6 +123,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_replay_gemm.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.qv_profile_replay_kernel.argtypes = [vp, i32, C.c_char_p, i32]
     lib.qv_debug_gemm_tiles.argtypes = [i32]
+    lib.qv_debug_attention_variant.argtypes = [i32]
     lib.qv_profile_inject_logprobs.argtypes = [vp, vp, i32, vp, i32]
     lib.qv_profile_stages.argtypes = [vp, i32]
     lib.qv_stage_times.argtypes = [vp, i32, vp]
@@ -365,6 +366,11 @@ class Engine:
         """process-wide GEMM tile policy (qv_debug_gemm_tiles): 0 = 128-wide only, 1 = default, 2 = 256 x 256
         wherever the shape allows, -1 = environment / default."""
         self._check(self.lib.qv_debug_gemm_tiles(int(mode)), "qv_debug_gemm_tiles")
+
+    def attention_variant(self, mode: int):
+        """process-wide attention kernel variant (qv_debug_attention_variant): 0 = two heads per block (default),
+        1 = one head per block, 2 = one wave per query tile, -1 = environment / default.  Bit-identical results."""
+        self._check(self.lib.qv_debug_attention_variant(int(mode)), "qv_debug_attention_variant")
 
     def profile_gemm(self, enable: bool):
         self._check(self.lib.qv_profile_gemm(self.h, int(enable)), "qv_profile_gemm")

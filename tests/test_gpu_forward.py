@@ -77,6 +77,22 @@ def test_logprobs_within_tolerance(setup):
         assert (got.argmax(-1) == setup["lp_ref"][i, :n].argmax(-1)).all()
 
 
+def test_rows_past_an_utterances_length_are_zero(setup):
+    """qv_forward's contract (include/qverse.h): onnxruntime returns exactly [1, T, 1025] to the reference
+    (mixed/run.py:59-63); a padded batch tensor holds zeros -- never uninitialised memory -- in rows t >= T[b]."""
+    eng, audio = setup["eng"], setup["audio"]
+    a = audio.cuda().contiguous()
+    for fill in (float("nan"), 7.0):
+        # poison the allocator's next block so that an untouched row would show
+        junk = torch.full((3, max(setup["t"]), 1025), fill, device="cuda")
+        del junk
+        lp, T = eng.forward(a, LENS)
+        torch.cuda.synchronize()
+        for b, t in enumerate(T):
+            assert bool((lp[b, t:] == 0).all()), (b, fill)
+            assert torch.equal(lp[b, :t], setup["lp"][b, :t])
+
+
 def test_batch_invariance(setup):
     """an utterance alone == the same utterance inside a padded batch."""
     eng, audio = setup["eng"], setup["audio"]
@@ -314,11 +330,14 @@ def test_fused_subsampling_equals_two_kernel_path(setup, monkeypatch):
 
 def test_specialised_attention_equals_one_wave_per_tile_kernel(setup, monkeypatch):
     """k_attention_ws (loader / consumer waves, K, V^T and the relative-position ring staged in LDS)
-    against the plain one-wave-per-query-tile kernel (QVERSE_ATT_OLD=1): bit-identical log-probs."""
-    monkeypatch.setenv("QVERSE_ATT_OLD", "1")
+    against the plain one-wave-per-query-tile kernel (qv_debug_attention_variant(2)): bit-identical log-probs."""
     eng = setup["eng"]
-    lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
-    torch.cuda.synchronize()
+    eng.attention_variant(2)
+    try:
+        lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
+        torch.cuda.synchronize()
+    finally:
+        eng.attention_variant(-1)
     assert t == setup["t"]
     for i, n in enumerate(t):
         assert torch.equal(lp[i, :n], setup["lp"][i, :n])
@@ -326,11 +345,14 @@ def test_specialised_attention_equals_one_wave_per_tile_kernel(setup, monkeypatc
 
 def test_two_heads_per_block_attention_equals_one_head_per_block(setup, monkeypatch):
     """k_attention_ws<2 heads, 2 stages, 192-row ring> (the default) against <1 head, 3 stages, 256-row ring>
-    (QVERSE_ATT_HPB=1): the same wave program per (head, query tile), bit-identical log-probs on a ragged batch."""
-    monkeypatch.setenv("QVERSE_ATT_HPB", "1")
+    (qv_debug_attention_variant(1)): the same wave program per (head, query tile), bit-identical log-probs on a ragged batch."""
     eng = setup["eng"]
-    lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
-    torch.cuda.synchronize()
+    eng.attention_variant(1)
+    try:
+        lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
+        torch.cuda.synchronize()
+    finally:
+        eng.attention_variant(-1)
     assert t == setup["t"]
     for i, n in enumerate(t):
         assert torch.equal(lp[i, :n], setup["lp"][i, :n])
@@ -440,12 +462,14 @@ def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
             one, t1 = eng.forward(dev[b: b + 1, :n].contiguous(), [n])
             assert t1[0] == t[b] and torch.equal(one[0, : t[b]], lp[b, : t[b]]), frames[b]
         if precision == 0:
-            for var in ("QVERSE_ATT_HPB", "QVERSE_ATT_OLD"):
-                monkeypatch.setenv(var, "1")
-                lp2, _ = eng.forward(dev, lens)
+            for var in (1, 2):   # one head per block, one wave per query tile
+                eng.attention_variant(var)
+                try:
+                    lp2, _ = eng.forward(dev, lens)
+                finally:
+                    eng.attention_variant(-1)
                 for b in range(len(lens)):
                     assert torch.equal(lp2[b, : t[b]], lp[b, : t[b]]), (var, frames[b])
-                monkeypatch.delenv(var)
     finally:
         eng.close()
 

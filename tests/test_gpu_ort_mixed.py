@@ -271,8 +271,13 @@ def test_prequantised_file_in_the_export_form_runs_on_its_own_integers(tmp_path)
             outs[(prec, path.name)] = lp.cpu()
         finally:
             eng.close()
-    assert torch.equal(outs[(0, "marked.qvw")], outs[(1, "marked.qvw")])
-    assert not torch.equal(outs[(1, "plain.qvw")], outs[(1, "marked.qvw")])
+    def valid(lp):   # the frames that exist; rows t >= T[b] are qv_forward's zero padding (checked below)
+        return torch.cat([lp[b, : T[b]].flatten() for b in range(len(T))])
+
+    assert torch.equal(valid(outs[(0, "marked.qvw")]), valid(outs[(1, "marked.qvw")]))
+    assert not torch.equal(valid(outs[(1, "plain.qvw")]), valid(outs[(1, "marked.qvw")]))
+    for lp in outs.values():
+        assert all(bool((lp[b, T[b]:] == 0).all()) for b in range(len(T)))
     print(f"[ort-prequant] marked file vs oracle: max {mx:.4f} rms {rms:.5f}; unmarked (re-quantised): max {mx_p:.4f} rms {rms_p:.5f}")
     assert mx <= 0.2 and rms <= 0.03, (mx, rms)
     assert rms_p > 1.5 * rms, (rms_p, rms)
