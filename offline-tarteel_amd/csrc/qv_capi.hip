@@ -148,8 +148,12 @@ extern "C" int qv_debug_int8_roundtrip(const float *w, int32_t N, int32_t K, flo
 }
 
 extern "C" const char *qv_build_info(void) {
-    static char buf[128];
-    snprintf(buf, sizeof buf, "libqverse gfx950 hip-%d.%d", HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
+    // the compiler is part of the contract: the GEMM loaders are inline-asm buffer loads with hand-counted s_waitcnt
+    // vmcnt(N), correct for the register allocation THIS hipcc produced (tests/test_loader_hazards.py checks the code
+    // objects of every build; a different compiler has to pass that test again)
+    static char buf[256];
+    snprintf(buf, sizeof buf, "libqverse gfx950 hip-%d.%d.%d clang-%s", HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH,
+             __clang_version__);
     return buf;
 }
 
