@@ -329,6 +329,12 @@ int32_t qv_weight_count(void);
 int qv_weight_spec(int32_t index, char *name_out, int32_t name_cap, int32_t *dims4_out, int32_t *ndim_out);
 int qv_weight_random(uint64_t seed, int32_t index, float *out, int64_t numel);
 
+/* What the engine's acoustic model actually runs on, as text: the precision mode and where the quantisation grids came
+ * from -- "weights quantised by the engine", or for a file converted from the reference's quantised ONNX
+ * (tools/convert_weights.py --onnx marks it) how many Linear tensors sit on the FILE's own MatMulNBits grid and how many
+ * run as dequantised f16 values (block sizes other than 128).  bench.py / the plugin report it next to a number. */
+int qv_weights_info(qv_engine *e, char *out, int32_t cap);
+
 /* Library build info: "gfx950;hip-x.y;..." */
 const char *qv_build_info(void);
 

@@ -925,6 +925,14 @@ extern "C" int qv_profile_replay_kernel(qv_engine *eng, int32_t which, char *nam
     return qv_model_replay_kernel(eng, eng->model, which, name_out, name_cap);
 }
 
+extern "C" int qv_weights_info(qv_engine *eng, char *out, int32_t cap) {
+    QV_SERIALISE(eng);
+    if (!eng || !out || cap < 16) return QV_ERR_ARG;
+    if (!eng->model) { snprintf(out, (size_t)cap, "no acoustic model (post-logits stages only)"); return QV_OK; }
+    qv_model_weights_info(eng->model, out, cap);
+    return QV_OK;
+}
+
 extern "C" int qv_debug_attention_variant(int32_t mode) {
     if (mode < -1 || mode > 2) return QV_ERR_ARG;
     qv_attention_set_variant(mode);

@@ -195,6 +195,7 @@ int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out_dev
 int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s);
 int qv_model_replay_kernel(qv_engine *eng, QvModel *m, int which, char *name_out, int cap);
 
+void qv_model_weights_info(const QvModel *m, char *out, int cap);
 void qv_model_select_ctx(QvModel *m, int k);
 // records stage event `i` of the current context on `s` when stage profiling is on (qv_capi.hip)
 void qv_stage_mark(qv_engine *eng, int i, hipStream_t s);

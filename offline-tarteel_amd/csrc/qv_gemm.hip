@@ -814,6 +814,38 @@ void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out)
     }
 }
 
+// The same device layout from a grid that is GIVEN (a weight file converted from the reference's quantised ONNX carries
+// MatMulNBits' own block scales and zero points, tools/convert_weights.py): w[n][k] = (q - zp[n][kb]) * scale[n][kb] holds
+// exactly in float32, so q = rint(w / scale + zp) returns the file's integer verbatim.  The device then multiplies by
+// half(scale) -- the file's float32 scale rounded once, 2.4e-4 relative at most -- and subtracts the file's zero point
+// (asymmetric blocks included: the {scale, 1024 + zp} pair format always carried one).  Returns the number of elements
+// whose recovered q was not an integer in [0, 15] to 1e-3 (0 for a consistent file).
+int64_t qv_pack_w4_given(const float *w, int N, int K, const float *scale, const float *zp, uint8_t *q_out, half_t *scale_out) {
+    const int nk = K / 64, nkb = K / 128;
+    int64_t bad = 0;
+    for (int n = 0; n < N; ++n) {
+        const float *row = w + (size_t)n * K;
+        for (int kb = 0; kb < nkb; ++kb) {
+            const float sc = scale[(size_t)n * nkb + kb], z = zp[(size_t)n * nkb + kb];
+            scale_out[((size_t)kb * N + n) * 2] = (half_t)sc;
+            scale_out[((size_t)kb * N + n) * 2 + 1] = (half_t)(1024.f + z);
+            for (int k = 0; k < 128; ++k) {
+                const float t = sc != 0.f ? row[kb * 128 + k] / sc + z : z;
+                int q = (int)nearbyintf(t);
+                if (fabsf(t - (float)q) > 1e-3f || q < 0 || q > 15) ++bad;
+                q = q < 0 ? 0 : q > 15 ? 15 : q;
+                int kk = kb * 128 + k, kt = kk >> 6, c = (kk & 63) >> 3, e = kk & 7;
+                int nib = (e >> 1) + 4 * (e & 1);
+                int pos = c ^ ((n >> 2) & 7);
+                size_t byte = ((size_t)(n >> 6) * nk + kt) * 2048 + (size_t)(n & 63) * 32 + pos * 4 + (nib >> 1);
+                if (nib & 1) q_out[byte] = (uint8_t)((q_out[byte] & 0x0F) | (q << 4));
+                else q_out[byte] = (uint8_t)((q_out[byte] & 0xF0) | q);
+            }
+        }
+    }
+    return bad;
+}
+
 // Per-row symmetric int8: scale = max|w| / 127 (1 for an all-zero row), q = clamp(floor(w / scale + 0.5), -127, 127),
 // stored as q + 128.  oracle/fastconformer_ref.py:quant_dequant_int8 mirrors this exactly.
 void qv_pack_w8(const float *w, int N, int K, uint8_t *q_out, float *scale_out) {

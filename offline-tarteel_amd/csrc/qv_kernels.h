@@ -100,6 +100,9 @@ __global__ void k_gemm(GemmArgs g);
 
 // host-side packer for the W4A16 layout above (w: [N][K] f32 row-major; N % 64 == 0, K % 128 == 0)
 void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out);
+// ... from a GIVEN grid (a pre-quantised weight file's own MatMulNBits blocks): scale, zp [N][K/128]; returns the count of
+// elements that did not sit on that grid (0 for a consistent file)
+int64_t qv_pack_w4_given(const float *w, int N, int K, const float *scale, const float *zp, uint8_t *q_out, half_t *scale_out);
 // ... and for the W8A16 layout (N % 64 == 0, K % 64 == 0): scale = max|w| / 127 per row, q = round(w / scale)
 void qv_pack_w8(const float *w, int N, int K, uint8_t *q_out, float *scale_out);
 

@@ -55,6 +55,10 @@ struct HostWeights {
         auto it = t.find("qv.prequantised");
         return it != t.end() && !it->second.empty() && it->second[0] != 0.f;
     }
+    // MatMulNBits' own grid of a Linear weight, block 128: "<key>#int4_scale" / "<key>#int4_zp", [N][K/128] each (absent for
+    // other block sizes: such a tensor runs as its dequantised f16 values)
+    const std::vector<float> *int4_scale(const std::string &n) const { auto it = t.find(n + "#int4_scale"); return it == t.end() ? nullptr : &it->second; }
+    const std::vector<float> *int4_zp(const std::string &n) const { auto it = t.find(n + "#int4_zp"); return it == t.end() ? nullptr : &it->second; }
     float int8_scale(const std::string &n) const {   // 0: none given (derive max|w| / 127)
         auto it = t.find(n + "#int8_scale");
         return it != t.end() && it->second.size() == 1 ? it->second[0] : 0.f;
@@ -265,6 +269,7 @@ struct QvModel : QvActs {
     bool w4;             // QV_PREC_MIXED_INT4_INT8 / QV_PREC_ORT_MIXED: Linear-layer weights are block-128 int4
     bool ort;            // QV_PREC_ORT_MIXED: every Conv runs DynamicQuantizeLinear -> ConvInteger (qv_ort.h)
     bool prequant;       // the weight file is marked pre-quantised (HostWeights::prequantised): nothing is re-quantised
+    int prequant_w4_linears = 0, prequant_f16_linears = 0;   // ... its Linear weights on the file's int4 grid / as f16 values
     OrtDw o_c0, o_dw2, o_dw5;
     OrtConv o_pw3, o_pw6, o_head;
     const float *o_dw2_b, *o_dw5_b;
@@ -319,11 +324,23 @@ std::vector<half_t> to_half(const std::vector<float> &v) {
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-// upload a Linear weight [N][K]: f16, or int4 nibbles + scales when the model runs W4A16
-int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K, WMat *out) {
-    if (!m->w4 || m->prequant) return up(eng, m, to_half(w), &out->w);
+// upload a Linear weight [N][K]: f16, or int4 nibbles + scales when the model runs W4A16.  A pre-quantised file's weight
+// goes onto the FILE's grid (`gs`, `gz`: its block scales / zero points) and is never re-quantised; without a grid
+// (MatMulNBits block size other than 128) it runs as its dequantised values, f16.
+int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K, WMat *out,
+           const std::vector<float> *gs = nullptr, const std::vector<float> *gz = nullptr) {
+    const bool grid = m->prequant && gs && gz && gs->size() == (size_t)N * (K / 128) && gz->size() == gs->size();
+    if (!m->w4 || (m->prequant && !grid)) {
+        if (m->w4) ++m->prequant_f16_linears;
+        return up(eng, m, to_half(w), &out->w);
+    }
     std::vector<uint8_t> q((size_t)N * K / 2, 0);
     std::vector<half_t> sc((size_t)N * (K / 128) * 2);
+    if (grid) {
+        const int64_t bad = qv_pack_w4_given(w.data(), N, K, gs->data(), gz->data(), q.data(), sc.data());
+        if (bad) { qv_set_error(eng, "pre-quantised weight file: a Linear weight does not sit on the int4 grid it declares"); return QV_ERR_IO; }
+        ++m->prequant_w4_linears;
+    } else
     qv_pack_w4(w.data(), N, K, q.data(), sc.data());
     TRY(up(eng, m, q, &out->q));
     return up(eng, m, sc, &out->sc);
@@ -498,6 +515,27 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
         TRY(up(eng, m, pb, &m->head_b));
     }
     std::vector<float> posw((size_t)N_LAYERS * QV_D * QV_D);
+    // the file's own int4 grid of a Linear weight (pre-quantised files only), concatenated along N for fused weights
+    std::vector<float> gs_tmp, gz_tmp;
+    auto grid_of = [&](std::initializer_list<std::string> names, const std::vector<float> *&gs, const std::vector<float> *&gz) {
+        gs = gz = nullptr;
+        if (!m->prequant) return;
+        gs_tmp.clear(); gz_tmp.clear();
+        for (const std::string &n : names) {
+            const std::vector<float> *a = hw.int4_scale(n), *b = hw.int4_zp(n);
+            if (!a || !b || a->size() != b->size()) return;
+            gs_tmp.insert(gs_tmp.end(), a->begin(), a->end());
+            gz_tmp.insert(gz_tmp.end(), b->begin(), b->end());
+        }
+        gs = &gs_tmp; gz = &gz_tmp;
+    };
+    auto up_lin = [&](const std::string &name, int N, int K, WMat *out) {
+        const std::vector<float> *gs, *gz;
+        grid_of({name}, gs, gz);
+        return up_mat(eng, m, hw.get(name), N, K, out, gs, gz);
+    };
+    std::vector<float> pos_gs, pos_gz;
+    bool pos_grid = m->prequant;
     for (int i = 0; i < N_LAYERS; ++i) {
         std::string p = "encoder.layers." + std::to_string(i) + ".";
         LayerW &L = m->L[i];
@@ -506,13 +544,13 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
             TRY(up(eng, m, hw.get(p + lns[k] + ".weight"), &L.ln_g[k]));
             TRY(up(eng, m, hw.get(p + lns[k] + ".bias"), &L.ln_b[k]));
         }
-        TRY(up_mat(eng, m, hw.get(p + "feed_forward1.linear1.weight"), QV_FF, QV_D, &L.ff1_w1));
+        TRY(up_lin(p + "feed_forward1.linear1.weight", QV_FF, QV_D, &L.ff1_w1));
         TRY(up(eng, m, hw.get(p + "feed_forward1.linear1.bias"), &L.ff1_b1));
-        TRY(up_mat(eng, m, hw.get(p + "feed_forward1.linear2.weight"), QV_D, QV_FF, &L.ff1_w2));
+        TRY(up_lin(p + "feed_forward1.linear2.weight", QV_D, QV_FF, &L.ff1_w2));
         TRY(up(eng, m, hw.get(p + "feed_forward1.linear2.bias"), &L.ff1_b2));
-        TRY(up_mat(eng, m, hw.get(p + "feed_forward2.linear1.weight"), QV_FF, QV_D, &L.ff2_w1));
+        TRY(up_lin(p + "feed_forward2.linear1.weight", QV_FF, QV_D, &L.ff2_w1));
         TRY(up(eng, m, hw.get(p + "feed_forward2.linear1.bias"), &L.ff2_b1));
-        TRY(up_mat(eng, m, hw.get(p + "feed_forward2.linear2.weight"), QV_D, QV_FF, &L.ff2_w2));
+        TRY(up_lin(p + "feed_forward2.linear2.weight", QV_D, QV_FF, &L.ff2_w2));
         TRY(up(eng, m, hw.get(p + "feed_forward2.linear2.bias"), &L.ff2_b2));
         {
             std::vector<float> w, b;
@@ -522,16 +560,23 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
                 w.insert(w.end(), ww.begin(), ww.end());
                 b.insert(b.end(), bb.begin(), bb.end());
             }
-            TRY(up_mat(eng, m, w, 3 * QV_D, QV_D, &L.qkv_w));
+            const std::vector<float> *gs, *gz;
+            grid_of({p + "self_attn.linear_q.weight", p + "self_attn.linear_k.weight", p + "self_attn.linear_v.weight"}, gs, gz);
+            TRY(up_mat(eng, m, w, 3 * QV_D, QV_D, &L.qkv_w, gs, gz));
             TRY(up(eng, m, b, &L.qkv_b));
         }
-        TRY(up_mat(eng, m, hw.get(p + "self_attn.linear_out.weight"), QV_D, QV_D, &L.out_w));
+        TRY(up_lin(p + "self_attn.linear_out.weight", QV_D, QV_D, &L.out_w));
         TRY(up(eng, m, hw.get(p + "self_attn.linear_out.bias"), &L.out_b));
         TRY(up(eng, m, hw.get(p + "self_attn.pos_bias_u"), &L.bias_u));
         TRY(up(eng, m, hw.get(p + "self_attn.pos_bias_v"), &L.bias_v));
         {
             const auto &pw = hw.get(p + "self_attn.linear_pos.weight");
             for (size_t k = 0; k < pw.size(); ++k) posw[(size_t)i * QV_D * QV_D + k] = pw[k];
+            const std::vector<float> *a = hw.int4_scale(p + "self_attn.linear_pos.weight"), *b = hw.int4_zp(p + "self_attn.linear_pos.weight");
+            if (pos_grid && a && b && a->size() == b->size()) {
+                pos_gs.insert(pos_gs.end(), a->begin(), a->end());
+                pos_gz.insert(pos_gz.end(), b->begin(), b->end());
+            } else pos_grid = false;
         }
         {
             // GLU pairing: 64-column groups = [32 value channels | their 32 gate channels]
@@ -590,7 +635,7 @@ int prepare_weights(qv_engine *eng, QvModel *m, const HostWeights &hw) {
                             hw.int8_scale(p + "conv.pointwise_conv2.weight")));
         TRY(up(eng, m, hw.get(p + "conv.pointwise_conv2.bias"), &L.pw2_b));
     }
-    TRY(up_mat(eng, m, posw, N_LAYERS * QV_D, QV_D, &m->pos_w));
+    TRY(up_mat(eng, m, posw, N_LAYERS * QV_D, QV_D, &m->pos_w, pos_grid ? &pos_gs : nullptr, pos_grid ? &pos_gz : nullptr));
     // linear_pos has no bias; the GEMM epilogue always reads one
     TRY(up(eng, m, std::vector<float>((size_t)N_LAYERS * QV_D, 0.f), &m->zero_bias));
     return QV_OK;
@@ -990,6 +1035,16 @@ static int replay_args(qv_engine *eng, QvModel *m, int which, GemmArgs &a, int &
         a.mm_in = m->mm + (size_t)MM_LAYER(0) * m->max_batch * QV_MM_STRIDE; a.mm_out = (uint32_t *)a.mm_in + (size_t)m->max_batch * QV_MM_STRIDE;
     }
     return QV_OK;
+}
+
+void qv_model_weights_info(const QvModel *m, char *out, int cap) {
+    const char *prec = m->ort ? "ort-mixed" : m->w4 ? "mixed-int4-int8" : "fp16";
+    if (!m->prequant)
+        snprintf(out, (size_t)cap, "precision %s; weights quantised by the engine%s", prec, m->w4 ? " (symmetric block-128 int4 Linear)" : " (none: f16)");
+    else
+        snprintf(out, (size_t)cap, "precision %s; pre-quantised file: %d Linear tensors on the file's own int4 grid (W4A16), %d as "
+                 "dequantised f16 values%s", prec, m->prequant_w4_linears, m->prequant_f16_linears,
+                 m->ort ? "; Conv weights on the file's int8 integers" : m->w4 ? "; pointwise-conv weights as dequantised f16 values" : "");
 }
 
 int qv_model_replay_kernel(qv_engine *eng, QvModel *m, int which, char *name_out, int cap) {

@@ -124,6 +124,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_replay_kernel.argtypes = [vp, i32, C.c_char_p, i32]
     lib.qv_debug_gemm_tiles.argtypes = [i32]
     lib.qv_debug_attention_variant.argtypes = [i32]
+    lib.qv_weights_info.argtypes = [vp, C.c_char_p, i32]
     lib.qv_profile_inject_logprobs.argtypes = [vp, vp, i32, vp, i32]
     lib.qv_profile_stages.argtypes = [vp, i32]
     lib.qv_stage_times.argtypes = [vp, i32, vp]
@@ -366,6 +367,12 @@ class Engine:
         """process-wide GEMM tile policy (qv_debug_gemm_tiles): 0 = 128-wide only, 1 = default, 2 = 256 x 256
         wherever the shape allows, -1 = environment / default."""
         self._check(self.lib.qv_debug_gemm_tiles(int(mode)), "qv_debug_gemm_tiles")
+
+    def weights_info(self) -> str:
+        """precision mode and where the quantisation grids came from (qv_weights_info)"""
+        buf = C.create_string_buffer(512)
+        self._check(self.lib.qv_weights_info(self.h, buf, 512), "qv_weights_info")
+        return buf.value.decode()
 
     def attention_variant(self, mode: int):
         """process-wide attention kernel variant (qv_debug_attention_variant): 0 = two heads per block (default),

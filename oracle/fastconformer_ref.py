@@ -146,6 +146,41 @@ def random_weights(seed: int = 20260630, n_layers: int = N_LAYERS) -> dict[str, 
     return out
 
 
+def structured_weights(seed: int = 20260630, rank: int = 16, mix: float = 0.15, head_gain: float = 6.0,
+                       blank_bias: float = 3.0, n_layers: int = N_LAYERS) -> dict[str, torch.Tensor]:
+    """Seeded weights with STRUCTURE, for the quantised-arithmetic noise-floor measurements (tools/ort_noise_floor.py,
+    tools/ort_delta.py, tests/test_gpu_ort_mixed.py): i.i.d. N(0, 1/fan_in) matrices make every activation tensor
+    unstructured and every posterior near-uniform -- the worst case for rounding-boundary flips.
+    Here every weight matrix is a rank-`rank` product plus `mix` of the i.i.d. matrix (same Frobenius norm, so the
+    activation scales of random_weights() are kept: trained layers are far from full rank), and the CTC head is
+    `head_gain` times larger with `blank_bias` added to the blank logit (a trained CTC model emits peaked posteriors,
+    mostly blank).  Still not a trained model -- the real file is absent -- but the two properties the objection names."""
+    w = random_weights(seed, n_layers)
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    out = {}
+    for name, t in w.items():
+        a = t.numpy()
+        shape = a.shape
+        # matrices: Linear [N,K], 1x1 / pointwise convolutions [N,K,1(,1)]; depthwise / 3x3 stencils and vectors stay
+        is_matrix = name.endswith("weight") and a.ndim >= 2 and shape[0] >= 64 and int(np.prod(shape[1:])) >= 64
+        if is_matrix:
+            m = a.reshape(shape[0], -1).astype(np.float64)
+            u = rng.standard_normal((m.shape[0], rank))
+            v = rng.standard_normal((rank, m.shape[1]))
+            lr = u @ v
+            lr *= np.linalg.norm(m) / np.linalg.norm(lr)
+            m2 = (1.0 - mix) * lr + mix * m
+            m2 *= np.linalg.norm(m) / np.linalg.norm(m2)
+            a = m2.reshape(shape).astype(np.float32)
+        out[name] = torch.from_numpy(np.ascontiguousarray(a))
+    head = "ctc_decoder.decoder_layers.0."
+    out[head + "weight"] = out[head + "weight"] * np.float32(head_gain)
+    b = out[head + "bias"].clone()
+    b[VOCAB - 1] += np.float32(blank_bias)
+    out[head + "bias"] = b
+    return out
+
+
 # ------------------------------------------------------------------- int4 weights -----
 # The reference's "mixed" model file stores the Linear-layer MatMuls as 4-bit MatMulNBits
 # ("MatMulNBitsQuantizer int4", experiments/c2c-direct-mixed/run.py:1-9; the script it names,

@@ -135,17 +135,32 @@ def test_whole_layer_and_head_on_device_inputs(setup):
         _report(f"head[{b}]", got, want, 2e-6)
 
 
+FLOOR_K = 1.5   # device-vs-oracle may be at most this many times the oracle's distance from itself on the same clip
+
+
+def _assert_on_the_floor(tag, got, floor):
+    mx, rms, same = got
+    print(f"[ort-e2e] {tag}: hip vs OrtMixed max {mx:.4f} rms {rms:.5f} argmax {same:.4f} | oracle vs itself: max {floor['max']:.4f} "
+          f"rms {floor['rms']:.5f} argmax {floor['argmax']:.4f}  ({', '.join(f'{k} {v[0]:.4f}/{v[1]:.5f}' for k, v in floor['rows'].items())})")
+    # within north_star's 1e-2 outright, or within FLOOR_K x what the reference's arithmetic reproduces of itself
+    assert mx <= max(FLOOR_K * floor["max"], 1e-2), (tag, mx, floor["max"])
+    assert rms <= max(FLOOR_K * floor["rms"], 2.5e-3), (tag, rms, floor["rms"])
+    assert same >= floor["argmax"] - 0.03, (tag, same, floor["argmax"])
+
+
 def test_logprobs_against_the_oracle_and_its_noise_floor(setup):
+    """End to end against the oracle, judged against the ORACLE'S OWN reproducibility on the same clips (ort_floor.py):
+    the device may be at most FLOOR_K x as far from the oracle as the oracle is from itself when only the float32
+    summation order / one ulp of its Linear inputs change -- not a fixed number that a 4x regression would pass."""
+    from ort_floor import delta, oracle_floor
+
     R, w, T = setup["R"], setup["w"], setup["t"]
     lp_ref, t_ref = R.forward(w, setup["audio"], LENS, ort=R.OrtMixed())
     assert t_ref.tolist() == T
     got = setup["lp"].cpu()
-    d = torch.cat([(got[b, : T[b]] - lp_ref[b, : T[b]]).flatten() for b in range(len(T))])
-    mx, rms = float(d.abs().max()), float(d.pow(2).mean().sqrt())
-    same = sum(int((got[b, : T[b]].argmax(-1) == lp_ref[b, : T[b]].argmax(-1)).sum()) for b in range(len(T))) / sum(T)
-    print(f"[ort-e2e] hip_ort vs OrtMixed: max {mx:.4f} rms {rms:.5f} argmax {same:.4f}")
-    # the oracle against itself (threads 1 vs 16): 0.05-0.07 max, 0.012 rms, 0.97-0.99 argmax
-    assert mx <= 0.2 and rms <= 0.03 and same >= 0.95, (mx, rms, same)
+    floor = oracle_floor(R, w, setup["audio"], LENS, lp_ref, T)
+    _assert_on_the_floor("random weights, 3 ragged clips", delta(got, lp_ref, T), floor)
+    mx, rms, same = delta(got, lp_ref, T)
     for b, n in enumerate(T):
         assert torch.allclose(got[b, :n].exp().sum(-1), torch.ones(n), atol=1e-4)
     # the f16-arithmetic mixed path is a different model from this one
@@ -154,11 +169,96 @@ def test_logprobs_against_the_oracle_and_its_noise_floor(setup):
     eng1 = Engine(device=0, with_model=True, seed=SEED, precision=1, max_batch=4, max_samples=80000)
     try:
         lp1, _ = eng1.forward(setup["audio"].cuda().contiguous(), LENS)
-        d1 = torch.cat([(lp1[b, : T[b]].cpu() - lp_ref[b, : T[b]]).flatten() for b in range(len(T))])
-        print(f"[ort-e2e] hip_mixed (W4A16/W8A16) vs OrtMixed: max {float(d1.abs().max()):.4f} rms {float(d1.pow(2).mean().sqrt()):.5f}")
-        assert float(d1.pow(2).mean().sqrt()) > 1.5 * rms
+        d1 = delta(lp1, lp_ref, T)
+        print(f"[ort-e2e] hip_mixed (W4A16/W8A16) vs OrtMixed: max {d1[0]:.4f} rms {d1[1]:.5f}")
+        assert d1[1] > 1.5 * rms
     finally:
         eng1.close()
+
+
+def test_structured_weights_stay_on_their_own_floor(tmp_path):
+    """The same judgement on weights with structure (rank-16 + noise matrices, a peaked blank-biased CTC head:
+    fastconformer_ref.structured_weights): i.i.d. weights are the worst case for rounding-boundary flips; if the floor
+    is lower here, the device has to follow it down (the bound is relative)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    from offline_tarteel_amd.engine import Engine
+    from oracle import fastconformer_ref as R
+    from ort_floor import delta, oracle_floor
+
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("convert_weights", str(root / "tools" / "convert_weights.py"))
+    C = importlib.util.module_from_spec(spec)
+    sys.modules["convert_weights"] = C
+    spec.loader.exec_module(C)
+    w = R.structured_weights(SEED)
+    shapes = C.weight_shapes(C._lib())
+    path = tmp_path / "structured.qvw"
+    C.write_qvw(path, {k: w[k].numpy() for k in shapes})
+    lens = [48000, 30000]
+    audio = torch.from_numpy(synth_audio(2, 48000, seed=5))
+    audio[1, lens[1]:] = 0
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    lp_ref, t_ref = R.forward(w, audio, lens, ort=R.OrtMixed())
+    T = t_ref.tolist()
+    floor = oracle_floor(R, w, audio, lens, lp_ref, T)
+    peak = float(torch.cat([lp_ref[b, : T[b]].exp().max(-1).values for b in range(2)]).mean())
+    print(f"[ort-e2e] structured weights: mean max-probability {peak:.3f}")
+    eng = Engine(device=0, with_model=True, weights_path=str(path), precision=2, max_batch=2, max_samples=48000)
+    try:
+        lp, t = eng.forward(audio.cuda().contiguous(), lens)
+        assert t == T
+        _assert_on_the_floor("structured weights", delta(lp, lp_ref, T), floor)
+    finally:
+        eng.close()
+
+
+def test_the_integer_chain_from_the_audio(setup):
+    """The stage tests above start every stage from the DEVICE's own input tensor: they pin each stage, not the chain.
+    Here both sides run the whole chain from the audio and the stage tensors are compared in place: conv.2 / conv.3 /
+    conv.5 / conv.6 outputs and, for layers 0 and 8, norm_conv -> pointwise_conv1 + GLU -> depthwise + BN + Swish.  A
+    stage's output moves in steps of its quantiser's LSB (s_x * s_w per unit of the integer accumulator), so `differs`
+    counts elements further apart than a quarter of the smallest such step seen in the tensor, i.e. elements whose
+    integer accumulators are not the same.  Reported per stage: the fraction that differs and the largest difference
+    relative to the tensor's range; the first stage with a difference is named.  What is asserted: the first integer
+    stage (conv.0 + conv.2, fed by log-mel features that agree to ~1e-4) has < 2 % of its elements off and nothing
+    further than 2 % of its range, and no later stage of the subsampling stack is further than 5 % of its range --
+    differences enter through rounding-boundary flips of individual activations and stay local."""
+    eng, R, w = setup["eng"], setup["R"], setup["w"]
+    tm, l2, l3, T = setup["tm"], setup["l2"], setup["l3"], setup["t"]
+    B = len(LENS)
+    taps = {}
+    R.forward(w, setup["audio"], LENS, ort=R.OrtMixed(), taps=taps)
+    stages = [("mel", eng.forward_tap(0, 0, (B, max(tm), 80)).cpu(), taps["mel"], tm),
+              ("conv.0+conv.2", eng.forward_tap(6, 0, (B, max(l2), 20, 256)).cpu(), taps["c1"], l2),
+              ("conv.3+ReLU", eng.forward_tap(7, 0, (B, max(l2), 20, 256)).cpu(), taps["c1p"], l2),
+              ("conv.5", eng.forward_tap(8, 0, (B, max(l3), 10, 256)).cpu(), taps["c2"], l3),
+              ("conv.6+ReLU", eng.forward_tap(9, 0, (B, max(l3), 10, 256)).cpu(), taps["c2p"].half().float(), l3)]
+    for layer in (0, 8):
+        stages += [(f"L{layer} norm_conv", eng.forward_tap(3, layer, (B, max(T), 512)).cpu(), taps[f"lnc{layer}"], T),
+                   (f"L{layer} pw1+GLU", eng.forward_tap(4, layer, (B, max(T), 512)).cpu(), taps[f"glu{layer}"], T),
+                   (f"L{layer} dw+BN+Swish", eng.forward_tap(5, layer, (B, max(T), 512)).cpu(), taps[f"dw{layer}"], T)]
+    first = None
+    table = {}
+    for name, got, want, lens in stages:
+        worst_frac, worst_rel = 0.0, 0.0
+        for b in range(B):
+            g, r = got[b, : lens[b]].float(), want[b, : lens[b]].float()
+            rng = float(r.abs().max()) or 1.0
+            d = (g - r).abs()
+            worst_frac = max(worst_frac, float((d > 2e-4 * rng).float().mean()))
+            worst_rel = max(worst_rel, float(d.max()) / rng)
+        table[name] = (worst_frac, worst_rel)
+        if first is None and name != "mel" and worst_frac > 0:
+            first = name
+        print(f"[ort-chain] {name}: {100 * worst_frac:.3f} % of the elements differ, largest difference {worst_rel:.2e} of the range")
+    print(f"[ort-chain] first stage with a difference: {first}")
+    assert table["mel"][1] <= 1e-3
+    assert table["conv.0+conv.2"][0] <= 0.02 and table["conv.0+conv.2"][1] <= 0.02, table["conv.0+conv.2"]
+    for name in ("conv.3+ReLU", "conv.5", "conv.6+ReLU"):
+        assert table[name][1] <= 0.05, (name, table[name])
 
 
 def test_batch_invariance_is_exact(setup):
@@ -198,14 +298,14 @@ def test_configs2_batch256_ort_mixed_vs_oracle_sample():
         assert T == [126] * 256
         one, _ = eng.forward(a[200:201].contiguous(), [n])
         assert torch.equal(one[0], lp[200])
+        from ort_floor import delta, oracle_floor
+
         w = R.random_weights(20260630)
+        torch.set_num_threads(min(16, torch.get_num_threads()))
         for b in (0, 255):
             ref, _ = R.forward(w, audio[b: b + 1], [n], ort=R.OrtMixed())
-            d = (lp[b].cpu() - ref[0])
-            mx, rms = float(d.abs().max()), float(d.pow(2).mean().sqrt())
-            same = float((lp[b].cpu().argmax(-1) == ref[0].argmax(-1)).float().mean())
-            print(f"[ort-e2e] B=256 utt {b}: max {mx:.4f} rms {rms:.5f} argmax {same:.4f}")
-            assert mx <= 0.25 and rms <= 0.035 and same >= 0.93, (b, mx, rms, same)
+            floor = oracle_floor(R, w, audio[b: b + 1], [n], ref, [126], one_thread=False, seeds=(1, 2, 3))
+            _assert_on_the_floor(f"B=256 utt {b}", delta(lp[b: b + 1], ref, [126]), floor)
         res = eng.predict_batch(a, [n] * 256, want_text=False)
         assert len(res) == 256 and all(r["t_frames"] == 126 for r in res)
     finally:
@@ -249,37 +349,49 @@ def test_prequantised_file_in_the_export_form_runs_on_its_own_integers(tmp_path)
     lp_ref, t_ref = R.forward(wt, audio, lens, ort=R.OrtMixed(int4_linears=False, conv_scales=scales))
     T = t_ref.tolist()
 
+    from ort_floor import delta, oracle_floor
+
     def run(path):
         eng = Engine(device=0, with_model=True, weights_path=str(path), precision=2, max_batch=2, max_samples=32000)
         try:
             lp, t = eng.forward(audio.cuda().contiguous(), lens)
             assert t == T
-            d = torch.cat([(lp[b, : T[b]].cpu() - lp_ref[b, : T[b]]).flatten() for b in range(len(T))])
-            return float(d.abs().max()), float(d.pow(2).mean().sqrt())
+            return delta(lp, lp_ref, T)
         finally:
             eng.close()
 
-    mx, rms = run(marked)
-    mx_p, rms_p = run(plain)
-    # precisions 0 and 1 on a marked file: nothing is re-quantised, so both run the file's values as f16 operands -- the
-    # same bits (precision 1 on an UNMARKED file packs its own int4 / int8 grids and differs)
-    outs = {}
+    got = run(marked)
+    mx, rms = got[:2]
+    mx_p, rms_p = run(plain)[:2]
+    floor = oracle_floor(R, wt, audio, lens, lp_ref, T, int4_linears=False, conv_scales=scales)
+    # A marked file is never re-quantised, and it does not silently fall back to f16 either: under precisions 1
+    # and 2 every Linear weight runs W4A16 on the FILE's own MatMulNBits grid (its integers, its zero points, its scale
+    # rounded to f16), which qv_weights_info reports; precision 0 runs the dequantised values as f16 operands.
+    outs, infos = {}, {}
     for prec, path in ((0, marked), (1, marked), (1, plain)):
         eng = Engine(device=0, with_model=True, weights_path=str(path), precision=prec, max_batch=2, max_samples=32000)
         try:
             lp, t = eng.forward(audio.cuda().contiguous(), lens)
             outs[(prec, path.name)] = lp.cpu()
+            infos[(prec, path.name)] = eng.weights_info()
         finally:
             eng.close()
+
     def valid(lp):   # the frames that exist; rows t >= T[b] are qv_forward's zero padding (checked below)
         return torch.cat([lp[b, : T[b]].flatten() for b in range(len(T))])
 
-    assert torch.equal(valid(outs[(0, "marked.qvw")]), valid(outs[(1, "marked.qvw")]))
-    assert not torch.equal(valid(outs[(1, "plain.qvw")]), valid(outs[(1, "marked.qvw")]))
+    print("[ort-prequant]", infos)
+    assert "103 Linear tensors on the file's own int4 grid" in infos[(1, "marked.qvw")] and ", 0 as dequantised" in infos[(1, "marked.qvw")]
+    assert "quantised by the engine" in infos[(1, "plain.qvw")]
+    same_values = float((valid(outs[(0, "marked.qvw")]) - valid(outs[(1, "marked.qvw")])).abs().max())
+    requantised = float((valid(outs[(0, "marked.qvw")]) - valid(outs[(1, "plain.qvw")])).abs().max())
+    print(f"[ort-prequant] precision 1 vs precision 0 on the marked file: max {same_values:.4f}; re-quantised (unmarked): {requantised:.4f}")
+    assert 0.0 < same_values <= 2e-2          # the same weight VALUES: f16 scale rounding and W4A16 vs f16 operand rounding only
+    assert requantised > 5 * same_values      # a second quantisation on another grid is a different model
     for lp in outs.values():
         assert all(bool((lp[b, T[b]:] == 0).all()) for b in range(len(T)))
     print(f"[ort-prequant] marked file vs oracle: max {mx:.4f} rms {rms:.5f}; unmarked (re-quantised): max {mx_p:.4f} rms {rms_p:.5f}")
-    assert mx <= 0.2 and rms <= 0.03, (mx, rms)
+    _assert_on_the_floor("marked file", got, floor)
     assert rms_p > 1.5 * rms, (rms_p, rms)
 
 
@@ -312,13 +424,14 @@ def test_edge_shapes_one_frame_thirty_seconds_and_silence():
             assert t1[0] == T[b] and torch.equal(one[0, : T[b]], lp[b, : T[b]]), b
         w = R.random_weights(SEED)
         torch.set_num_threads(min(16, torch.get_num_threads()))
+        from ort_floor import delta, oracle_floor
+
         for b in (0, 4, 3, 1):
-            ref, tr = R.forward(w, audio[b: b + 1, : lens[b]].contiguous(), [lens[b]], ort=R.OrtMixed())
+            one = audio[b: b + 1, : lens[b]].contiguous()
+            ref, tr = R.forward(w, one, [lens[b]], ort=R.OrtMixed())
             assert int(tr[0]) == T[b]
-            d = lp[b, : T[b]].cpu() - ref[0, : T[b]]
-            mx, rms = float(d.abs().max()), float(d.pow(2).mean().sqrt())
-            print(f"[ort-edge] utt {b} (T = {T[b]}): max {mx:.4f} rms {rms:.5f}")
-            assert mx <= 0.25 and rms <= 0.04, (b, mx, rms)
+            floor = oracle_floor(R, w, one, [lens[b]], ref, [T[b]], one_thread=False, seeds=(1, 2, 3))
+            _assert_on_the_floor(f"edge utt {b} (T = {T[b]})", delta(lp[b: b + 1], ref, [T[b]]), floor)
         res = eng.predict_batch(a, lens)
         assert [r["t_frames"] for r in res] == T
     finally:

@@ -239,7 +239,14 @@ def test_export_like_model_keeps_the_files_own_quantisation(tmp_path):
     k0 = "encoder.layers.0.feed_forward1.linear1.weight"
     assert np.abs(R.quant_dequant_int4_f32scale(deq[k0]) - deq[k0]).max() > 1e-4
     extra = C.prequantised_extras(meta)
-    assert extra[C.PREQUANT_KEY].tolist() == [1.0] and len(extra) == 1 + len(conv)
+    # marker + one scale per int8 Conv weight + the file's own int4 grid (block scales and zero points) per Linear weight
+    assert extra[C.PREQUANT_KEY].tolist() == [1.0] and len(extra) == 1 + len(conv) + 2 * len(lin)
+    for k in lin:
+        n_rows, kk = shapes[k][0], int(np.prod(shapes[k][1:]))
+        gs, gz = extra[k + "#int4_scale"].reshape(n_rows, kk // 128), extra[k + "#int4_zp"].reshape(n_rows, kk // 128)
+        q = sd[k].reshape(n_rows, kk // 128, 128) / gs[..., None] + gz[..., None]       # the file's integers, verbatim
+        assert np.abs(q - np.rint(q)).max() <= 1e-3 and q.min() >= -1e-3 and q.max() <= 15 + 1e-3, k
+    assert len({float(z) for k in lin for z in extra[k + "#int4_zp"]}) > 1                # asymmetric: zero points other than 8
     out = tmp_path / "w.qvw"
     C.write_qvw(out, {k: sd[k] for k in shapes}, extra)
     raw = out.read_bytes()
@@ -255,3 +262,19 @@ def test_export_like_model_keeps_the_files_own_quantisation(tmp_path):
     assert np.array_equal(ops._w8[kc][0].numpy(), q_file) and ops._w8[kc][1] == scales[kc]
     x = torch.ones(2, 512)
     assert torch.equal(ops.linear({k0: torch.from_numpy(deq[k0])}, k0, x, None), torch.nn.functional.linear(x, torch.from_numpy(deq[k0])))
+
+
+def test_converter_refuses_int8_grids_the_engine_cannot_hold():
+    """the engine's ConvInteger path holds ONE symmetric scale per Conv weight tensor.  A file quantised with
+    per_channel=True or with a non-zero weight zero point must not be re-derived or clamped silently under a
+    'runs on the file's own integers' marker: the converter refuses it.  MatMulInteger Linear weights get no scale entry
+    (the engine reads none)."""
+    C = _load("convert_weights")
+    ok = {"a.conv.weight": {"kind": "int8", "op": "ConvInteger", "per_channel": False, "scale": np.float32(0.01), "zero_point": 0},
+          "b.linear.weight": {"kind": "int8", "op": "MatMulInteger", "per_channel": False, "scale": np.float32(0.02), "zero_point": 0}}
+    extra = C.prequantised_extras(ok)
+    assert set(extra) == {C.PREQUANT_KEY, "a.conv.weight" + C.SCALE_SUFFIX}
+    for bad in ({"per_channel": True, "zero_point": 0}, {"per_channel": False, "zero_point": 3}):
+        meta = {"a.conv.weight": {"kind": "int8", "op": "ConvInteger", "scale": np.float32(0.01), **bad}}
+        with pytest.raises(SystemExit):
+            C.prequantised_extras(meta)

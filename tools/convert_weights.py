@@ -183,7 +183,19 @@ def prequantised_extras(meta: dict) -> dict:
     extra = {PREQUANT_KEY: np.ones(1, np.float32)}
     for name, m in meta.items():
         if m.get("kind") == "int8":
+            if m.get("op", "ConvInteger") != "ConvInteger":
+                continue          # MatMulInteger Linear weights: the engine holds no int8 Linear path and reads no scale for them
+            if m.get("per_channel") or int(m.get("zero_point", 0)) != 0:
+                raise SystemExit(f"{name}: int8 Conv weight with " + ("per-channel scales" if m.get("per_channel") else
+                                 f"zero point {m['zero_point']}") + " -- the engine's ConvInteger path holds ONE symmetric scale "
+                                 "per weight tensor (onnxruntime quantize_dynamic's default); re-export with per_channel=False / "
+                                 "symmetric weights, or convert the float model instead")
             extra[name + SCALE_SUFFIX] = np.array([m["scale"]], np.float32)
+        elif m.get("kind") == "int4" and int(m.get("block", 0)) == 128 and "scales" in m:
+            # the file's own MatMulNBits grid: the engine's W4A16 GEMM runs the file's integers with the file's zero points
+            # (scale rounded to f16); other block sizes have no grid entry and run as the dequantised f16 values
+            extra[name + "#int4_scale"] = np.asarray(m["scales"], np.float32).reshape(-1)
+            extra[name + "#int4_zp"] = np.asarray(m["zero_points"], np.float32).reshape(-1)
     return extra
 
 

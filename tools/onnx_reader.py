@@ -186,7 +186,8 @@ def read_model(path):
 
 
 # ------------------------------------------------------------------ dequantisation ----
-def dequant_matmul_nbits(node: Node, inits: dict) -> np.ndarray:
+def dequant_matmul_nbits(node: Node, inits: dict, with_grid: bool = False):
+    """the [N, K] float32 matrix of a MatMulNBits node; with_grid: also (block size, scales [N, nb], zero points [N, nb])"""
     K, N = int(node.attrs["K"]), int(node.attrs["N"])
     bits, bs = int(node.attrs.get("bits", 4)), int(node.attrs["block_size"])
     if bits != 4:
@@ -208,8 +209,11 @@ def dequant_matmul_nbits(node: Node, inits: dict) -> np.ndarray:
         else:                                   # already unpacked (float zero points)
             zp = z.astype(np.float32).reshape(N, nb, 1)
     else:
-        zp = np.float32(8.0)
-    return ((q - zp) * scales).reshape(N, nb * bs)[:, :K]
+        zp = np.full((N, nb, 1), 8.0, np.float32)
+    w = ((q - zp) * scales).reshape(N, nb * bs)[:, :K]
+    if with_grid:
+        return w, bs, scales.reshape(N, nb).copy(), np.asarray(zp, np.float32).reshape(N, nb).copy()
+    return w
 
 
 def dequant_linear(x: np.ndarray, scale: np.ndarray, zp, axis: int = 1) -> np.ndarray:
@@ -253,9 +257,9 @@ def float_weights(nodes, inits):
             if len(n.inputs) > 2 and n.inputs[2] in out and n.inputs[2] not in named:
                 out[scope + ".bias"] = (out[n.inputs[2]][0], f"{n.op} bias named by its node scope", None)
         if n.op == "MatMulNBits":
-            w = dequant_matmul_nbits(n, inits)
+            w, bs, g_scale, g_zp = dequant_matmul_nbits(n, inits, with_grid=True)
             for key in {scope, _strip(n.inputs[1])} - {""}:
-                out[key] = (w, "MatMulNBits [out, in]", {"kind": "int4"})
+                out[key] = (w, "MatMulNBits [out, in]", {"kind": "int4", "block": bs, "scales": g_scale, "zero_points": g_zp})
         elif n.op == "DequantizeLinear" and n.inputs[0] in inits:
             zp = inits.get(n.inputs[2]) if len(n.inputs) > 2 and n.inputs[2] else None
             w = dequant_linear(inits[n.inputs[0]], inits[n.inputs[1]], zp, int(n.attrs.get("axis", 1)))
@@ -268,10 +272,12 @@ def float_weights(nodes, inits):
                 continue
             zp = inits.get(n.inputs[3]) if len(n.inputs) > 3 and n.inputs[3] else inits.get(base + "_zero_point")
             w = dequant_linear(inits[n.inputs[1]], scale, zp, 0 if n.op == "ConvInteger" else 1)
-            meta = None
-            if np.asarray(scale).size == 1:
-                meta = {"kind": "int8", "scale": np.float32(np.asarray(scale, np.float32).reshape(-1)[0]),
-                        "zero_point": int(np.asarray(zp).reshape(-1)[0]) if zp is not None else 0}
+            # (per-channel scales / non-zero weight zero points are carried so that the converter can REFUSE them: the
+            # engine's precision-2 path holds one symmetric scale per Conv weight tensor, what quantize_dynamic writes)
+            zps = np.asarray(zp).reshape(-1) if zp is not None else np.zeros(1)
+            meta = {"kind": "int8", "op": n.op, "per_channel": bool(np.asarray(scale).size != 1),
+                    "scale": np.float32(np.asarray(scale, np.float32).reshape(-1)[0]),
+                    "zero_point": int(zps[0]) if zps.size == 1 else int(np.abs(zps).max())}
             keys = {base} | ({scope, scope + ".weight"} if scope else set())
             for key in keys:
                 out[key] = (w if n.op == "ConvInteger" else w.T,

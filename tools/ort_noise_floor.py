@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--out", default="")
+    ap.add_argument("--structured", action="store_true",
+                    help="low-rank + noise weight matrices and a peaked, blank-biased CTC head (fastconformer_ref.structured_weights) "
+                         "instead of i.i.d. weights: does the floor drop when activations and posteriors have structure?")
+    ap.add_argument("--head-gain", type=float, default=6.0, help="with --structured: factor on the CTC head's weight")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -49,7 +53,7 @@ def main():
     lens = [n, n - 8000]
     audio = torch.from_numpy(synth_audio(2, n))
     audio[1, lens[1]:] = 0
-    w = R.random_weights(20260630)
+    w = R.structured_weights(20260630, head_gain=args.head_gain) if args.structured else R.random_weights(20260630)
     torch.set_num_threads(args.threads)
     lp_ref, T = R.forward(w, audio, lens, ort=R.OrtMixed())
     T = [int(t) for t in T]
@@ -92,6 +96,9 @@ def main():
     doc = {"what": "self-consistency of the onnxruntime-semantics oracle (OrtMixed: int4 MatMulNBits + DynamicQuantizeLinear / "
                    "ConvInteger on every Conv) under changes that are not errors; seeded random weights, two clips of %g s, "
                    "reference = the oracle itself with %d threads" % (args.seconds, args.threads),
+           "weights": f"structured (rank-16 + 15 % i.i.d., CTC head x{args.head_gain:g}, blank bias +3)" if args.structured else "i.i.d. seeded",
+           "posterior_peak": {"mean_max_prob": round(float(torch.cat([lp_ref[b, : T[b]].exp().max(-1).values for b in range(2)]).mean()), 4),
+                              "blank_argmax_fraction": round(float(torch.cat([(lp_ref[b, : T[b]].argmax(-1) == 1024).float() for b in range(2)]).mean()), 4)},
            "frames": T, "rows": rows}
     print(json.dumps(doc, indent=1))
     if args.out:
