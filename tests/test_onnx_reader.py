@@ -7,6 +7,7 @@ packed zero points), int8 tensors behind DequantizeLinear, ConvInteger weights w
 quantisation, plain float initializers in raw / typed / fp16 encodings, and an anonymous MatMul
 operand that only the consuming node's scope identifies."""
 
+import pytest
 import importlib.util
 import struct
 import sys
