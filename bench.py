@@ -506,6 +506,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    fetched["batches"] = fetched["rows"] = 0
     import gc
 
     gc.collect()

@@ -33,9 +33,20 @@ def make_noise_ops(R, eps: float, seed: int, **ort_kw):
     return Noise()
 
 
-def oracle_floor(R, w, audio, lens, lp_ref, T, threads: int | None = None, seeds=(1, 2), one_thread: bool = True, **ort_kw):
+def make_f16_input_ops(R, **ort_kw):
+    """the device's design point as a perturbation of the ORACLE: every Linear input rounded to float16 (what an f16-operand
+    MFMA GEMM sees); quantisers and integer convolutions stay exact"""
+    class F16(R.OrtMixed):
+        def linear(self, w, name, x, bias_name):
+            return super().linear(w, name, x.half().float(), bias_name)
+
+    return F16(**ort_kw)
+
+
+def oracle_floor(R, w, audio, lens, lp_ref, T, threads: int | None = None, seeds=(1, 2), one_thread: bool = True,
+                 f16_inputs: bool = False, **ort_kw):
     """envelope of oracle-vs-oracle over: 1 intra-op thread (when `one_thread`), 1e-7 relative noise on the Linear inputs
-    (one run per seed).  lp_ref = the oracle's result with `threads` threads (the caller's reference).
+    (one run per seed), and -- only when `f16_inputs` -- the Linear inputs rounded to float16.  lp_ref = the oracle's result with `threads` threads (the caller's reference).
     Returns {"max": .., "rms": .., "argmax": .., "rows": {...}}."""
     threads = threads or torch.get_num_threads()
     rows = {}
@@ -47,5 +58,7 @@ def oracle_floor(R, w, audio, lens, lp_ref, T, threads: int | None = None, seeds
             torch.set_num_threads(threads)
     for s in seeds:
         rows[f"ulp_noise_seed{s}"] = delta(R.forward(w, audio, lens, ort=make_noise_ops(R, 1e-7, s, **ort_kw))[0], lp_ref, T)
+    if f16_inputs:
+        rows["f16_linear_inputs"] = delta(R.forward(w, audio, lens, ort=make_f16_input_ops(R, **ort_kw))[0], lp_ref, T)
     return {"max": max(r[0] for r in rows.values()), "rms": max(r[1] for r in rows.values()),
             "argmax": min(r[2] for r in rows.values()), "rows": rows}

@@ -430,7 +430,11 @@ def test_edge_shapes_one_frame_thirty_seconds_and_silence():
             one = audio[b: b + 1, : lens[b]].contiguous()
             ref, tr = R.forward(w, one, [lens[b]], ort=R.OrtMixed())
             assert int(tr[0]) == T[b]
-            floor = oracle_floor(R, w, one, [lens[b]], ref, [T[b]], one_thread=False, seeds=(1, 2, 3))
+            # a clip of ONE frame has a handful of values per quantiser: sub-ulp noise rarely flips any of them (the floor
+            # reads ~3e-3 or exactly 0), while the f16 rounding of the Linear inputs -- the device's design point, equal
+            # to the other perturbations on ordinary clips (profiles/r03_a_ort_noise_floor.json) -- does.  The edge
+            # shapes are therefore judged against the envelope that includes that row.
+            floor = oracle_floor(R, w, one, [lens[b]], ref, [T[b]], one_thread=False, seeds=(1, 2, 3), f16_inputs=True)
             _assert_on_the_floor(f"edge utt {b} (T = {T[b]})", delta(lp[b: b + 1], ref, [T[b]]), floor)
         res = eng.predict_batch(a, lens)
         assert [r["t_frames"] for r in res] == T
