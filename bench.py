@@ -69,6 +69,9 @@ def parse():
                     help="skip the short secondary legs (BASELINE configs[2] and configs[4] workloads) of the default run")
     ap.add_argument("--cpu-sample", type=int, default=24, help="clips timed on the host for cpu_baseline")
     ap.add_argument("--literal", action="store_true", help="run search()/pass-3 even when the gate passes")
+    ap.add_argument("--capacity-seconds", type=float, default=0.0,
+                    help="engine capacity (max_samples) in seconds, default = the clip length: a production engine is created for "
+                         "the longest clip it may ever see (the plugin's default is 30 s) and must not pay for it on shorter ones")
     ap.add_argument("--contexts", type=int, default=4,
                     help="batches in flight per GPU (execution contexts of the engine, 1..8)")
     ap.add_argument("--precision", choices=("fp16", "mixed", "ort"), default="fp16",
@@ -406,6 +409,8 @@ def main():
     lengths = [n] * B
     # TTA: the 1.1x-slowed copies are 10 % longer than the clips
     cap = int(n * 1.1) + 1600 if tta else n
+    if args.capacity_seconds > 0:
+        cap = max(cap, int(args.capacity_seconds * 16000))
     # TTA: anchor pass of the next step + the two perturbed batches of this one: three batches in flight at most
     n_ctx = min(args.contexts, 3) if tta else args.contexts
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=cap,
@@ -688,7 +693,7 @@ def main():
                        "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
                        "skip_unused_passes": not args.literal, "weights": args.precision, "weights_effective": weights_info,
-                       "batches_in_flight": n_ctx,
+                       "batches_in_flight": n_ctx, "engine_capacity_seconds": round(cap / 16000.0, 2),
                        "concurrent_streams_probe": int(eng.lib.qv_probe_concurrent_streams())},
             "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "realistic_mix": mix, "extra": extra,
         }

@@ -42,7 +42,7 @@ constexpr int NSLOT = 4;                      // LDS ring slots of one unit each
 constexpr int UNIT = QV_FFN_UNIT_BYTES;
 constexpr int NCHUNK = QV_FF / 32;            // 64 chunks of 32 hidden channels
 
-__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ffn_sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // scheduling-group masks of __builtin_amdgcn_sched_group_barrier
 #define SG_VALU 0x002
@@ -59,6 +59,10 @@ __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.
 #define QV_SB() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// ABL: timing ablations for tools/ffn_fused_bench.hip (results are WRONG with any bit set; the product launches ABL = 0):
+//   1 no activation VALU, 2 GEMM1 without the accumulate dependency (C = 0 every MFMA), 4 no s_barrier, 8 no fragment reads,
+//   16 no weight staging (no global loads, no ds_writes), 32 GEMM2 without the accumulate dependency
+template <int ABL>
 __global__ __launch_bounds__(256) void k_ffn_fused(FfnArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *sB1 = (float *)(smem + NSLOT * UNIT);   // b1 [2048] behind the ring
@@ -74,10 +78,12 @@ __global__ __launch_bounds__(256) void k_ffn_fused(FfnArgs g) {
     const unsigned lofs = (unsigned)(wave * 4096 + lane * 16);
     u32x4 st[4];
     auto fetch = [&](int u) {
+        if (ABL & 16) { if (u > 2) return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lofs + i * 1024, u * UNIT, 0);
     };
     auto put = [&](int u) {
+        if (ABL & 16) { if (u > 2) return; }
         unsigned char *s = smem + (u & (NSLOT - 1)) * UNIT + lofs;
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(u32x4 *)(s + i * 1024) = st[i];
@@ -112,13 +118,14 @@ __global__ __launch_bounds__(256) void k_ffn_fused(FfnArgs g) {
     int u = 0;
     half8 fr[4];
     auto rd1 = [&](half8 &f, int unit, int fi) {
+        if (ABL & 8) { if (unit > 0) return; }
         f = *(const half8 *)(smem + (unit & (NSLOT - 1)) * UNIT + lane * 16 + fi * 1024);
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i) rd1(fr[i], 0, i);
     auto step_end = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         ++u;
     };
     const std::integral_constant<int, 0> C0{};
@@ -128,8 +135,8 @@ __global__ __launch_bounds__(256) void k_ffn_fused(FfnArgs g) {
     // of k-step `part` of GEMM2's operand (lane (token, hi), register 4 q + e <-> hidden channel 8 q + 4 hi + e of the chunk)
     auto act1 = [&](const f32x16 &acc, const f32x4 &ba, const f32x4 &bb, int part, int e, half8 &out) {
         const float a = acc[8 * part + e] + ba[e], b = acc[8 * part + 4 + e] + bb[e];
-        out[e] = (half_t)(a * sigm(a));
-        out[4 + e] = (half_t)(b * sigm(b));
+        out[e] = (half_t)(a * ffn_sigm(a));
+        out[4 + e] = (half_t)(b * ffn_sigm(b));
     };
 
     // GEMM1 step: K half kh of the NEXT chunk's hidden tile into `nxt`; meanwhile (ACT) half of the CURRENT chunk's
@@ -144,13 +151,18 @@ __global__ __launch_bounds__(256) void k_ffn_fused(FfnArgs g) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             // fragment i of this unit is in buffer i % 4 (read four MFMAs ago); its buffer is refilled right behind the MFMA
+            if (ABL & 2) {
+                f32x16 z = {};
+                const f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i & 3], xf[16 * kh + i], z, 0, 0, 0);
+                asm volatile("" ::"v"(t));
+            } else
             nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i & 3], xf[16 * kh + i], nxt, 0, 0, 0);
             rd1(fr[i & 3], i < 12 ? u : u + 1, (i + 4) & 15);
-            if (ACT && (i & 3) == 0) {
+            if (ACT && !(ABL & 1) && (i & 3) == 0) {
                 const int e = i >> 2;
                 const float a = cur[8 * kh + e] + bp[e], b = cur[8 * kh + 4 + e] + bp[8 + e];
-                hfo[e] = (half_t)(a * sigm(a));
-                hfo[4 + e] = (half_t)(b * sigm(b));
+                hfo[e] = (half_t)(a * ffn_sigm(a));
+                hfo[4 + e] = (half_t)(b * ffn_sigm(b));
             }
             if ((i & 3) == 3) {
 #pragma unroll
@@ -172,6 +184,11 @@ __global__ __launch_bounds__(256) void k_ffn_fused(FfnArgs g) {
         QV_SB();
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (ABL & 32) {
+                f32x16 z = {};
+                const f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i & 3], hf[i & 1], z, 0, 0, 0);
+                asm volatile("" ::"v"(t));
+            } else
             acc2[nh * 8 + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i & 3], hf[i & 1], acc2[nh * 8 + (i >> 1)], 0, 0, 0);
             rd1(fr[i & 3], i < 12 ? u : u + 1, (i + 4) & 15);
             if ((i & 3) == 3) {
@@ -274,11 +291,19 @@ void qv_ffn_pack(const float *w1, const float *w2, half_t *out) {
     }
 }
 
+#ifdef QV_FFN_ABLATIONS
+template <int ABL>
+void launch_ffn_fused_abl(const FfnArgs &a, hipStream_t s) {
+    (void)hipFuncSetAttribute((const void *)k_ffn_fused<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * UNIT + QV_FF * 4);
+    hipLaunchKernelGGL(k_ffn_fused<ABL>, dim3((a.M + 127) / 128), dim3(256), NSLOT * UNIT + QV_FF * 4, s, a);
+}
+#endif
+
 void launch_ffn_fused(const FfnArgs &a, hipStream_t s) {
     static bool opted = false;
     if (!opted) {
-        (void)hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * UNIT + QV_FF * 4);
+        (void)hipFuncSetAttribute((const void *)k_ffn_fused<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * UNIT + QV_FF * 4);
         opted = true;
     }
-    hipLaunchKernelGGL(k_ffn_fused, dim3((a.M + 127) / 128), dim3(256), NSLOT * UNIT + QV_FF * 4, s, a);
+    hipLaunchKernelGGL(k_ffn_fused<0>, dim3((a.M + 127) / 128), dim3(256), NSLOT * UNIT + QV_FF * 4, s, a);
 }

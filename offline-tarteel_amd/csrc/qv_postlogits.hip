@@ -1695,7 +1695,11 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
         if (rc) return rc;
         qv_stage_mark(eng, 3, stream);
         if (skip & 16) { }
-        else if (wk.t_cap > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        // the long-target variant (up to 768 states per candidate: 12 state registers per lane, 3 KB of LDS per wave) only when
+        // THIS batch has a clip of more than 384 frames -- not whenever the engine COULD hold one: an engine created for
+        // 30 s clips used to run every 10 s batch through it (round 4: tools/sweep.py's 10 s row, 4.8 ms, against bench.py's
+        // 3.8 ms for the same batch on an engine sized for it).  2L + 1 <= T <= t_max <= 384 holds for every candidate then.
+        else if (t_max > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
         else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
         hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
         qv_stage_mark(eng, 4, stream);
