@@ -3,7 +3,7 @@
 // experiments/c2c-direct-mixed/run.py:55-63).  Layouts and the kernel: qv_ffn.hip.
 #pragma once
 
-#include "qv_kernels.h"
+#include "../offline-tarteel_amd/csrc/qv_kernels.h"
 
 #define QV_FFN_UNIT_BYTES 16384          // one staged unit of weights = 16 MFMA fragments of 1 KB
 #define QV_FFN_UNITS (2 * (QV_FF / 32) * 2)   // 256 units = W1 + W2 = 4 MB
@@ -21,6 +21,7 @@ struct FfnArgs {
 
 // Host side: W1 [2048][512], W2 [512][2048] (f32, row-major = the state-dict tensors) -> the unit stream the kernel walks
 // front to back.  Stream order: W1(0)a W1(0)b, then for c = 0..63: [W1(c+1)a W1(c+1)b if c < 63] W2(c)a W2(c)b, where
-// chunk c is hidden channels 32c..32c+31, a / b are the two K halves of W1 (256 wide) resp. the two N halves of W2.
+// chunk c is hidden channels 32c..32c+31, a / b are the two K halves of W1 (256 wide) resp. the two 16-deep k-steps of W2
+// (all 512 output columns each).
 void qv_ffn_pack(const float *w1, const float *w2, half_t *stream_out);
 void launch_ffn_fused(const FfnArgs &a, hipStream_t s);

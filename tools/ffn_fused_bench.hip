@@ -7,7 +7,7 @@
 #include "../offline-tarteel_amd/csrc/qv_gemm.hip"
 #include "../offline-tarteel_amd/csrc/qv_gemm256.hip"
 #define QV_FFN_ABLATIONS
-#include "../offline-tarteel_amd/csrc/qv_ffn.hip"
+#include "ffn_fused.hip"
 
 #include <math.h>
 #include <stdlib.h>
@@ -118,14 +118,16 @@ int main(int argc, char **argv) {
     const double t_2 = time("FFN-up + FFN-down back to back", [&] { launch_gemm(EPI_F16_SWISH, up, 0); launch_gemm(EPI_RESID, dn, 0); });
     // ablations (wrong results, timing only): where does a step's time go?
     time("  abl 1  no activation VALU", [&] { launch_ffn_fused_abl<1>(fa, 0); });
-    time("  abl 2  GEMM1 without the accumulate chain", [&] { launch_ffn_fused_abl<2>(fa, 0); });
-    time("  abl 34 neither GEMM accumulates", [&] { launch_ffn_fused_abl<34>(fa, 0); });
     time("  abl 4  no s_barrier", [&] { launch_ffn_fused_abl<4>(fa, 0); });
     time("  abl 8  no fragment reads", [&] { launch_ffn_fused_abl<8>(fa, 0); });
     time("  abl 16 no weight staging", [&] { launch_ffn_fused_abl<16>(fa, 0); });
     time("  abl 24 no reads, no staging", [&] { launch_ffn_fused_abl<24>(fa, 0); });
-    time("  abl 29 MFMA + chain only", [&] { launch_ffn_fused_abl<29>(fa, 0); });
-    time("  abl 63 bare MFMA issue", [&] { launch_ffn_fused_abl<63>(fa, 0); });
+    time("  abl 28 no reads, staging, barrier", [&] { launch_ffn_fused_abl<28>(fa, 0); });
+    time("  abl 29 MFMA + accumulate chain only", [&] { launch_ffn_fused_abl<29>(fa, 0); });
+    time("  abl 93 only GEMM2's MFMAs", [&] { launch_ffn_fused_abl<93>(fa, 0); });
+    time("  abl 157 only GEMM1's MFMAs", [&] { launch_ffn_fused_abl<157>(fa, 0); });
+    time("  abl 221 no MFMA at all (loop skeleton)", [&] { launch_ffn_fused_abl<221>(fa, 0); });
+    time("  abl 192 everything but the MFMAs", [&] { launch_ffn_fused_abl<192>(fa, 0); });
     const int blocks = (M + 127) / 128;
     printf("fused: %d blocks of 128 tokens (%d CUs busy); CU-microseconds per module: fused %.0f, two-kernel %.0f (up: 256 x 256 tiles %d, down %d)\n",
            blocks, blocks < 256 ? blocks : 256, t_f * (blocks < 256 ? blocks : 256), t_2 * 256.0, ((M + 255) / 256) * 8, ((M + 255) / 256) * 2);
