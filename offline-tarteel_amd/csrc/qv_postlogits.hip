@@ -276,6 +276,50 @@ __device__ __forceinline__ int lcs_dispatch(int W, const uint64_t *pm, int strid
     return lcs_core<16>(pm, stride, text, n, m);
 }
 
+// ---- the same recurrence with the pattern's words spread over G neighbouring lanes (G = 4, 8, 16; lane w of the group
+// owns word w) as a skewed wavefront: at step t lane w applies text code j = t - w, with the carry lane w - 1 produced for
+// that code one step earlier (one DPP row shift).  A lane's serial chain is then one 64-bit add per text code instead of
+// W of them: the span pass and the window scans last as long as their LONGEST lane, and for transcripts of several hundred
+// characters (W = 4..7) that lane used to walk 1,000+ codes x W words.  Same integer result as lcs_core.
+// All G lanes pass the same text / n / m / W; the return value is valid in every lane of the group.
+template <int G>
+__device__ __forceinline__ int lcs_systolic(const uint64_t *__restrict__ pm, int stride, const uint8_t *__restrict__ text, int n,
+                                            int m, int W, int w) {
+    uint64_t V = ~0ull;
+    unsigned cout = 0;                      // the carry this lane produced in its last step
+    const bool act = w < W;
+    const int total = n + G - 1;            // steps t = 0 .. total - 1; lane w is at code j = t - w
+    for (int t0 = 0; t0 < total; t0 += 8) {
+        const int j0 = t0 - w;
+        uint64_t chunk = 0;                 // the lane's next 8 codes (text buffers are padded by >= 8 bytes)
+        if (j0 < n && j0 > -8) chunk = j0 >= 0 ? *(const u64_unaligned *)(text + j0) : (*(const u64_unaligned *)text << (8 * -j0));
+        uint64_t mk[8];                     // their match-mask words, requested together in front of the dependent chain
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = j0 + e, c = (int)((chunk >> (8 * e)) & 0xFF);
+            const bool valid = act && j >= 0 && j < n && c < QV_NSYM;
+            const uint64_t x = pm[(size_t)(valid ? c : 0) * stride + (act ? w : 0)];
+            mk[e] = valid ? x : 0ull;       // a zero mask leaves V alone and produces no carry
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned cin = (unsigned)__builtin_amdgcn_update_dpp(0, (int)cout, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+            if (w == 0) cin = 0;
+            unsigned long long carry;
+            const uint64_t s2 = __builtin_addcll(V, V & mk[e], (unsigned long long)cin, &carry);
+            V = s2 | (V & ~mk[e]);
+            cout = (unsigned)carry;
+        }
+    }
+    uint64_t z = ~V;
+    const int lo = w * 64;
+    if (m < lo + 64) z &= (m > lo) ? ((1ull << (m - lo)) - 1ull) : 0ull;
+    int cnt = act ? __popcll(z) : 0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    return cnt;
+}
+
 // stage the transcript's match masks (both the spaced and the spaceless pattern, 10 KB) in LDS
 // LDS row stride of the match masks (u64 units).  With the global stride QV_MAXW = 16 (128 B) every
 // symbol's word w sat in the same two banks, so the 64 lanes of a wave - each on a different
@@ -1014,7 +1058,8 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
         for (int si = 0; si < 20; ++si)
             cum[si + 1] = cum[si] + (si < u.n_surah20 ? tab.surah_len[u.surah20[si] - 1] * per : 0);
         const int total = cum[20];
-        for (int g = blockIdx.x * 256 + tid; g < total; g += gridDim.x * 256) {
+        // job g -> (span text, bound check); false = nothing to score (window runs off the surah / cannot beat pass 1)
+        auto job = [&](int g, uint32_t &start, int &n, double &bonus, unsigned long long &key) -> bool {
             int si = 0, base = 0;
 #pragma unroll
             for (int k = 1; k < 20; ++k)
@@ -1023,22 +1068,51 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
             int s0 = tab.surah_start[s - 1], sl = tab.surah_len[s - 1];
             int r = g - base;
             int span = 2 + r / sl, i = r % sl;
-            if (i + span > sl) continue;
+            if (i + span > sl) return false;
             int v0 = s0 + i, v1 = v0 + span - 1;
             int nl = tab.nobsm_len[v0];
-            uint32_t start = tab.clean_off[v0] + (nl ? tab.clean_len[v0] - nl : 0);
-            int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
+            start = tab.clean_off[v0] + (nl ? tab.clean_len[v0] - nl : 0);
+            n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - start);
             int mn = m < n ? m : n;
-            double bonus = 0.0;                   // of the span's first verse (quran_db.py:352-353)
+            bonus = 0.0;                          // of the span's first verse (quran_db.py:352-353)
             for (int k = 0; k < u.hint_n; ++k)
                 if (v0 == u.hint_v[k]) bonus = u.hint_bonus[k];
             double ub = __dadd_rn(ratio_from(mn, m, n), bonus);
-            if (!((ub < 1.0 ? ub : 1.0) > u.best1_score)) continue;
-            int l = lcs_dispatch(W, pm, QV_PMS, tab.clean + start, n, m);
+            if (!((ub < 1.0 ? ub : 1.0) > u.best1_score)) return false;
+            key = (unsigned long long)base + (unsigned long long)(i * per + span - 2);
+            return true;
+        };
+        auto score = [&](int l, int n, double bonus, unsigned long long key) {
             double raw = __dadd_rn(ratio_from(l, m, n), bonus);
             double sc = raw < 1.0 ? raw : 1.0;
-            unsigned long long key = (unsigned long long)base + (unsigned long long)(i * per + span - 2);
             if (better(sc, key, best, bkey)) { best = sc; bkey = key; }
+        };
+        if (W <= 2) {
+            // short transcripts: one span per lane (the chain is at most two words per code)
+            for (int g = blockIdx.x * 256 + tid; g < total; g += gridDim.x * 256) {
+                uint32_t start; int n; double bonus; unsigned long long key;
+                if (!job(g, start, n, bonus, key)) continue;
+                score(lcs_dispatch(W, pm, QV_PMS, tab.clean + start, n, m), n, bonus, key);
+            }
+        } else {
+            // long transcripts: G lanes per span (lcs_systolic).  Every group first walks to its next span that survives
+            // the bound -- most do not -- so that the groups of a wave enter the recurrence together.
+            auto run = [&](auto g_c) {
+                constexpr int G = decltype(g_c)::value;
+                const int w = tid & (G - 1), ngroups = gridDim.x * (256 / G);
+                for (int g = blockIdx.x * (256 / G) + tid / G; g < total; g += ngroups) {
+                    uint32_t start = 0; int n = 0; double bonus = 0.0; unsigned long long key = 0;
+                    bool ok = false;
+                    for (; g < total; g += ngroups)
+                        if ((ok = job(g, start, n, bonus, key))) break;
+                    if (!ok) break;
+                    const int l = lcs_systolic<G>(pm, QV_PMS, tab.clean + start, n, m, W, w);
+                    if (w == 0) score(l, n, bonus, key);
+                }
+            };
+            if (W <= 4) run(std::integral_constant<int, 4>{});
+            else if (W <= 8) run(std::integral_constant<int, 8>{});
+            else run(std::integral_constant<int, 16>{});
         }
     }
     block_best(best, bkey, sh_s, sh_k);
