@@ -821,9 +821,13 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
 // transcript against the clean text (c2c-direct/run.py:284-297; a space matches nothing in the spaceless pattern, so
 // the spaced text is streamed).
 __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int mode) {
+    // grid = (utterance, chunk of the job list): the hardware dispatches workgroups x-fastest, and in mode 1 chunk 0 holds
+    // every utterance's LONGEST verses (len_order).  With the chunk on x the 64 long blocks were spread over the whole
+    // launch and the last of them started when everything else was done; on y they all start first (longest first).
+    const int slot = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y;
     int b;
-    if (mode == 0) b = blockIdx.y;
-    else { if ((int)blockIdx.y >= *wk.n_fail) return; b = wk.fail_list[blockIdx.y]; }
+    if (mode == 0) b = slot;
+    else { if (slot >= *wk.n_fail) return; b = wk.fail_list[slot]; }
     const QvUtt &u = wk.utt[b];
     if (u.q_len == 0) return;
     const int m = u.q_len, ms = u.qs_len, W = (m + 63) >> 6, N = tab.n_verses, qw = u.q_words;
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
     const uint8_t *q = wk.q + (size_t)b * QV_MAXQ;
     const int lane = threadIdx.x & 63;
     const int jobs = mode == 0 ? u.n_cand1 * 3 : N * 3;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < jobs; j += gridDim.x * 256) {
+    for (int j = chunk * 256 + threadIdx.x; j < jobs; j += nchunk * 256) {
         int v, variant;
         if (mode == 0) { v = cand1[j / 3]; variant = j % 3; }
         else {
@@ -1034,9 +1038,13 @@ __device__ void base_final_one(const QvTables &tab, const QvWork &wk, const QvKn
 __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs kn) {
     __shared__ double sh_s[8];
     __shared__ unsigned long long sh_k[8];
-    int b = blockIdx.y, tid = threadIdx.x;
+    // grid = (block of the utterance's job space, utterance).  (Round 4: the transposed grid that cut k_lcs_full's tail --
+    // utterance on x, so that every round of blocks mixes all utterances -- made THIS kernel slower, 738 -> 848 us per
+    // launch: its blocks are balanced inside an utterance already, and neighbours then no longer share an utterance's
+    // tables in L2.)
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
     // pass 1's window scans are done, search()'s have not started: empty the fragment work list
-    if (blockIdx.x == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
+    if (blk == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
         };
         if (W <= 2) {
             // short transcripts: one span per lane (the chain is at most two words per code)
-            for (int g = blockIdx.x * 256 + tid; g < total; g += gridDim.x * 256) {
+            for (int g = blk * 256 + tid; g < total; g += nblk * 256) {
                 uint32_t start; int n; double bonus; unsigned long long key;
                 if (!job(g, start, n, bonus, key)) continue;
                 score(lcs_dispatch(W, pm, QV_PMS, tab.clean + start, n, m), n, bonus, key);
@@ -1099,8 +1107,8 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
             // the bound -- most do not -- so that the groups of a wave enter the recurrence together.
             auto run = [&](auto g_c) {
                 constexpr int G = decltype(g_c)::value;
-                const int w = tid & (G - 1), ngroups = gridDim.x * (256 / G);
-                for (int g = blockIdx.x * (256 / G) + tid / G; g < total; g += ngroups) {
+                const int w = tid & (G - 1), ngroups = nblk * (256 / G);
+                for (int g = blk * (256 / G) + tid / G; g < total; g += ngroups) {
                     uint32_t start = 0; int n = 0; double bonus = 0.0; unsigned long long key = 0;
                     bool ok = false;
                     for (; g < total; g += ngroups)
@@ -1117,8 +1125,8 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     }
     block_best(best, bkey, sh_s, sh_k);
     if (tid == 0) {
-        wk.span_part_score[(size_t)b * QV_SPAN_BLOCKS + blockIdx.x] = best;
-        wk.span_part_key[(size_t)b * QV_SPAN_BLOCKS + blockIdx.x] = bkey;
+        wk.span_part_score[(size_t)b * QV_SPAN_BLOCKS + blk] = best;
+        wk.span_part_key[(size_t)b * QV_SPAN_BLOCKS + blk] = bkey;
     }
 }
 
@@ -1634,7 +1642,8 @@ __global__ __launch_bounds__(256) void k_track(QvTables tab, QvTrack tw) {
     __shared__ unsigned long long spm[QV_NSYM * QV_PMS];
     __shared__ double sh_s[8];
     __shared__ unsigned long long sh_k[8];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    // grid = (text, chunk of the verse order): chunk 0 = every text's longest verses, dispatched first (see k_lcs_full)
+    const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int m = tw.meta[b * 4], n_text = tw.meta[b * 4 + 1], bonus = tw.meta[b * 4 + 2];
     const uint8_t *q = tw.q + tw.meta[b * 4 + 3];
     for (int i = tid; i < QV_NSYM * QV_PMS; i += 256) spm[i] = 0ull;
@@ -1644,7 +1653,7 @@ __global__ __launch_bounds__(256) void k_track(QvTables tab, QvTrack tw) {
     const int W = (m + 63) >> 6;
     // lanes walk the verses in order of decreasing length, so the 64 verses of a wave cost about
     // the same; the first-maximum rule lives in the key (verse index), not in the visiting order
-    const int slot = blockIdx.x * 256 + tid;
+    const int slot = chunk * 256 + tid;
     const int v = slot < tab.n_verses ? tab.len_order[slot] : -1;
     double best = 0.0;
     unsigned long long bkey = ~0ull;
@@ -1684,8 +1693,8 @@ __global__ __launch_bounds__(256) void k_track(QvTables tab, QvTrack tw) {
     }
     block_best(best, bkey, sh_s, sh_k);
     if (tid == 0) {
-        tw.part_s[(size_t)b * QV_TRACK_BLOCKS + blockIdx.x] = best;
-        tw.part_k[(size_t)b * QV_TRACK_BLOCKS + blockIdx.x] = bkey;
+        tw.part_s[(size_t)b * QV_TRACK_BLOCKS + chunk] = best;
+        tw.part_k[(size_t)b * QV_TRACK_BLOCKS + chunk] = bkey;
     }
 }
 
@@ -1721,14 +1730,14 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
     size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + TRI_WORDS * 4 +
                     QV_MAXQ * 2 + 8 * 4 + 64;
     hipLaunchKernelGGL(k_trigram, dim3(batch), dim3(256), sm_tri, stream, tab, wk);
-    hipLaunchKernelGGL(k_lcs_full, dim3(32, batch), dim3(256), 0, stream, tab, wk, 0);
+    hipLaunchKernelGGL(k_lcs_full, dim3(batch, 32), dim3(256), 0, stream, tab, wk, 0);
     hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
     hipLaunchKernelGGL(k_pass1_final, dim3(batch), dim3(256), sm_p1, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_base_final, dim3((batch + 63) / 64), dim3(64), 0, stream, tab, wk, kn, batch, force_ctc);
     // gate-failed utterances only (device-side list; blocks past n_fail exit at once)
-    hipLaunchKernelGGL(k_lcs_full, dim3(74, batch), dim3(256), 0, stream, tab, wk, 1);   // 3 jobs per verse: one round of 74 x 256 lanes
+    hipLaunchKernelGGL(k_lcs_full, dim3(batch, 74), dim3(256), 0, stream, tab, wk, 1);   // 3 jobs per verse: one round of 74 x 256 lanes
     hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     hipLaunchKernelGGL(k_topk, dim3(batch, 2), dim3(256), sm_p1, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_candidates, dim3(batch), dim3(256), (size_t)CAND_PCAP * 12 + CAND_HT * 8 + 1200, stream, tab, wk, kn);
@@ -1880,7 +1889,7 @@ int qv_post_tracker_match(qv_engine *eng, const uint8_t *codes_host, const int32
         const int32_t total = offsets_host[b0 + nb] - base;   // <= nb * QV_MAXQ (lengths were checked)
         if (total > 0) QV_HIP(hipMemcpyAsync(tw.q, codes_host + base, (size_t)total, hipMemcpyHostToDevice, stream));
         QV_HIP(hipMemcpyAsync(tw.meta, meta.data(), sizeof(int32_t) * 4 * nb, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_track, dim3(nblk, nb), dim3(256), 0, stream, eng->tab, tw);
+        hipLaunchKernelGGL(k_track, dim3(nb, nblk), dim3(256), 0, stream, eng->tab, tw);
         hipLaunchKernelGGL(k_track_final, dim3((nb + 63) / 64), dim3(64), 0, stream, eng->tab, tw, nb, nblk);
         QV_HIP(hipGetLastError());
         QV_HIP(hipMemcpyAsync(out_host + b0, tw.out, sizeof(qv_track_match) * nb, hipMemcpyDeviceToHost, stream));
@@ -1910,7 +1919,7 @@ int qv_post_match_verse(qv_engine *eng, const uint8_t *codes_host, int n, int n_
     size_t sm_tri = (size_t)N * 8 + 8 * 8 + 8 * 8 + 64 * 4 + 512 * 4 + 272 * 4 + 128 * 8 + 64 * 4 + TRI_WORDS * 4 +
                     QV_MAXQ * 2 + 8 * 4 + 64;
     hipLaunchKernelGGL(k_trigram, dim3(1), dim3(256), sm_tri, stream, tab, wk);
-    hipLaunchKernelGGL(k_lcs_full, dim3(74, 1), dim3(256), 0, stream, tab, wk, 0);
+    hipLaunchKernelGGL(k_lcs_full, dim3(1, 74), dim3(256), 0, stream, tab, wk, 0);
     hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     if (n_bonus > 0) hipLaunchKernelGGL(k_hint_sp, dim3(1), dim3(64), 0, stream, tab, wk, 0);
     size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;

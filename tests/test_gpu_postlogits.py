@@ -242,6 +242,47 @@ def test_random_transcripts_vs_oracle(engine, oracle):
         assert r["cand_score"].tolist() == sc.tolist(), it
 
 
+def test_span_pass_with_the_pattern_spread_over_lanes(engine, oracle):
+    """k_spans spreads the words of a long transcript over 4 / 8 / 16 neighbouring lanes (lcs_systolic: skewed wavefront,
+    carry by DPP row shift).  Corrupted multi-ayah recitations of ~150 ... ~1,000 normalised characters (3 ... 16 words of
+    64 pattern bits: every group size, both ends of each) against the oracle: the winner of match_verse -- usually a span --
+    its score bit for bit, and the whole candidate list in order."""
+    import random
+
+    from oracle.oracle import normalize_arabic
+
+    rnd = random.Random(404)
+    letters = [ch for ch in oracle.alphabet if ch != " "][:28]
+    seen_w = set()
+    for target in (150, 200, 250, 260, 330, 500, 515, 640, 770, 900, 1000, 1024):
+        for rate in (0.15, 0.45):
+            v = rnd.randrange(210, 280) if target >= 640 else rnd.randrange(6000)   # (the long ayat of surah 2 for the long ones)
+            words = []
+            k = 0
+            while sum(len(w) + 1 for w in words) < target + 80 and k < 8:      # up to 8 consecutive ayat
+                last = int(oracle.t["surah_start"][oracle.surah[v]]) - 1
+                if v + k > last:
+                    break
+                words += oracle.verse_text(v + k).split()
+                k += 1
+            out = []
+            for ch in " ".join(words):
+                x = rnd.random()
+                if x < rate / 3:
+                    continue
+                out.append(rnd.choice(letters) if x < 2 * rate / 3 else ch)
+            t = normalize_arabic(" ".join("".join(out).split())[:target]).strip()
+            if len(t) < 130:
+                continue
+            seen_w.add((len(t) + 63) // 64)
+            r = engine.debug_retrieve(t)
+            cs, cp, sc, m = oracle.build_candidates(t)
+            assert (r["base_start"], r["base_span"], r["base_score"]) == (m.start, m.span, m.score), (target, rate, len(t))
+            assert r["cand_start"].tolist() == cs.tolist() and r["cand_span"].tolist() == cp.tolist(), (target, rate)
+            assert r["cand_score"].tolist() == sc.tolist(), (target, rate)
+    assert {3, 4, 5, 8, 9, 16} <= seen_w, seen_w      # both ends of G = 4, 8 and 16
+
+
 def test_text_weight_fixtures(golden_dir):
     """CTC_DIRECT_TEXT_WEIGHT != 0 on the device: the reference's winner (and exp(-norm_loss) score) for weights 0.35 and
     2.0 -- one of the three recipes changes its winner between the two."""
