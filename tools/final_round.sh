@@ -18,6 +18,7 @@ timeout 300 python bench.py --precision ort --steps 30 --no-cpu-baseline --no-ex
 timeout 300 python bench.py --batch 256 --precision ort --steps 12 --no-cpu-baseline --no-extra > "$O/bench_cfg2_b256_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_cfg2_b256_ort.json"
 timeout 300 python bench.py --workload tta30 --steps 6 --warmup 2 --no-cpu-baseline > "$O/bench_tta30.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30.json"
 timeout 300 python bench.py --workload tta30 --precision ort --steps 4 --warmup 2 --no-cpu-baseline --no-extra > "$O/bench_tta30_ort.json" 2>/dev/null; cut -c1-170 "$O/bench_tta30_ort.json"
+timeout 300 python bench.py --capacity-seconds 30 --steps 40 --no-cpu-baseline --no-extra --no-post-logits > "$O/bench_capacity30s.json" 2>/dev/null; cut -c1-170 "$O/bench_capacity30s.json"
 timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; tail -n 3 "$O/sweep.log" | cut -c1-200
 timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench.jsonl"
 timeout 200 python tools/tracker_bench.py --cpu-texts 4 > "$O/tracker_bench.jsonl" 2>/dev/null; tail -n 2 "$O/tracker_bench.jsonl"
@@ -30,7 +31,10 @@ for prec in fp16 mixed ort; do   # B = 256 (configs[2] / the per-rank slice of c
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b256_$prec" -o p -- python "$R/bench.py" --precision $prec --batch 256 --steps 8 --warmup 2 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b64_ort" -o p -- python "$R/bench.py" --precision ort --steps 16 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
+# the rejected fused feed-forward prototype next to the two GEMM kernels it would replace ("commit it with its rocprof table")
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_ffn_fused" -o p -- "$R/tools/ffn_fused_bench" 30 32256 1 > "$O/ffn_fused_bench_under_rocprof.log" 2>&1
 cd "$R"
+timeout 120 tools/ffn_fused_bench 30 8064 1 > "$O/ffn_fused_bench.log" 2>&1; timeout 120 tools/ffn_fused_bench 30 32256 1 >> "$O/ffn_fused_bench.log" 2>&1
 find "$O" -name "*_kernel_trace.csv" -path "*prof*" -delete   # the traces are large; the stats are what is kept
 bash tools/pmc_round.sh ${1:-final} 8064 > /dev/null 2>&1
 ls "$O" | head -40
