@@ -158,6 +158,12 @@ int qv_predict_batch(qv_engine *e, const float *audio_dev, const int64_t *length
 int qv_predict_batch_async(qv_engine *e, const float *audio_dev, const int64_t *lengths_host,
                            int32_t batch, int64_t n_max, void *stream);
 
+/* Same, and returns the execution context the batch runs on in *ctx_out under the same lock hold -- what a caller
+ * that may share the engine with other threads passes to qv_wait_ctx / qv_fetch_results_ctx / qv_packed_results_ctx
+ * (qv_last_context() after a separate call can already name another thread's batch). */
+int qv_predict_batch_async_ctx(qv_engine *e, const float *audio_dev, const int64_t *lengths_host,
+                               int32_t batch, int64_t n_max, void *stream, int32_t *ctx_out);
+
 /* ---- a15: speed perturbation / sample-rate conversion ------------------------------------
  * The float32 polyphase FIR behind scipy.signal.resample_poly(x, up, down), which the reference's
  * TTA wrapper calls with (9, 10) and (11, 10) (experiments/c2c-direct-mixed-tta/run.py:60-71):

@@ -726,6 +726,14 @@ extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, co
     return QV_OK;
 }
 
+extern "C" int qv_predict_batch_async_ctx(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
+                                          int64_t n_max, void *stream, int32_t *ctx_out) {
+    QV_SERIALISE(eng);   // (recursive: the call below takes it again) -- the context id is read under the same lock hold
+    int rc = qv_predict_batch_async(eng, audio_dev, lengths_host, batch, n_max, stream);
+    if (rc == QV_OK && ctx_out) *ctx_out = eng->cur_ctx;
+    return rc;
+}
+
 extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const int64_t *lengths_host, int32_t batch,
                                 int64_t n_max, qv_result *res, int32_t *greedy_host, void *stream) {
     QV_SERIALISE(eng);

@@ -103,6 +103,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_fetch_results.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.qv_predict_batch.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp]
     lib.qv_predict_batch_async.argtypes = [vp, vp, vp, i32, i64, vp]
+    lib.qv_predict_batch_async_ctx.argtypes = [vp, vp, vp, i32, i64, vp, vp]
     lib.qv_packed_results_dev.argtypes = [vp]
     lib.qv_packed_results_dev.restype = vp
     lib.qv_upfirdn.argtypes = [vp, vp, i64, vp, i32, i32, i32, i64, i64, vp, vp]
@@ -300,10 +301,11 @@ class Engine:
     def predict_batch_async(self, audio, lengths):
         B, N = audio.shape
         ln = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
-        rc = self.lib.qv_predict_batch_async(self.h, C.c_void_p(audio.data_ptr()),
-                                             ln.ctypes.data_as(C.c_void_p), B, N, self._stream())
-        self._check(rc, "qv_predict_batch_async")
-        return int(self.lib.qv_last_context(self.h))
+        ctx = C.c_int32(-1)
+        rc = self.lib.qv_predict_batch_async_ctx(self.h, C.c_void_p(audio.data_ptr()), ln.ctypes.data_as(C.c_void_p), B, N,
+                                                 self._stream(), C.byref(ctx))
+        self._check(rc, "qv_predict_batch_async_ctx")
+        return int(ctx.value)     # (the id comes back from the call itself: another thread cannot get in between)
 
     def fetch_results(self, ctx: int, batch: int, t_max: int, want_text: bool = False) -> list[dict]:
         """join context `ctx` (the value predict_batch_async returned) and copy its results out."""
