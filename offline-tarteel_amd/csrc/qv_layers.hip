@@ -474,7 +474,12 @@ __global__ void k_to_float(const half_t *__restrict__ x, float *__restrict__ y, 
 // of V^T a lane loads).  The rel-pos term needs raw[c = 31 - i + j]: the two raw tiles go through
 // a per-wave LDS slab (row = query, odd stride) and come back skewed.
 #define ATT_LDS_LD 67  // floats per query row of the skew slab (odd: conflict-free skewed reads)
-__global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
+// PF = 1 (round 4, variant 3): the K and position fragments of key tile kt + 1 are requested before tile kt is computed
+// (two register sets) and tile kt's V^T at its top, so that a wave's chain no longer has two exposed global latencies
+// per key tile.
+// Same products in the same order: bit-identical to PF = 0 and to the wave-specialised kernel.
+template <int PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 1 : 2, PF ? 1 : 2))) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
                                                    const half_t *__restrict__ pos, int pos_ld, const float *__restrict__ bias_u,
                                                    const float *__restrict__ bias_v, const int32_t *__restrict__ len,
                                                    const int32_t *__restrict__ row_off, half_t *__restrict__ out, int t_max,
@@ -514,7 +519,10 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
         float m_run = -1e30f, l_run = 0.f;
-        for (int kt = 0; kt < n_kt; ++kt) {
+        // fragments of one key tile: K rows, the two position tiles, V^T pieces (in the key order of the P.V operand)
+        struct TileKP { half8 kf[4], p0[4], p1[4]; };
+        struct TileV { half4 a0[2], a1[2], c0[2], c1[2]; };
+        auto fetch_kp = [&](int kt, TileKP &f) {
             const int j0 = kt * 32;
             int kj = j0 + l31;
             kj = kj < T ? kj : T - 1;
@@ -523,18 +531,35 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
             int pr0 = rr0 + l31, pr1 = rr0 + 32 + l31;
             pr0 = pr0 < 0 ? 0 : (pr0 > 2 * t_max - 2 ? 2 * t_max - 2 : pr0);
             pr1 = pr1 < 0 ? 0 : (pr1 > 2 * t_max - 2 ? 2 * t_max - 2 : pr1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int d = ks * 16 + hi * 8;
+                f.kf[ks] = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
+                f.p0[ks] = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
+                f.p1[ks] = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
+            }
+        };
+        auto fetch_v = [&](int kt, TileV &f) {
+            const int j0 = kt * 32;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                int jb = j0 + 16 * ks + 4 * hi;  // < t_pad
+                f.a0[ks] = *(const half4 *)(vb + (size_t)l31 * t_pad + jb);
+                f.a1[ks] = *(const half4 *)(vb + (size_t)l31 * t_pad + jb + 8);
+                f.c0[ks] = *(const half4 *)(vb + (size_t)(32 + l31) * t_pad + jb);
+                f.c1[ks] = *(const half4 *)(vb + (size_t)(32 + l31) * t_pad + jb + 8);
+            }
+        };
+        auto tile = [&](int kt, const TileKP &cur, const TileV &cv) {
+            const int j0 = kt * 32;
             f32x16 st, r0, r1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; r0[r] = 0.f; r1[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                int d = ks * 16 + hi * 8;
-                half8 kf = *(const half8 *)(kb + (size_t)kj * (2 * QV_D) + d);
-                half8 p0 = *(const half8 *)(pb + (size_t)pr0 * pos_ld + d);
-                half8 p1 = *(const half8 *)(pb + (size_t)pr1 * pos_ld + d);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);   // S^T[jj][ii]
-                r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);   // raw^T[c][ii], c < 32
-                r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);   // raw^T[32 + c][ii]
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.kf[ks], qu[ks], st, 0, 0, 0);   // S^T[jj][ii]
+                r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.p0[ks], qv[ks], r0, 0, 0, 0);   // raw^T[c][ii], c < 32
+                r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.p1[ks], qv[ks], r1, 0, 0, 0);   // raw^T[32 + c][ii]
             }
             // skew through LDS: slab[ii][c] <- raw^T[c][ii]; BD^T[jj][ii] = slab[ii][31 - ii + jj]
             __builtin_amdgcn_wave_barrier();
@@ -578,14 +603,36 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
                 half8 pbf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pbf[e] = (half_t)p[8 * ks + e];
-                int jb = j0 + 16 * ks + 4 * hi;  // < t_pad
-                half4 a0 = *(const half4 *)(vb + (size_t)l31 * t_pad + jb), a1 = *(const half4 *)(vb + (size_t)l31 * t_pad + jb + 8);
-                half4 c0 = *(const half4 *)(vb + (size_t)(32 + l31) * t_pad + jb),
-                      c1 = *(const half4 *)(vb + (size_t)(32 + l31) * t_pad + jb + 8);
+                const half4 a0 = cv.a0[ks], a1 = cv.a1[ks], c0 = cv.c0[ks], c1 = cv.c1[ks];
                 half8 va = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 half8 vc = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pbf, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vc, pbf, o1, 0, 0, 0);
+            }
+        };
+        if (PF) {
+            // K/position fragments one tile ahead in two NAMED register sets (a dynamically indexed pair would live in
+            // scratch); V^T of the current tile is requested at the top of the tile and only needed after the softmax
+            TileKP ka, kc;
+            TileV cv;
+            fetch_kp(0, ka);
+            for (int kt = 0; kt < n_kt; kt += 2) {
+                fetch_v(kt, cv);
+                if (kt + 1 < n_kt) fetch_kp(kt + 1, kc);
+                tile(kt, ka, cv);
+                if (kt + 1 < n_kt) {
+                    fetch_v(kt + 1, cv);
+                    if (kt + 2 < n_kt) fetch_kp(kt + 2, ka);
+                    tile(kt + 1, kc, cv);
+                }
+            }
+        } else {
+            for (int kt = 0; kt < n_kt; ++kt) {
+                TileKP cur;
+                TileV cv;
+                fetch_kp(kt, cur);
+                fetch_v(kt, cv);
+                tile(kt, cur, cv);
             }
         }
         // O^T column (query i0 + l31): d = (r&3) + 8*(r>>2) + 4*hi (+32)
@@ -605,6 +652,217 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
     }
 }
 
+__device__ __forceinline__ void att_glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l,
+                                     16, 0, 0);
+}
+
+// Short utterances (T <= 128 encoder frames: every 10 s clip of the headline batch is 126).  The key-tiled kernel below
+// walks the keys tile by tile with an online softmax, which for four key tiles is four times (stage -> barrier ->
+// fragments -> MFMA -> skew through LDS -> softmax -> MFMA) in a row: 16 us of dependent chain for 0.5 us of MFMA.
+// Here a block is one (utterance, head): its four waves (one query tile each) stage ALL of K, V^T and the 256
+// relative-position rows the four query tiles can touch with coalesced direct-to-LDS loads (16 wave-loads per wave, one
+// latency, one barrier; a first version that fetched the fragments straight from global memory -- 56 scattered loads per
+// wave, every wave of the block fetching the same K and V -- ran 25 us, bound by the vector-memory pipeline), then each
+// wave issues the K / position products of the WHOLE key range back to back (<= 16 + 20 MFMAs: the five position tiles
+// of its 160-row window are each computed once, not once per key tile that touches them), skews tile after tile through
+// its LDS slab (which takes the place of K and the position rows after a second barrier), takes ONE softmax over the
+// complete row (no running maximum, no rescaling of the output accumulator) and ends with the <= 16 P.V products.
+// 64 KB of LDS and < 256 registers: two blocks per CU, the headline batch (512 blocks) in one round.  Not the same
+// summation as the key-tiled kernels (single-pass softmax), so not bit-identical to them; WHICH kernel an utterance gets
+// depends on its own length only, never on the batch around it, so an utterance alone and in any batch has the same bits.
+#define ATT_SHORT_T 128
+#ifdef QV_ATT_STAMPS   // tools/att_bench.hip: shader-clock stamps of one block's waves at the phase boundaries
+__device__ long long g_att_stamp[4][8];
+#define ATT_STAMP(i) do { if (blockIdx.x == 3 && blockIdx.y == 17 && lane == 0) g_att_stamp[wave][i] = clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attention_short(
+    const half_t *__restrict__ qk, const half_t *__restrict__ vt, const half_t *__restrict__ pos, int pos_ld,
+    const float *__restrict__ bias_u, const float *__restrict__ bias_v, const int32_t *__restrict__ len,
+    const int32_t *__restrict__ row_off, half_t *__restrict__ out, int t_max, int t_pad) {
+    // [0, 16 K): K as 4 tiles [32 keys][64], 16-B chunks swizzled by (key >> 1) & 7; [16 K, 48 K): 256 position rows [64],
+    // swizzled the same way; [48 K, 64 K): V^T as 4 tiles [64 d][32 keys], chunks swizzled by (d >> 2) & 3.
+    // The four skew slabs (34,304 B) reuse [0, 48 K) once every wave has its K / position products.
+    __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
+    half_t *sK = (half_t *)smem, *sP = (half_t *)(smem + 16 * 1024), *sV = (half_t *)(smem + 48 * 1024);
+    const int b = blockIdx.y, h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int T = len[b];
+    if (T > ATT_SHORT_T) return;                // whole block: a long utterance belongs to k_attention_ws
+    ATT_STAMP(0);
+    const size_t row0 = (size_t)row_off[b];
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int i0 = wave * 32;
+    const bool active = i0 < T;
+    const half_t *qb = qk + row0 * (2 * QV_D) + h * QV_DK;
+    const half_t *kb = qb + QV_D;
+    const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;
+    const half_t *pb = pos + h * QV_DK;
+    const int n_kt = (T + 31) >> 5;             // 1..4 key tiles = query tiles
+    const int Rb = t_max - 128;                 // position row of window row 0
+    // the query rows first: their latency is the longest chain in front of the first product (convert, add the biases)
+    half8 q8[4];
+    {
+        int qi = i0 + l31;
+        qi = qi < T ? qi : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) q8[ks] = *(const half8 *)(qb + (size_t)qi * (2 * QV_D) + ks * 16 + hi * 8);
+    }
+    // ---- stage: wave w loads keys 8 w .. 8 w + 7 of every key tile, d rows 16 w .. of every V^T tile, its share of the
+    // position rows [96 - 32 (n_kt - 1), 96 + 32 (n_kt + 1)) that the active query tiles touch
+    for (int kt = 0; kt < n_kt; ++kt) {
+        {
+            int r = wave * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            int kj = kt * 32 + r;
+            kj = kj < T ? kj : T - 1;
+            att_glds16(kb + (size_t)kj * (2 * QV_D) + c * 8, sK + kt * 2048 + wave * 512);
+        }
+        {
+            int r = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+            att_glds16(vb + (size_t)r * t_pad + kt * 32 + c * 8, sV + kt * 2048 + wave * 512);
+        }
+    }
+    for (int q = 4 * (4 - n_kt) + wave; q < 4 * (4 + n_kt); q += 4) {      // chunks of 8 window rows
+        int wr = q * 8 + (lane >> 3);
+        int c = (lane & 7) ^ ((wr >> 1) & 7);
+        int rr = Rb + wr;
+        rr = rr < 0 ? 0 : (rr > 2 * t_max - 2 ? 2 * t_max - 2 : rr);
+        att_glds16(pb + (size_t)rr * pos_ld + c * 8, sP + q * 512);
+    }
+    half8 qu[4], qv[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        int d = ks * 16 + hi * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float qf = (float)q8[ks][e];
+            qu[ks][e] = (half_t)(qf + bias_u[h * QV_DK + d + e]);
+            qv[ks][e] = (half_t)(qf + bias_v[h * QV_DK + d + e]);
+        }
+    }
+    ATT_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ATT_STAMP(2);
+    // S^T[kt][jj][ii] for every key tile, raw^T[pt][c][ii] for position tiles pt = 0 .. n_kt (window rows 96 - i0 + 32 pt + c)
+    f32x16 st[4], raw[5];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+        if (active && kt < n_kt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = ks * 2 + hi;
+                half8 kf = *(const half8 *)(sK + kt * 2048 + l31 * 64 + ((c ^ ((l31 >> 1) & 7)) << 3));
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st[kt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int pt = 0; pt < 5; ++pt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[pt][r] = 0.f;
+        if (active && pt <= n_kt) {
+            const int wr = 96 - i0 + 32 * pt + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = ks * 2 + hi;
+                half8 pf = *(const half8 *)(sP + wr * 64 + ((c ^ ((wr >> 1) & 7)) << 3));
+                raw[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, qv[ks], raw[pt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                            // K and the position rows are dead: the slabs take their place
+    if (!active) return;
+    ATT_STAMP(3);
+    float *sl = (float *)smem + wave * (32 * ATT_LDS_LD);
+    // skew tile by tile: BD^T of key tile kt is slab[ii][31 - ii + jj] over the 64 columns (raw^T tile kt | tile kt + 1).
+    // Every position tile is written ONCE: tile pt lives in slab columns 32 (pt & 1) .., so key tile kt finds tile kt in
+    // one half and only tile kt + 1 has to replace tile kt - 1 in the other; the read column wraps modulo 64.
+    // st[kt] becomes the masked, scaled score
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sl[l31 * ATT_LDS_LD + (r & 3) + 8 * (r >> 2) + 4 * hi] = raw[0][r];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt < n_kt) {
+            __builtin_amdgcn_wave_barrier();    // the reads of key tile kt - 1 are issued before tile kt + 1 lands on tile kt - 1
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sl[l31 * ATT_LDS_LD + 32 * ((kt + 1) & 1) + (r & 3) + 8 * (r >> 2) + 4 * hi] = raw[kt + 1][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float bd = sl[l31 * ATT_LDS_LD + ((32 * (kt & 1) + 31 - l31 + jj) & 63)];
+                float sc = (st[kt][r] + bd) * 0.125f;
+                sc = (kt * 32 + jj < T) ? sc : -1e30f;
+                st[kt][r] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    ATT_STAMP(4);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt < n_kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float e = (kt * 32 + jj < T) ? __expf(st[kt][r] - mx) : 0.f;
+                st[kt][r] = e;
+                sum += e;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    ATT_STAMP(5);
+    // P.V: B operand = exp(S^T) registers 8ks .. 8ks + 7 of tile kt (keys 32 kt + 16 ks + 4 hi + {0..3, 8..11});
+    // A operand = V^T rows d with the same key order: 16-B chunks 2 ks and 2 ks + 1 of the tile, 8-byte half `hi`
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt < n_kt) {
+            const half_t *sVb = sV + kt * 2048;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 pbf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pbf[e] = (half_t)st[kt][8 * ks + e];
+                const int da = l31, dc = 32 + l31;
+                half4 a0 = *(const half4 *)(sVb + da * 32 + (((2 * ks) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
+                half4 a1 = *(const half4 *)(sVb + da * 32 + (((2 * ks + 1) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
+                half4 c0 = *(const half4 *)(sVb + dc * 32 + (((2 * ks) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+                half4 c1 = *(const half4 *)(sVb + dc * 32 + (((2 * ks + 1) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+                half8 va = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                half8 vc = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pbf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vc, pbf, o1, 0, 0, 0);
+            }
+        }
+    }
+    if (i0 + l31 < T) {
+        float inv = 1.f / sum;
+        half_t *o = out + (row0 + i0 + l31) * QV_D + h * QV_DK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int d = 8 * q + 4 * hi;
+            half4 h0, h1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h0[e] = (half_t)(o0[4 * q + e] * inv); h1[e] = (half_t)(o1[4 * q + e] * inv); }
+            *(half4 *)(o + d) = h0;
+            *(half4 *)(o + 32 + d) = h1;
+        }
+    }
+    ATT_STAMP(6);
+}
+
 // Wave-specialised version of the same computation (same arithmetic, same order).  k_attention's
 // duration is one wave's serial chain -- per key tile two exposed global-load latencies (K and
 // position fragments, then V) in front of 16 MFMAs -- and it keeps a wave busy with one query tile
@@ -619,17 +877,13 @@ __global__ __launch_bounds__(256) void k_attention(const half_t *__restrict__ qk
 // round of 256 blocks instead of two rounds of 512.  LDS then only holds NST = 2 K/V stages (tile kt + 1 is requested
 // when tile kt's barrier frees the other buffer) and a 192-row position ring (160-row window + the 32 rows of the next
 // tile).  The arithmetic of a (head, query tile) is the same wave program in both shapes: outputs are bit-identical.
-__device__ __forceinline__ void att_glds16(const void *g, void *l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l,
-                                     16, 0, 0);
-}
 
 template <int HPB, int NST, int RING>
 __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
                                                                   const half_t *__restrict__ pos, int pos_ld,
                                                                   const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                   const int32_t *__restrict__ len, const int32_t *__restrict__ row_off,
-                                                                  half_t *__restrict__ out, int t_max, int t_pad) {
+                                                                  half_t *__restrict__ out, int t_max, int t_pad, int t_short) {
     static_assert(RING % 8 == 0 && RING >= 160 + 32 * (NST - 1), "position ring: window + prefetched rows");
     __shared__ __attribute__((aligned(16))) half_t sK[HPB][NST][32 * 64];    // [key][d], 16-B chunks swizzled by (key >> 1) & 7
     __shared__ __attribute__((aligned(16))) half_t sV[HPB][NST][64 * 32];    // [d][key], 16-B chunks swizzled by (d >> 2) & 3
@@ -637,7 +891,7 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
     __shared__ float slab[4 * HPB][32 * ATT_LDS_LD];
     const int b = blockIdx.z, qg = blockIdx.y;
     const int T = len[b];
-    if (qg * 128 >= T) return;                       // whole block: no query of this group exists
+    if (qg * 128 >= T || T <= t_short) return;       // whole block: no query of this group exists / k_attention_short's utterance
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool loader = wave >= 4 * HPB;
     const int w4 = wave & 3, l31 = lane & 31, hi = lane >> 5;
@@ -976,27 +1230,45 @@ static std::atomic<int> g_att_variant{-1};
 void qv_attention_set_variant(int mode) { g_att_variant.store(mode); }
 static int attention_variant() {
     static const int env = [] {
-        const char *o = getenv("QVERSE_ATT_OLD"), *h = getenv("QVERSE_ATT_HPB");
-        return (o && o[0] == '1') ? 2 : (h && h[0] == '1') ? 1 : 0;
+        // QVERSE_ATT_OLD=1 / 3: one wave per query tile (3: prefetched fragments); QVERSE_ATT_HPB=1: one head per block;
+        // QVERSE_ATT_TILED=1: the two-heads-per-block kernel for every utterance (no k_attention_short)
+        const char *o = getenv("QVERSE_ATT_OLD"), *h = getenv("QVERSE_ATT_HPB"), *t = getenv("QVERSE_ATT_TILED");
+        return (o && o[0] == '3') ? 3 : (o && o[0] == '1') ? 2 : (h && h[0] == '1') ? 1 : (t && t[0] == '1') ? 0 : 4;
     }();
     const int v = g_att_variant.load();
     return v < 0 ? env : v;
 }
 
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
-                      const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_pad, int batch, hipStream_t s) {
+                      const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_min, int t_pad, int batch,
+                      hipStream_t s) {
     const int variant = attention_variant();
-    if (variant == 2) {
-        hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out,
-                           t_max, t_pad);
+    if (variant == 2 || variant == 3) {
+        if (variant == 2)
+            hipLaunchKernelGGL(k_attention<0>, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out,
+                               t_max, t_pad);
+        else
+            hipLaunchKernelGGL(k_attention<1>, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out,
+                               t_max, t_pad);
         return;
     }
-    if (variant == 0)
-        hipLaunchKernelGGL((k_attention_ws<2, 2, 192>), dim3(QV_H / 2, (t_max + 127) / 128, batch), dim3(768), 0, s, qk, vt, pos,
-                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad);
-    else
+    // default (4): an utterance of at most ATT_SHORT_T frames goes to k_attention_short, a longer one to the
+    // wave-specialised kernel -- by its OWN length, so that its bits do not depend on the batch it travels in; a launch
+    // none of whose utterances qualify is skipped (t_min / t_max are the batch's shortest / longest utterance)
+    int t_short = 0;
+    if (variant == 4) {
+        t_short = ATT_SHORT_T;
+        if (t_min <= ATT_SHORT_T)
+            hipLaunchKernelGGL(k_attention_short, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off,
+                               out, t_max, t_pad);
+        if (t_max <= ATT_SHORT_T) return;
+    }
+    if (variant == 1)
         hipLaunchKernelGGL((k_attention_ws<1, 3, 256>), dim3(QV_H, (t_max + 127) / 128, batch), dim3(512), 0, s, qk, vt, pos,
-                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad);
+                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad, t_short);
+    else
+        hipLaunchKernelGGL((k_attention_ws<2, 2, 192>), dim3(QV_H / 2, (t_max + 127) / 128, batch), dim3(768), 0, s, qk, vt, pos,
+                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad, t_short);
 }
 
 void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const int32_t *len, const int32_t *row_off, half_t *y,

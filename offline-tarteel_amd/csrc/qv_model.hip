@@ -802,7 +802,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
                      float *logprobs, int t_max_out, int32_t *t_out_host, hipStream_t s, bool zero_pad_rows) {
     if (batch < 1 || batch > m->max_batch) { qv_set_error(eng, "batch exceeds engine capacity"); return QV_ERR_CAPACITY; }
     int B = batch, MB = m->max_batch;
-    int tm_max = 0, t1m = 0, t2m = 0, t3m = 0, rows = 0;
+    int tm_max = 0, t1m = 0, t2m = 0, t3m = 0, t3min = INT32_MAX, rows = 0;
     const int slot = m->lens_slot;
     if (m->lens_pending[slot]) { QV_HIP(hipEventSynchronize(m->lens_copied[slot])); m->lens_pending[slot] = false; }
     int32_t *lh = m->lens_host + (size_t)slot * (MB * 6 + 1);
@@ -815,6 +815,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         int tm = (int)(n / 160 + 1), l1 = stage_len(tm), l2 = stage_len(l1), l3 = stage_len(l2);
         lh[0 * MB + b] = (int32_t)n; lh[1 * MB + b] = tm; lh[2 * MB + b] = l1; lh[3 * MB + b] = l2; lh[4 * MB + b] = l3;
         tm_max = std::max(tm_max, tm); t1m = std::max(t1m, l1); t2m = std::max(t2m, l2); t3m = std::max(t3m, l3);
+        t3min = std::min(t3min, l3);
         t_out_host[b] = l3;
         lh[5 * MB + b] = rows;   // first packed row of utterance b
         rows += l3;
@@ -928,8 +929,8 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         if (dup & 1) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         gemm(EPI_QKV, m->ln, QV_D, L.qkv_w, L.qkv_b, m->qk, 3 * QV_D, 2 * QV_D, 1.f);
-        if (!(skip & 4)) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
-        if (dup & 4) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t_pad, B, s);
+        if (!(skip & 4)) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t3min, t_pad, B, s);
+        if (dup & 4) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t3min, t_pad, B, s);
         gemm(EPI_RESID, m->att, QV_D, L.out_w, L.out_b, m->x, QV_D, QV_D, 1.f);
         // conv module
         if (m->ort) {

@@ -328,34 +328,64 @@ def test_fused_subsampling_equals_two_kernel_path(setup, monkeypatch):
         eng.close()
 
 
-def test_specialised_attention_equals_one_wave_per_tile_kernel(setup, monkeypatch):
-    """k_attention_ws (loader / consumer waves, K, V^T and the relative-position ring staged in LDS)
-    against the plain one-wave-per-query-tile kernel (qv_debug_attention_variant(2)): bit-identical log-probs."""
-    eng = setup["eng"]
-    eng.attention_variant(2)
+def _forward_with_variant(eng, audio, lens, variant):
+    eng.attention_variant(variant)
     try:
-        lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
+        lp, t = eng.forward(audio, lens)
         torch.cuda.synchronize()
+        return lp.clone(), t
     finally:
         eng.attention_variant(-1)
-    assert t == setup["t"]
-    for i, n in enumerate(t):
-        assert torch.equal(lp[i, :n], setup["lp"][i, :n])
 
 
-def test_two_heads_per_block_attention_equals_one_head_per_block(setup, monkeypatch):
-    """k_attention_ws<2 heads, 2 stages, 192-row ring> (the default) against <1 head, 3 stages, 256-row ring>
-    (qv_debug_attention_variant(1)): the same wave program per (head, query tile), bit-identical log-probs on a ragged batch."""
+def test_key_tiled_attention_kernels_agree_bit_for_bit(setup):
+    """k_attention_ws<2 heads, 2 stages, 192-row ring> (variant 0), <1 head, 3 stages, 256-row ring> (1), the plain
+    one-wave-per-query-tile kernel (2) and its prefetching form (3) run the same wave program per (head, query tile):
+    bit-identical log-probs on a ragged batch."""
     eng = setup["eng"]
-    eng.attention_variant(1)
+    dev = setup["audio"].cuda().contiguous()
+    lp0, t0 = _forward_with_variant(eng, dev, LENS, 0)
+    assert t0 == setup["t"]
+    for var in (1, 2, 3):
+        lp, t = _forward_with_variant(eng, dev, LENS, var)
+        assert t == t0
+        for i, n in enumerate(t):
+            assert torch.equal(lp[i, :n], lp0[i, :n]), var
+
+
+def test_short_utterance_attention_against_the_key_tiled_kernel(setup):
+    """The default serves utterances of <= 128 frames with k_attention_short (all keys at once, single-pass softmax).  It
+    is the same attention up to the softmax's summation order: the log-probs stay within 4e-3 of the key-tiled kernel's
+    (both are within 1e-2 of the fp32 restatement, test_logprobs_match_reference), and a batch that mixes short and long
+    utterances gives every utterance the bits it has alone."""
+    eng = setup["eng"]
+    dev = setup["audio"].cuda().contiguous()
+    lp0, t0 = _forward_with_variant(eng, dev, LENS, 0)
+    d = _maxdiff(setup["lp"], lp0.cpu(), t0)
+    print(f"short-utterance kernel vs key-tiled kernel: {d:.2e}")
+    assert 0.0 < d <= 4e-3      # measured 2.3e-3; 0.0 would mean the short kernel did not run
+    from offline_tarteel_amd.engine import Engine
+
+    lens = [_samples_for_frames(t) for t in (126, 200, 64, 128, 129)]
+    a = torch.from_numpy(synth_audio(len(lens), max(lens), seed=31))
+    for b, n in enumerate(lens):
+        a[b, n:] = 0
+    dev = a.cuda().contiguous()
+    eng2 = Engine(device=0, with_model=True, seed=SEED, max_batch=len(lens), max_samples=max(lens))
     try:
-        lp, t = eng.forward(setup["audio"].cuda().contiguous(), LENS)
+        lp, t = eng2.forward(dev, lens)
         torch.cuda.synchronize()
+        lp = lp.clone()
+        assert t == [126, 200, 64, 128, 129]
+        lpt, _ = _forward_with_variant(eng2, dev, lens, 0)
+        for b, n in enumerate(lens):
+            one, t1 = eng2.forward(dev[b: b + 1, :n].contiguous(), [n])
+            assert t1[0] == t[b] and torch.equal(one[0, : t[b]], lp[b, : t[b]]), t[b]
+            same = torch.equal(lp[b, : t[b]], lpt[b, : t[b]])
+            assert same == (t[b] > 128), t[b]     # long utterances: the key-tiled kernel either way
+            assert float((lp[b, : t[b]] - lpt[b, : t[b]]).abs().max()) <= 4e-3
     finally:
-        eng.attention_variant(-1)
-    assert t == setup["t"]
-    for i, n in enumerate(t):
-        assert torch.equal(lp[i, :n], setup["lp"][i, :n])
+        eng2.close()
 
 
 def test_tiny_and_long_utterances_share_a_packed_batch(setup):
@@ -441,8 +471,8 @@ def _samples_for_frames(T):
 def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
     """Encoder frame counts on and around the tile edges of the attention kernel (32-key tiles, 128-query groups, two
     heads per block) and of the GEMM row tiles, ragged in one batch: every utterance equals itself run alone, bit for
-    bit, in all three precisions; in fp16 the one-head-per-block and one-wave-per-tile attention kernels give the same
-    bits for the whole batch."""
+    bit, in all three precisions; in fp16 the key-tiled attention kernels give the same bits for the whole batch, and the
+    default differs from them only for the utterances the short-utterance kernel serves."""
     from offline_tarteel_amd.engine import Engine
 
     frames = [1, 31, 32, 33, 64, 65, 127, 128, 129, 160, 255, 256, 257]
@@ -462,14 +492,22 @@ def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
             one, t1 = eng.forward(dev[b: b + 1, :n].contiguous(), [n])
             assert t1[0] == t[b] and torch.equal(one[0, : t[b]], lp[b, : t[b]]), frames[b]
         if precision == 0:
-            for var in (1, 2):   # one head per block, one wave per query tile
+            lp0 = None
+            for var in (0, 1, 2, 3):   # key-tiled kernels: two heads per block, one head, one wave per query tile, + prefetch
                 eng.attention_variant(var)
                 try:
                     lp2, _ = eng.forward(dev, lens)
+                    torch.cuda.synchronize()
+                    lp2 = lp2.clone()
                 finally:
                     eng.attention_variant(-1)
+                if lp0 is None:
+                    lp0 = lp2
                 for b in range(len(lens)):
-                    assert torch.equal(lp2[b, : t[b]], lp[b, : t[b]]), (var, frames[b])
+                    assert torch.equal(lp2[b, : t[b]], lp0[b, : t[b]]), (var, frames[b])
+            for b in range(len(lens)):   # the default differs from them exactly where k_attention_short serves the utterance
+                assert torch.equal(lp[b, : t[b]], lp0[b, : t[b]]) == (frames[b] > 128), frames[b]
+                assert float((lp[b, : t[b]] - lp0[b, : t[b]]).abs().max()) <= 4e-3, frames[b]
     finally:
         eng.close()
 
