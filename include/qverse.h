@@ -296,13 +296,13 @@ int qv_profile_replay_kernel(qv_engine *e, int32_t which, char *name_out, int32_
  * the shape allows, -1 = back to the environment (QVERSE_GEMM_T256) / default.  The tile shape never changes
  * a result: both kernels form the same products in the same accumulation order. */
 int qv_debug_gemm_tiles(int32_t mode);
-/* Process-wide attention kernel variant, for the tests: 4 = the default: an utterance of at most 128 encoder frames
+/* Process-wide attention kernel variant, for the tests: 3 = the default: an utterance of at most 128 encoder frames
  * (10.2 s) is served by the single-pass short-utterance kernel, a longer one by the key-tiled kernel -- by its OWN length,
  * so the bits of an utterance never depend on the batch it travels in; 0 = the key-tiled kernel (two heads per block)
- * for every utterance, 1 = one head per block, 2 = one wave per query tile, 3 = 2 with prefetched fragments;
- * -1 = back to the environment (QVERSE_ATT_TILED=1 / QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1|3, read once per process) /
- * default.  Variants 0..3 give identical bits; 4 differs from them for short utterances by the softmax's summation
- * order only (one pass over the row instead of a running maximum). */
+ * for every utterance, 1 = one head per block, 2 = one wave per query tile; -1 = back to the environment
+ * (QVERSE_ATT_TILED=1 / QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1, read once per process) / default.  Variants 0..2 give
+ * identical bits; 3 differs from them for short utterances by the softmax's summation order only (one pass over the row
+ * instead of a running maximum). */
 int qv_debug_attention_variant(int32_t mode);
 
 /* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty

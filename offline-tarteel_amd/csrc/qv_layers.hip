@@ -474,12 +474,7 @@ __global__ void k_to_float(const half_t *__restrict__ x, float *__restrict__ y, 
 // of V^T a lane loads).  The rel-pos term needs raw[c = 31 - i + j]: the two raw tiles go through
 // a per-wave LDS slab (row = query, odd stride) and come back skewed.
 #define ATT_LDS_LD 67  // floats per query row of the skew slab (odd: conflict-free skewed reads)
-// PF = 1 (round 4, variant 3): the K and position fragments of key tile kt + 1 are requested before tile kt is computed
-// (two register sets) and tile kt's V^T at its top, so that a wave's chain no longer has two exposed global latencies
-// per key tile.
-// Same products in the same order: bit-identical to PF = 0 and to the wave-specialised kernel.
-template <int PF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 1 : 2, PF ? 1 : 2))) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attention(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
                                                    const half_t *__restrict__ pos, int pos_ld, const float *__restrict__ bias_u,
                                                    const float *__restrict__ bias_v, const int32_t *__restrict__ len,
                                                    const int32_t *__restrict__ row_off, half_t *__restrict__ out, int t_max,
@@ -610,30 +605,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 1 : 2,
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vc, pbf, o1, 0, 0, 0);
             }
         };
-        if (PF) {
-            // K/position fragments one tile ahead in two NAMED register sets (a dynamically indexed pair would live in
-            // scratch); V^T of the current tile is requested at the top of the tile and only needed after the softmax
-            TileKP ka, kc;
+        for (int kt = 0; kt < n_kt; ++kt) {
+            TileKP cur;
             TileV cv;
-            fetch_kp(0, ka);
-            for (int kt = 0; kt < n_kt; kt += 2) {
-                fetch_v(kt, cv);
-                if (kt + 1 < n_kt) fetch_kp(kt + 1, kc);
-                tile(kt, ka, cv);
-                if (kt + 1 < n_kt) {
-                    fetch_v(kt + 1, cv);
-                    if (kt + 2 < n_kt) fetch_kp(kt + 2, ka);
-                    tile(kt + 1, kc, cv);
-                }
-            }
-        } else {
-            for (int kt = 0; kt < n_kt; ++kt) {
-                TileKP cur;
-                TileV cv;
-                fetch_kp(kt, cur);
-                fetch_v(kt, cv);
-                tile(kt, cur, cv);
-            }
+            fetch_kp(kt, cur);
+            fetch_v(kt, cv);
+            tile(kt, cur, cv);
         }
         // O^T column (query i0 + l31): d = (r&3) + 8*(r>>2) + 4*hi (+32)
         if (i0 + l31 < T) {
@@ -982,6 +959,9 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
+    f32x16 rprev;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rprev[r] = 0.f;
     for (int kt = 0; kt < n_kt; ++kt) {
         __builtin_amdgcn_s_barrier();
         if (!active) continue;
@@ -990,33 +970,47 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
         // window-relative position rows of this wave: 32 kt + 96 - 32 w4 + c, c in [0, 64)
         const int wr0 = 32 * kt + 96 - 32 * w4 + l31;
         const int ring0 = wr0 % RING, ring1 = (wr0 + 32) % RING;
+        // position tile pt = rows 32 pt .. of the wave's window: key tile kt needs tiles kt and kt + 1, and tile kt is what
+        // key tile kt - 1 computed as ITS second tile -- same operands, same products, so it is carried over instead of
+        // being computed (and pushed through the slab) twice
         f32x16 st, r0, r1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = 0.f; r0[r] = 0.f; r1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; r1[r] = 0.f; }
+        if (kt == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r0[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = ks * 2 + hi;
+                half8 p0 = *(const half8 *)(sPh + ring0 * 64 + ((c ^ ((ring0 >> 1) & 7)) << 3));
+                r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);
+            }
+        } else r0 = rprev;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + hi;
             half8 kf = *(const half8 *)(sKb + l31 * 64 + ((c ^ ((l31 >> 1) & 7)) << 3));
-            half8 p0 = *(const half8 *)(sPh + ring0 * 64 + ((c ^ ((ring0 >> 1) & 7)) << 3));
             half8 p1 = *(const half8 *)(sPh + ring1 * 64 + ((c ^ ((ring1 >> 1) & 7)) << 3));
             st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);
-            r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);
             r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);
         }
+        rprev = r1;
+        // skew: tile pt lives in slab columns 32 (pt & 1) .., so tile kt is already there (written as tile (kt - 1) + 1) and
+        // only tile kt + 1 replaces tile kt - 1; BD^T[jj][ii] = slab[ii][(32 (kt & 1) + 31 - ii + jj) mod 64]
         __builtin_amdgcn_wave_barrier();
+        if (kt == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            sl[l31 * ATT_LDS_LD + c] = r0[r];
-            sl[l31 * ATT_LDS_LD + 32 + c] = r1[r];
+            for (int r = 0; r < 16; ++r) sl[l31 * ATT_LDS_LD + (r & 3) + 8 * (r >> 2) + 4 * hi] = r0[r];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sl[l31 * ATT_LDS_LD + 32 * ((kt + 1) & 1) + (r & 3) + 8 * (r >> 2) + 4 * hi] = r1[r];
         __builtin_amdgcn_wave_barrier();
         float p[16];
         float mx = -1e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float bd = sl[l31 * ATT_LDS_LD + 31 - l31 + jj];
+            float bd = sl[l31 * ATT_LDS_LD + ((32 * (kt & 1) + 31 - l31 + jj) & 63)];
             float sc = (st[r] + bd) * 0.125f;
             p[r] = (j0 + jj < T) ? sc : -1e30f;
             mx = fmaxf(mx, p[r]);
@@ -1230,10 +1224,10 @@ static std::atomic<int> g_att_variant{-1};
 void qv_attention_set_variant(int mode) { g_att_variant.store(mode); }
 static int attention_variant() {
     static const int env = [] {
-        // QVERSE_ATT_OLD=1 / 3: one wave per query tile (3: prefetched fragments); QVERSE_ATT_HPB=1: one head per block;
-        // QVERSE_ATT_TILED=1: the two-heads-per-block kernel for every utterance (no k_attention_short)
+        // QVERSE_ATT_OLD=1: one wave per query tile; QVERSE_ATT_HPB=1: one head per block; QVERSE_ATT_TILED=1: the
+        // two-heads-per-block kernel for every utterance (no k_attention_short)
         const char *o = getenv("QVERSE_ATT_OLD"), *h = getenv("QVERSE_ATT_HPB"), *t = getenv("QVERSE_ATT_TILED");
-        return (o && o[0] == '3') ? 3 : (o && o[0] == '1') ? 2 : (h && h[0] == '1') ? 1 : (t && t[0] == '1') ? 0 : 4;
+        return (o && o[0] == '1') ? 2 : (h && h[0] == '1') ? 1 : (t && t[0] == '1') ? 0 : 3;
     }();
     const int v = g_att_variant.load();
     return v < 0 ? env : v;
@@ -1243,20 +1237,16 @@ void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_min, int t_pad, int batch,
                       hipStream_t s) {
     const int variant = attention_variant();
-    if (variant == 2 || variant == 3) {
-        if (variant == 2)
-            hipLaunchKernelGGL(k_attention<0>, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out,
-                               t_max, t_pad);
-        else
-            hipLaunchKernelGGL(k_attention<1>, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out,
-                               t_max, t_pad);
+    if (variant == 2) {
+        hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out, t_max,
+                           t_pad);
         return;
     }
-    // default (4): an utterance of at most ATT_SHORT_T frames goes to k_attention_short, a longer one to the
+    // default (3): an utterance of at most ATT_SHORT_T frames goes to k_attention_short, a longer one to the
     // wave-specialised kernel -- by its OWN length, so that its bits do not depend on the batch it travels in; a launch
     // none of whose utterances qualify is skipped (t_min / t_max are the batch's shortest / longest utterance)
     int t_short = 0;
-    if (variant == 4) {
+    if (variant == 3) {
         t_short = ATT_SHORT_T;
         if (t_min <= ATT_SHORT_T)
             hipLaunchKernelGGL(k_attention_short, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off,

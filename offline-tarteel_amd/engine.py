@@ -377,10 +377,9 @@ class Engine:
         return buf.value.decode()
 
     def attention_variant(self, mode: int):
-        """process-wide attention kernel variant (qv_debug_attention_variant): 4 = default (utterances of <= 128 frames on
+        """process-wide attention kernel variant (qv_debug_attention_variant): 3 = default (utterances of <= 128 frames on
         the single-pass kernel, longer ones key-tiled), 0 = key-tiled with two heads per block for every utterance,
-        1 = one head per block, 2 = one wave per query tile, 3 = 2 with prefetched fragments (0..3: identical bits),
-        -1 = environment / default."""
+        1 = one head per block, 2 = one wave per query tile (0..2: identical bits), -1 = environment / default."""
         self._check(self.lib.qv_debug_attention_variant(int(mode)), "qv_debug_attention_variant")
 
     def profile_gemm(self, enable: bool):

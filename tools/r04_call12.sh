@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the prefetching variant QVERSE_ATT_OLD=3 this script measured was removed after it; see DESIGN.md, kernel table)
 # attention variants again: the one-wave-per-tile kernel bounded to 2 waves/SIMD (variant 2) and with prefetched fragments (3)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
