@@ -505,9 +505,13 @@ def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
                     lp0 = lp2
                 for b in range(len(lens)):
                     assert torch.equal(lp2[b, : t[b]], lp0[b, : t[b]]), (var, frames[b])
-            for b in range(len(lens)):   # the default differs from them exactly where k_attention_short serves the utterance
-                assert torch.equal(lp[b, : t[b]], lp0[b, : t[b]]) == (frames[b] > 128), frames[b]
+            differ = 0
+            for b in range(len(lens)):   # the default may differ from them only where k_attention_short serves the utterance
+                same = torch.equal(lp[b, : t[b]], lp0[b, : t[b]])
+                assert same or frames[b] <= 128, frames[b]
+                differ += not same
                 assert float((lp[b, : t[b]] - lp0[b, : t[b]]).abs().max()) <= 4e-3, frames[b]
+            assert differ >= 4      # ... and it does run there (a one-frame softmax is the same in any kernel)
     finally:
         eng.close()
 

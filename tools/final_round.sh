@@ -30,6 +30,8 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/profpost
 for prec in fp16 mixed ort; do   # B = 256 (configs[2] / the per-rank slice of configs[3]), one batch at a time: which kernels the step is made of
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b256_$prec" -o p -- python "$R/bench.py" --precision $prec --batch 256 --steps 8 --warmup 2 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_tta30" -o p -- python "$R/bench.py" --workload tta30 --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+timeout 120 "$R/tools/att_bench" 64 126 200 > "$O/att_bench.log" 2>&1; timeout 120 "$R/tools/att_bench" 256 126 100 >> "$O/att_bench.log" 2>&1; timeout 120 "$R/tools/att_bench" 64 376 50 >> "$O/att_bench.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b64_ort" -o p -- python "$R/bench.py" --precision ort --steps 16 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 # the rejected fused feed-forward prototype next to the two GEMM kernels it would replace ("commit it with its rocprof table")
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_ffn_fused" -o p -- "$R/tools/ffn_fused_bench" 30 32256 1 > "$O/ffn_fused_bench_under_rocprof.log" 2>&1
