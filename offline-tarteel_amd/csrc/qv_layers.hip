@@ -129,8 +129,60 @@ __global__ __launch_bounds__(320) void k_melapply(const float *__restrict__ feat
 
 // ------------------------------------------------------------------ subsampling --------
 // conv0: Conv2d(1->256, 3x3, s2, p1) + ReLU on [B][Tm][80] -> channels-last f16 [B][T1][40][256].
-// Block = one output row t1; a thread owns 8 channels (weights [9][256] tap-major, held in
-// registers) and walks the 40 frequency positions with stride 8; the 3 input rows sit in LDS.
+// Round 4: on the f32 matrix pipe.  As 9 FMAs per output on the VALU this layer was 6 GFLOP per batch at 17 % of the
+// packed-FMA peak, issue-bound (k_sub01: 36 packed FMAs + ~30 address / LDS instructions per position and thread).
+// It is a [channels] x [9 taps] x [positions] product: v_mfma_f32_32x32x2_f32 takes two taps per instruction, so a
+// 32-channel x 32-position tile is five of them (the tenth tap is zero) with the bias as the initial accumulator --
+// float32 operands and accumulation like before, only the summation order inside the instruction is the hardware's.
+// A operand: lane (l31 = channel, hi = tap parity) holds w[2j + hi][channel]; B operand: lane (l31 = position, hi)
+// holds the input sample of tap 2j + hi at that position; D register r of lane (l31 = position, hi) is channel
+// (r & 3) + 8 (r >> 2) + 4 hi.  conv0_taps / conv0_tile are shared by the fused kernel and the two-kernel cross-check
+// path, which therefore still agree bit for bit.
+__device__ __forceinline__ void conv0_weights(const float *__restrict__ wt /*[9][256]*/, const float *__restrict__ bias, int ch0,
+                                              int l31, int hi, float wa[5], float bc[16]) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) wa[j] = 2 * j + hi < 9 ? wt[(2 * j + hi) * QV_SUBC + ch0 + l31] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bc[r] = bias[ch0 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+}
+// the five B operands of one position: input rows r0 .. r0 + 2 (LDS row pitch QV_NMEL + 2, column f + 1), columns 2 f1 + kx.
+// koff[j] is the lane's offset of tap 2j + hi inside that 3 x 3 window (conv0_tap_offsets; the tenth tap reads the ninth's
+// sample against a zero weight), so the fetch is five plain LDS reads
+__device__ __forceinline__ void conv0_tap_offsets(int hi, int koff[5]) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int k = 2 * j + hi < 9 ? 2 * j + hi : 8;
+        koff[j] = (k / 3) * (QV_NMEL + 2) + k % 3;
+    }
+}
+__device__ __forceinline__ void conv0_taps(const float *rows, int r0, int f1, const int koff[5], float xb[5]) {
+    const float *base = rows + r0 * (QV_NMEL + 2) + 2 * f1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) xb[j] = base[koff[j]];
+}
+__device__ __forceinline__ f32x16 conv0_tile(const float wa[5], const float bc[16], const float xb[5]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bc[r];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], acc, 0, 0, 0);
+    return acc;
+}
+
+// ReLU + conversion of a D tile's 16 registers: convert first (round to nearest even, v_cvt_pk_f16_f32), then clamp the
+// f16 BITS as signed integers (a negative float is a negative int16; one v_pk_max_i16 per two channels).
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4 conv0_relu4(const f32x16 &acc, int q) {
+    const float4_t v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    const half4 h = __builtin_convertvector(v, half4);
+    short4_t b = __builtin_bit_cast(short4_t, h);
+    b = __builtin_elementwise_max(b, (short4_t){0, 0, 0, 0});
+    return __builtin_bit_cast(half4, b);
+}
+
+// two-kernel path (QVERSE_SUB_UNFUSED=1, the cross-check of k_sub01): block = one output row t1; the 3 input rows sit in
+// LDS; wave w owns channel tiles 2w and 2w + 1, both position tiles (40 positions = 32 + 8).
 __global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_in,
                                                const double *__restrict__ stats, const float *__restrict__ wt /*[9][256]*/,
                                                const float *__restrict__ bias, half_t *__restrict__ out, int t1_max) {
@@ -147,36 +199,27 @@ __global__ __launch_bounds__(256) void k_conv0(const float *__restrict__ feats, 
         int dt = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = 2 * t1 - 1 + dt;
         rows[dt][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? (x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f] : 0.f;
     }
-    const int c0 = (tid & 31) * 8, fl = tid >> 5;
-    float w[9][8], bs[8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        f32x4 w0 = *(const f32x4 *)(wt + k * QV_SUBC + c0), w1 = *(const f32x4 *)(wt + k * QV_SUBC + c0 + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { w[k][c] = w0[c]; w[k][4 + c] = w1[c]; }
-    }
-    {
-        f32x4 b0 = *(const f32x4 *)(bias + c0), b1 = *(const f32x4 *)(bias + c0 + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bs[c] = b0[c]; bs[4 + c] = b1[c]; }
-    }
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    int koff[5];
+    conv0_tap_offsets(hi, koff);
     __syncthreads();
-    for (int f1 = fl; f1 < 40; f1 += 8) {
-        float acc[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = bs[c];
+    for (int ct = 0; ct < 2; ++ct) {
+        const int ch0 = (2 * wave + ct) * 32;
+        float wa[5], bc[16];
+        conv0_weights(wt, bias, ch0, l31, hi, wa, bc);
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+        for (int pt = 0; pt < 2; ++pt) {
+            const int f1 = pt * 32 + l31, f1c = f1 < 40 ? f1 : 39;
+            float xb[5];
+            conv0_taps(&rows[0][0], 0, f1c, koff, xb);
+            const f32x16 acc = conv0_tile(wa, bc, xb);
+            if (f1 < 40) {
+                half_t *o = out + (((size_t)b * t1_max + t1) * 40 + f1) * QV_SUBC + ch0 + 4 * hi;
 #pragma unroll
-            for (int df = 0; df < 3; ++df) {
-                float v = rows[dt][2 * f1 + df];  // input f = 2*f1 - 1 + df, stored at +1
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], v, acc[c]);
+                for (int q = 0; q < 4; ++q) *(half4 *)(o + 8 * q) = conv0_relu4(acc, q);
             }
-        half8 o;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] > 0.f ? acc[c] : 0.f);
-        *(half8 *)(out + (((size_t)b * t1_max + t1) * 40 + f1) * QV_SUBC + c0) = o;
+        }
     }
 }
 
@@ -249,19 +292,22 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
                                                half_t *__restrict__ out, int t2_max) {
     __shared__ __attribute__((aligned(16))) float rows[SUB_RM][QV_NMEL + 2];
     __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
-    __shared__ __attribute__((aligned(16))) half_t tile[SUB_R1][40][SUB_CG];
-    const int b = blockIdx.z, t2_0 = blockIdx.y * SUB_TT, cg = blockIdx.x * SUB_CG, tid = threadIdx.x;
+    // conv0 tile, position-major: position p = row * 40 + f owns 64 channels = eight 16-byte chunks; chunk c is stored at
+    // ((c + p) & 7) so that the 8-byte stores of the conv0 epilogue (32 positions x 2 halves per wave) spread over the banks
+    __shared__ __attribute__((aligned(16))) half_t tile[SUB_R1 * 40][SUB_CG];
+    // both convolutions' taps (rows 0 .. 8) and biases (row 9) for all 256 channels: fetched once per block, next to the mel
+    // rows' latency (per channel group from global memory they were 72 load instructions per thread and a latency in
+    // front of every group's matrix products)
+    __shared__ __attribute__((aligned(16))) float w0s[10][QV_SUBC], w1s[10][QV_SUBC];
+    const int b = blockIdx.z, t2_0 = blockIdx.y * SUB_TT, tid = threadIdx.x;
     const int tin = len_mel[b], l1 = len1[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
     if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
-    // the second convolution's taps + bias (10 x 64 floats) are requested now, one quad per thread, and parked in the
-    // mel-row buffer once conv0 has finished with it: fetched after conv0 they were a global latency in the middle of
-    // every block (and a buffer of their own would cost the third block per CU)
-    static_assert(10 * (SUB_CG / 4) <= 256 - 96 && 10 * SUB_CG <= SUB_RM * (QV_NMEL + 2), "w1 staging");
-    float (*w1s)[SUB_CG] = (float (*)[SUB_CG]) & rows[0][0];
-    f32x4 w1q = {0.f, 0.f, 0.f, 0.f};
-    const int w1k = (tid - 96) / (SUB_CG / 4), w1c = ((tid - 96) % (SUB_CG / 4)) * 4;
-    if (tid >= 96) w1q = *(const f32x4 *)((w1k < 9 ? w1t + w1k * QV_SUBC : b1) + cg + w1c);
+    for (int i = tid; i < 10 * QV_SUBC / 4; i += 256) {
+        const int k = i / (QV_SUBC / 4), c = (i % (QV_SUBC / 4)) * 4;
+        *(f32x4 *)&w0s[k][c] = *(const f32x4 *)((k < 9 ? w0t + k * QV_SUBC : b0) + c);
+        *(f32x4 *)&w1s[k][c] = *(const f32x4 *)((k < 9 ? w1t + k * QV_SUBC : b1) + c);
+    }
     __syncthreads();
     const int t1_0 = 2 * t2_0 - 1;         // first c0 row of the tile
     const int tm_0 = 2 * t1_0 - 1;         // first mel row
@@ -269,29 +315,63 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
         int r = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = tm_0 + r;
         rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? (x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f] : 0.f;
     }
-    const int c8 = (tid & 7) * 8, pl = tid >> 3;   // 8 channels per thread, 32 positions per pass
-    float w[9][8], bs[8];
-    auto load_w = [&](const float *wt, const float *bias) {
+    const int c8 = (tid & 7) * 8, pl = tid >> 3;   // depthwise stage: 8 channels per thread, 32 positions per pass
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    int koff[5];
+    conv0_tap_offsets(hi, koff);
+    // Round 4: the block walks the four 64-channel groups itself (the grid had one block per group: four blocks each
+    // waited for the statistics, fetched and normalised the same 19 mel rows -- three global latencies in front of
+    // ~7 k cycles of arithmetic, the larger part of a block's life).  The tile is reused from group to group.
+    for (int cg = 0; cg < QV_SUBC; cg += SUB_CG) {
+        // ---- conv0 + ReLU into the LDS tile on the f32 matrix pipe (rows outside [0, l1) are the depthwise conv's zero
+        // padding): the 360 positions are 12 tiles of 32 (the last one 8 wide), wave w owns tiles w, w + 4, w + 8 and
+        // both 32-channel halves of the group
+        {
+            __syncthreads();        // the mel rows and the weights are in LDS / the previous group's depthwise stage has left the tile
+            float wa[2][5], bc[2][16];
+            conv0_weights(&w0s[0][0], &w0s[9][0], cg, l31, hi, wa[0], bc[0]);
+            conv0_weights(&w0s[0][0], &w0s[9][0], cg + 32, l31, hi, wa[1], bc[1]);
+#pragma unroll
+            for (int pt = wave; pt < (SUB_R1 * 40 + 31) / 32; pt += 4) {
+                const int p = pt * 32 + l31, pc = p < SUB_R1 * 40 ? p : SUB_R1 * 40 - 1;
+                const int r = pc / 40, f1 = pc - r * 40;
+                float xb[5];
+                conv0_taps(&rows[0][0], 2 * r, f1, koff, xb);
+                half_t *trow = &tile[pc][4 * hi];       // lanes past the last position rewrite position 359 with its own values
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const f32x16 acc = conv0_tile(wa[ct], bc[ct], xb);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(half4 *)(trow + (((ct * 4 + q + pc) & 7) << 3)) = conv0_relu4(acc, q);
+                }
+            }
+        }
+        // rows outside [0, l1) are the depthwise conv's zero padding, not conv0 outputs: only the first block of an
+        // utterance and the ones at its end have any, and they zero them behind the products
+        if (t1_0 < 0 || t1_0 + SUB_R1 > l1) {
+            __syncthreads();
+            for (int i = tid; i < SUB_R1 * 40 * (SUB_CG / 8); i += 256) {
+                const int pp = i >> 3, t1 = t1_0 + pp / 40;
+                if (t1 < 0 || t1 >= l1) *(f32x4 *)&tile[pp][(i & 7) << 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();            // conv0 done: the tile is complete
+        // ---- depthwise 3x3 stride 2 over the tile
+        float w[9][8], bs[8];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            f32x4 wa = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8), wb = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8 + 4);
+            const f32x4 wa = *(const f32x4 *)&w1s[k][cg + c8], wb = *(const f32x4 *)&w1s[k][cg + c8 + 4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { w[k][c] = wa[c]; w[k][4 + c] = wb[c]; }
         }
-        f32x4 ba = *(const f32x4 *)(bias + cg + c8), bb = *(const f32x4 *)(bias + cg + c8 + 4);
+        {
+            const f32x4 ba = *(const f32x4 *)&w1s[9][cg + c8], bb = *(const f32x4 *)&w1s[9][cg + c8 + 4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
-    };
-    load_w(w0t, b0);
-    __syncthreads();
-    // ---- conv0 + ReLU into the LDS tile (rows outside [0, l1) are the depthwise conv's zero padding)
-    for (int p = pl; p < SUB_R1 * 40; p += 32) {
-        int r = p / 40, f1 = p - r * 40, t1 = t1_0 + r;
-        half8 o;
-        if (t1 < 0 || t1 >= l1) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
-        } else {
+            for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
+        }
+        for (int p = pl; p < SUB_TT * 20; p += 32) {
+            int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
+            if (t2 >= t2_max) continue;
             float acc[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = bs[c];
@@ -299,50 +379,18 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
             for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
                 for (int df = 0; df < 3; ++df) {
-                    float v = rows[2 * r + dt][2 * f1 + df];
+                    int f = 2 * fo - 1 + df;
+                    if (f < 0 || f >= 40) continue;
+                    const int pp = (2 * tl + dt) * 40 + f;
+                    half8 v = *(const half8 *)&tile[pp][(((tid & 7) + pp) & 7) << 3];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], v, acc[c]);
+                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
                 }
+            half8 o;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] > 0.f ? acc[c] : 0.f);
+            for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
+            *(half8 *)(out + (((size_t)b * t2_max + t2) * 20 + fo) * QV_SUBC + cg + c8) = o;
         }
-        *(half8 *)&tile[r][f1][c8] = o;
-    }
-    __syncthreads();            // conv0 done: the tile is complete, the mel rows are dead
-    if (tid >= 96) *(f32x4 *)&w1s[w1k][w1c] = w1q;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const f32x4 wa = *(const f32x4 *)&w1s[k][c8], wb = *(const f32x4 *)&w1s[k][c8 + 4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { w[k][c] = wa[c]; w[k][4 + c] = wb[c]; }
-    }
-    {
-        const f32x4 ba = *(const f32x4 *)&w1s[9][c8], bb = *(const f32x4 *)&w1s[9][c8 + 4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
-    }
-    // ---- depthwise 3x3 stride 2 over the tile
-    for (int p = pl; p < SUB_TT * 20; p += 32) {
-        int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
-        if (t2 >= t2_max) continue;
-        float acc[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = bs[c];
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-            for (int df = 0; df < 3; ++df) {
-                int f = 2 * fo - 1 + df;
-                if (f < 0 || f >= 40) continue;
-                half8 v = *(const half8 *)&tile[2 * tl + dt][f][c8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
-            }
-        half8 o;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
-        *(half8 *)(out + (((size_t)b * t2_max + t2) * 20 + fo) * QV_SUBC + cg + c8) = o;
     }
 }
 
@@ -1183,7 +1231,7 @@ void launch_conv0(const float *feats, int tm_max, const int32_t *len_in, const d
 void launch_sub01(const float *feats, int tm_max, const int32_t *len_mel, const double *stats, const float *w0,
                   const float *b0, const int32_t *len1, const float *w1, const float *b1, half_t *out, int t2_max, int batch,
                   hipStream_t s) {
-    hipLaunchKernelGGL(k_sub01, dim3(QV_SUBC / SUB_CG, (t2_max + SUB_TT - 1) / SUB_TT, batch), dim3(256), 0, s, feats, tm_max,
+    hipLaunchKernelGGL(k_sub01, dim3(1, (t2_max + SUB_TT - 1) / SUB_TT, batch), dim3(256), 0, s, feats, tm_max,
                        len_mel, stats, w0, b0, len1, w1, b1, out, t2_max);
 }
 
