@@ -1,0 +1,9 @@
+#!/bin/bash
+# last GPU call of round 4: soak of batches in flight in the three precisions, then the evidence round (tests first)
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"
+mkdir -p gpurun_out
+for p in 0 1 2; do timeout 300 python tools/soak.py --batches 1500 --seed $((11 + p)) --precision $p 2>&1 | grep -v amdgpu.ids; done > gpurun_out/soak_r04t.log 2>&1
+cat gpurun_out/soak_r04t.log
+bash tools/final_round.sh r04t
