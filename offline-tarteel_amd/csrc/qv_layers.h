@@ -11,6 +11,7 @@ struct FrontendTab {
     const float *mel_w;     // [32][80]: tap-major (tap k of filter m at k * 80 + m), zero beyond a filter's mel_cnt
 };
 
+size_t qv_melstats_doubles(size_t max_batch);   // size of the `stats` buffer launch_logmel needs (results + partial sums)
 void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
                    int tm_max, double *stats, int batch, hipStream_t s);
 void launch_melapply(const float *feats, const int32_t *n_samples, int tm_max, const double *stats, float *out, int batch,

@@ -92,12 +92,17 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
     }
 }
 
-// per-feature sum / sum of squares over the valid frames (f64 accumulation, one atomic per
-// feature per block); the normalisation itself is applied by conv0 while it loads its input rows,
-// so the features make no extra round trip through HBM.
+// per-feature sum / sum of squares over the valid frames (f64 accumulation); the normalisation itself is applied by conv0
+// while it loads its input rows, so the features make no extra round trip through HBM.
+// Each of the MS_CHUNKS blocks of an utterance writes its partial sums and k_melstats_sum adds them in chunk order.  (Until
+// round 4 the blocks added their partials to the result with f64 atomics, i.e. in whatever order they finished: the last
+// bit of a sum then depends on what else the GPU is running, and over a 30 s clip that flips the float32 rounding of a
+// feature's mean or 1 / std often enough to be seen -- 38 of 1,500 soak batches under QV_PREC_ORT_MIXED, whose quantisers
+// amplify a one-ulp feature column into a 1 % change of a score.  Found by the soak against a one-context engine while
+// other batches were in flight.)
 #define MS_CHUNKS 16
 __global__ __launch_bounds__(320) void k_melstats(const float *__restrict__ feats, const int32_t *__restrict__ n_samples,
-                                                  int tm_max, double *__restrict__ acc /*[B][80][2]*/) {
+                                                  int tm_max, double *__restrict__ part /*[B][MS_CHUNKS][80][2]*/) {
     __shared__ double p1[4][QV_NMEL], p2[4][QV_NMEL];
     const int b = blockIdx.y, f = threadIdx.x % QV_NMEL, g = threadIdx.x / QV_NMEL;  // 4 time groups
     const int tm = n_samples[b] / 160 + 1;
@@ -108,10 +113,18 @@ __global__ __launch_bounds__(320) void k_melstats(const float *__restrict__ feat
     p1[g][f] = s1;
     p2[g][f] = s2;
     __syncthreads();
-    if (g == 0 && t0 < t1) {
-        atomicAdd(&acc[((size_t)b * QV_NMEL + f) * 2], p1[0][f] + p1[1][f] + p1[2][f] + p1[3][f]);
-        atomicAdd(&acc[((size_t)b * QV_NMEL + f) * 2 + 1], p2[0][f] + p2[1][f] + p2[2][f] + p2[3][f]);
+    if (g == 0) {     // an empty chunk writes zeros
+        double *o = part + (((size_t)b * MS_CHUNKS + blockIdx.x) * QV_NMEL + f) * 2;
+        o[0] = p1[0][f] + p1[1][f] + p1[2][f] + p1[3][f];
+        o[1] = p2[0][f] + p2[1][f] + p2[2][f] + p2[3][f];
     }
+}
+__global__ __launch_bounds__(2 * QV_NMEL) void k_melstats_sum(const double *__restrict__ part, double *__restrict__ acc /*[B][80][2]*/) {
+    const int b = blockIdx.x, i = threadIdx.x;      // i = feature * 2 + {sum, sum of squares}
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < MS_CHUNKS; ++c) s += part[((size_t)b * MS_CHUNKS + c) * (2 * QV_NMEL) + i];
+    acc[(size_t)b * 2 * QV_NMEL + i] = s;
 }
 
 // materialise the normalised features (only for the debug tap / parity tests)
@@ -1211,11 +1224,14 @@ __global__ __launch_bounds__(256) void k_zero_pad_rows(float *__restrict__ out, 
 
 // ====================================================================== launchers ======
 
+// stats: [batch][80][2] results, followed by room for the [batch][MS_CHUNKS][80][2] partial sums (qv_melstats_doubles)
+size_t qv_melstats_doubles(size_t max_batch) { return max_batch * 2 * QV_NMEL * (1 + MS_CHUNKS); }
 void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
                    int tm_max, double *stats, int batch, hipStream_t s) {
-    (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * QV_NMEL * batch, s);
+    double *part = stats + (size_t)batch * 2 * QV_NMEL;
     hipLaunchKernelGGL(k_logmel, dim3((tm_max + 3) / 4, batch), dim3(256), 0, s, audio, n_max, n_samples, ft, feats, tm_max);
-    hipLaunchKernelGGL(k_melstats, dim3(MS_CHUNKS, batch), dim3(320), 0, s, feats, n_samples, tm_max, stats);
+    hipLaunchKernelGGL(k_melstats, dim3(MS_CHUNKS, batch), dim3(320), 0, s, feats, n_samples, tm_max, part);
+    hipLaunchKernelGGL(k_melstats_sum, dim3(batch), dim3(2 * QV_NMEL), 0, s, part, stats);
 }
 
 void launch_melapply(const float *feats, const int32_t *n_samples, int tm_max, const double *stats, float *out, int batch,

@@ -239,7 +239,7 @@ extern "C" int qv_weight_random(uint64_t seed, int32_t index, float *out, int64_
 // per-context state: the activations of one batch in flight
 struct QvActs {
     float *feats, *x, *logits;
-    double *mel_stats;   // [max_batch][80][2] per-feature sum / sum of squares
+    double *mel_stats;   // [batch][80][2] per-feature sum / sum of squares, then the per-chunk partial sums (qv_melstats_doubles)
     half_t *c0, *c1, *c1p, *c2, *c2p, *c2k, *ln, *hbuf, *qk, *vt, *att, *glu, *dw, *xh;
     int32_t *lens_dev;   // [5][max_batch]: n_samples, tm, l1, l2, l3; then [max_batch + 1] packed row offsets
     int32_t *row_map;    // [M] utterance << 16 | frame of every packed row (written by k_pack_rows)
@@ -679,7 +679,7 @@ int alloc_context(qv_engine *eng, QvModel *m, int k, bool sub_unfused) {
     const int t_pad_cap = (m->t3_cap + 31) / 32 * 32;
     m->lens_host = nullptr;
     TRY(dal(eng, m, Bz * m->tm_cap * QV_NMEL, &m->feats));
-    TRY(dal(eng, m, Bz * QV_NMEL * 2, &m->mel_stats));
+    TRY(dal(eng, m, qv_melstats_doubles(Bz), &m->mel_stats));
     // the conv0 activation only exists on the two-kernel cross-check path (QVERSE_SUB_UNFUSED=1)
     m->c0 = nullptr;
     if (sub_unfused) TRY(dal(eng, m, Bz * m->t1_cap * 40 * QV_SUBC, &m->c0));
@@ -1085,6 +1085,8 @@ int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out, hi
     if (what == 0) {
         // normalised features are never materialised on the fast path (conv0 normalises on load)
         launch_melapply(m->feats, m->lens_dev, m->last_tm_max, m->mel_stats, out, m->last_batch, s);
+    } else if (what == 10) {   // the log-mel features as k_logmel left them, [B][tm_max][80]
+        QV_HIP(hipMemcpyAsync(out, m->feats, sizeof(float) * (size_t)m->last_batch * m->last_tm_max * QV_NMEL, hipMemcpyDeviceToDevice, s));
     } else if (what >= 6 && what <= 9) {
         // QV_PREC_ORT_MIXED: the dense subsampling tensors in front of / behind the quantisers, as they sit in HBM
         if (!m->ort) { qv_set_error(eng, "taps 6..9 exist under QV_PREC_ORT_MIXED only"); return QV_ERR_ARG; }

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--batches", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", type=int, default=0)
+    ap.add_argument("--contexts", type=int, default=4)
+    ap.add_argument("--third", action="store_true", help="a second one-context engine says which side of a mismatch is the odd one")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -30,8 +32,9 @@ def main():
     cap = 480000
     rng = np.random.default_rng(args.seed)
     pool = torch.from_numpy(synth_audio(64, cap, seed=args.seed)).cuda().contiguous()
-    e4 = Engine(device=0, with_model=True, seed=5, precision=args.precision, max_batch=64, max_samples=cap, contexts=4)
+    e4 = Engine(device=0, with_model=True, seed=5, precision=args.precision, max_batch=64, max_samples=cap, contexts=args.contexts)
     e1 = Engine(device=0, with_model=True, seed=5, precision=args.precision, max_batch=64, max_samples=cap, contexts=1)
+    e1b = Engine(device=0, with_model=True, seed=5, precision=args.precision, max_batch=64, max_samples=cap, contexts=1) if args.third else None
     key = lambda r: (r["surah"], r["ayah"], r["ayah_end"], r["source"], r["score"], r["t_frames"], r["n_candidates"])  # noqa: E731
     inflight, bad, t0, utts = [], 0, time.perf_counter(), 0
     try:
@@ -53,7 +56,14 @@ def main():
                 want = [key(r) for r in e1.predict_batch(aa, ll, want_text=False)]
                 if got != want:
                     bad += 1
-                    print("MISMATCH at batch", i, "B", len(ll), [j for j, (g, w) in enumerate(zip(got, want)) if g != w][:5], flush=True)
+                    diff = [j for j, (g, w) in enumerate(zip(got, want)) if g != w]
+                    j0 = diff[0]
+                    who = ""
+                    if e1b is not None:
+                        third = [key(r) for r in e1b.predict_batch(aa, ll, want_text=False)]
+                        who = "third engine agrees with: " + ("one-context" if third == want else "multi-context" if third == got else "neither")
+                    print("MISMATCH at batch", i, "B", len(ll), "max_len", max(ll), "n_diff", len(diff), diff[:5],
+                          "len", ll[j0], "got", got[j0], "want", want[j0], who, flush=True)
         while inflight:
             c, aa, ll = inflight.pop(0)
             got = [key(r) for r in e4.fetch_results(c, len(ll), e4.frames_for(max(ll)), want_text=False)]
@@ -61,6 +71,8 @@ def main():
             bad += got != want
     finally:
         e4.close(); e1.close()
+        if e1b is not None:
+            e1b.close()
     print(f"soak: {args.batches} ragged batches, {utts} utterances, {bad} mismatching batches, {time.perf_counter() - t0:.1f} s")
     return 1 if bad else 0
 
