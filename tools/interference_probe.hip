@@ -1,0 +1,136 @@
+// interference_probe.hip -- does a kernel running on one stream change what the log-mel kernel computes on another?
+// Round 4 withdrew a version of k_sub01_ort (tools/withdrawn/qv_ort_conv0_mfma.hip) because, with it running in a second
+// engine, k_logmel occasionally produced a few wrong bins.  This is that situation without the
+// engine: stream V recomputes the log-mel features of one ragged batch over and over and counts the values that differ
+// from its first (undisturbed) result; stream A runs the candidate "aggressor" (both passes of k_sub01_ort on its own
+// buffers) at the same time.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I offline-tarteel_amd/csrc -I include \
+//         [-DPROBE_WITHDRAWN] tools/interference_probe.hip -o tools/interference_probe_{current,withdrawn}
+//   tools/interference_probe_withdrawn [iterations] [aggressor: 0 none, 1 range pass, 2 real pass, 3 both, 4 the f16 path's k_sub01,
+//                                                                   8 k_attention_short (64 x 126 frames), 16 k_attention_ws (64 x 376 frames)]
+#include "../offline-tarteel_amd/csrc/qv_layers.hip"
+#ifdef PROBE_WITHDRAWN
+#include "withdrawn/qv_ort_conv0_mfma.hip"
+#else
+#include "../offline-tarteel_amd/csrc/qv_ort.hip"
+#endif
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void k_count_diff(const float *__restrict__ a, const float *__restrict__ b, size_t n, unsigned long long *cnt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long d = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) d += __float_as_uint(a[i]) != __float_as_uint(b[i]);
+    if (d) atomicAdd(cnt, d);
+}
+
+template <class T> static T *dev(const std::vector<T> &h) {
+    T *p = nullptr;
+    if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return p;
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 400, aggr = argc > 2 ? atoi(argv[2]) : 3;
+    const int B = 58;
+    const int64_t n_max = 480000;
+    srand(7);
+    std::vector<int32_t> n(B), tm(B), l1(B), l2(B);
+    int tm_max = 0, t2_max = 0;
+    for (int b = 0; b < B; ++b) {
+        n[b] = b == 0 ? (int)n_max - 123 : 800 + rand() % (int)(n_max - 800);
+        tm[b] = n[b] / 160 + 1; l1[b] = (tm[b] - 1) / 2 + 1; l2[b] = (l1[b] - 1) / 2 + 1;
+        tm_max = std::max(tm_max, tm[b]); t2_max = std::max(t2_max, l2[b]);
+    }
+    std::vector<float> audio((size_t)B * n_max);
+    uint32_t st = 12345;
+    for (auto &x : audio) { st = st * 1664525u + 1013904223u; x = ((int)(st >> 8) % 2001 - 1000) * 2.5e-4f; }
+    for (int b = 0; b < B; ++b) for (int64_t i = n[b]; i < n_max; ++i) audio[(size_t)b * n_max + i] = 0.f;
+    // front-end tables: shape matters, contents only have to be deterministic
+    std::vector<float> window(512, 0.f), melw(32 * 80, 0.f);
+    std::vector<float2> tw(256);
+    std::vector<int32_t> lo(80), cnt(80);
+    for (int i = 0; i < 400; ++i) window[56 + i] = 0.5f - 0.5f * cosf(6.2831853f * i / 399.f);
+    for (int m = 0; m < 256; ++m) tw[m] = make_float2(cosf(-6.2831853f * m / 512.f), sinf(-6.2831853f * m / 512.f));
+    for (int m = 0; m < 80; ++m) {
+        lo[m] = 1 + m * 2; cnt[m] = 4 + m / 4;
+        for (int k = 0; k < cnt[m]; ++k) melw[k * 80 + m] = 1.f - fabsf(2.f * k / (cnt[m] - 1) - 1.f) + 1e-3f;
+    }
+    FrontendTab ft{dev(window), dev(tw), dev(lo), dev(cnt), dev(melw)};
+    float *d_audio = dev(audio);
+    int32_t *d_n = dev(n), *d_tm = dev(tm), *d_l1 = dev(l1), *d_l2 = dev(l2);
+    const size_t nf = (size_t)B * tm_max * QV_NMEL;
+    float *feats_v, *feats_ref, *feats_a, *out_a;
+    double *stats_v, *stats_a;
+    uint32_t *mm;
+    unsigned long long *d_cnt;
+    CK(hipMalloc(&feats_v, nf * 4)); CK(hipMalloc(&feats_ref, nf * 4)); CK(hipMalloc(&feats_a, nf * 4));
+    CK(hipMalloc(&out_a, (size_t)B * t2_max * 20 * QV_SUBC * 4));
+    CK(hipMalloc(&stats_v, qv_melstats_doubles(B) * 8)); CK(hipMalloc(&stats_a, qv_melstats_doubles(B) * 8));
+    CK(hipMalloc(&mm, (size_t)3 * B * QV_MM_STRIDE * 4)); CK(hipMalloc(&d_cnt, 8));
+    CK(hipMemset(d_cnt, 0, 8));
+    std::vector<float> w0(9 * QV_SUBC), w1(9 * QV_SUBC), b0(QV_SUBC), b1(QV_SUBC);
+    for (auto &x : w0) x = (float)(rand() % 255 - 127);
+    for (auto &x : w1) x = (float)(rand() % 255 - 127);
+    for (auto &x : b0) x = (rand() % 2001 - 1000) * 1e-3f;
+    for (auto &x : b1) x = (rand() % 2001 - 1000) * 1e-3f;
+    float *d_w0 = dev(w0), *d_w1 = dev(w1), *d_b0 = dev(b0), *d_b1 = dev(b1);
+    // attention inputs (tools/att_bench.hip's): 64 utterances of 126 / 376 frames
+    const int AB = 64, AT = (aggr & 16) ? 376 : 126, at_pad = (AT + 31) / 32 * 32, apos_ld = 17 * QV_D;
+    std::vector<half_t> hqk((size_t)AB * AT * 2 * QV_D), hvt((size_t)AB * QV_D * at_pad), hpos((size_t)(2 * AT - 1) * apos_ld);
+    for (auto &x : hqk) x = (half_t)((rand() % 2001 - 1000) / 1000.0f);
+    for (auto &x : hvt) x = (half_t)((rand() % 2001 - 1000) / 1000.0f);
+    for (auto &x : hpos) x = (half_t)((rand() % 2001 - 1000) / 1000.0f);
+    std::vector<float> hbias(QV_D, 0.01f);
+    std::vector<int32_t> alen(AB, AT), aoff(AB);
+    for (int b = 0; b < AB; ++b) aoff[b] = b * AT;
+    half_t *a_qk = dev(hqk), *a_vt = dev(hvt), *a_pos = dev(hpos), *a_out = nullptr;
+    float *a_bu = dev(hbias), *a_bv = dev(hbias);
+    int32_t *a_len = dev(alen), *a_off = dev(aoff);
+    CK(hipMalloc(&a_out, (size_t)AB * AT * QV_D * 2));
+    hipStream_t sv, sa;
+    CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    // undisturbed reference + the aggressor's own inputs
+    launch_logmel(d_audio, n_max, d_n, ft, feats_ref, tm_max, stats_v, B, sv);
+    launch_logmel(d_audio, n_max, d_n, ft, feats_a, tm_max, stats_a, B, sv);
+    CK(hipStreamSynchronize(sv));
+    uint32_t *mm_mel = mm, *mm_c0 = mm + (size_t)B * QV_MM_STRIDE, *mm_c1 = mm + (size_t)2 * B * QV_MM_STRIDE;
+    unsigned long long last = 0;
+    int bad_iters = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (aggr) {
+            if (aggr & 3) {
+                launch_mm_init(mm, (size_t)3 * B * QV_MM_STRIDE, sa);
+                launch_mel_minmax(feats_a, d_n, tm_max, stats_a, mm_mel, B, sa);
+            }
+            if (aggr & 1) launch_sub01_ort(0, feats_a, tm_max, d_tm, stats_a, d_w0, 0.01f, d_b0, d_l1, d_w1, 0.01f, d_b1, d_l2, mm_mel, mm_c0, mm_c1, out_a, t2_max, B, sa);
+            if (aggr & 24)
+                for (int r = 0; r < 17; ++r) launch_attention(a_qk, a_vt, a_pos, apos_ld, a_bu, a_bv, a_len, a_off, a_out, AT, AT, at_pad, AB, sa);
+            if (aggr & 4) launch_sub01(feats_a, tm_max, d_tm, stats_a, d_w0, d_b0, d_l1, d_w1, d_b1, (half_t *)out_a, t2_max, B, sa);
+            if (aggr & 2) launch_sub01_ort(1, feats_a, tm_max, d_tm, stats_a, d_w0, 0.01f, d_b0, d_l1, d_w1, 0.01f, d_b1, d_l2, mm_mel, mm_c0, mm_c1, out_a, t2_max, B, sa);
+        }
+        launch_logmel(d_audio, n_max, d_n, ft, feats_v, tm_max, stats_v, B, sv);
+        hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, sv, feats_v, feats_ref, nf, d_cnt);
+        if (it % 8 == 7 || it == iters - 1) {
+            CK(hipStreamSynchronize(sv));
+            unsigned long long c;
+            CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+            if (c != last) { ++bad_iters; last = c; }
+        }
+    }
+    CK(hipDeviceSynchronize());
+    printf("%s k_sub01_ort, aggressor passes %d, %d iterations of k_logmel on %d clips (%d frames max): %llu differing values, "
+           "seen in %d of %d checked groups of 8 iterations\n",
+#ifdef PROBE_WITHDRAWN
+           "WITHDRAWN",
+#else
+           "current",
+#endif
+           aggr, iters, B, tm_max, last, bad_iters, (iters + 7) / 8);
+    return 0;
+}

@@ -7,12 +7,22 @@
 // All of these are HBM-bound elementwise / small-stencil kernels; they keep the tiling of their f16 counterparts in
 // qv_layers.hip (a lane owns 8 channels, weights in registers, sliding windows), only the element type changes.
 
+// (a copy of offline-tarteel_amd/csrc/qv_ort.hip as of commit 444de69, kept for tools/interference_probe.hip; PROBE_ABL
+// switches parts of k_sub01_ort off to find which one disturbs a co-running k_logmel:
+//   1 no MFMA (accumulator = operand sum)   2 B operand not read from LDS   4 at most 2 waves per SIMD
+//   8 no range fold at the end              16 accumulator input from a register instead of the inline 0
+//   32 no conv.0 loop at all (prologue + fold only)   64 the same MFMA through inline asm with a VGPR destination
+//   128 a float32 MFMA (v_mfma_f32_32x32x2_f32) in its place, destination left to the compiler)
+#ifndef PROBE_ABL
+#define PROBE_ABL 0
+#endif
 #include "qv_ort.h"
 #include "qv_dev_util.h"
 
 #include <math.h>
 
 namespace {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void k_mm_init(uint32_t *__restrict__ mm, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,32 +279,36 @@ __global__ __launch_bounds__(320) void k_mel_minmax(const float *__restrict__ fe
 //   PASS 0: only the range of ReLU(conv.0) over the valid frames (its DynamicQuantizeLinear needs the max first);
 //   PASS 1: conv.0 again, quantised with that range into the tile (integers 0..255: exact as f16), then conv.2 ->
 //           f32 [B][T2][20][256] with its range folded for conv.3's quantiser.
-// (Round 4 had a version of this kernel with conv.0 on the matrix pipe -- one v_mfma_f32_32x32x16_f16 per 32 positions x 32
-// channels, all four channel groups in one block: range pass 715 -> 435 us, real pass 1546 -> 1379 us at B = 256, every
-// integer stage still bit-identical.  It was withdrawn at the end of the round: with it on the GPU, a log-mel kernel of
-// ANOTHER engine running at the same moment occasionally computed a few wrong power-spectrum bins (soak against a second
-// engine: 38 of 1,500 batches with 30 s clips; tools/dev_ort_race.py shows the first differing stage, the raw features and
-// that the same call repeated is right; with this version as the only difference in the background engine: 0 of 300).
-// The kernel had no out-of-range access in its ISA (LDS and global checked instruction by instruction); tools/
-// interference_probe.hip reproduces the disturbance in a second and its ablations say it takes that kernel's f16 MFMA (a f32
-// MFMA or VALU arithmetic in its place: nothing).  The proven kernel is back; DESIGN.md section 4, "Precision 2's extra".)
+// Round 4: conv.0 runs on the MATRIX pipe.  It is a [positions x 9] x [9 x channels] product of small integers
+// (|x_q - zp| <= 255, |w_q| <= 127: exact as f16, sums < 2^24 exact in the f32 accumulator), i.e. one
+// v_mfma_f32_32x32x16_f16 per 32 positions x 32 channels with K = 9 padded to 16 by zero weights -- 24 MFMAs per block
+// where the VALU version issued 1,620 packed FMAs.  The operand of 32 positions is gathered from the f16 mel rows with
+// three ds_read2_b32 and two repacks per lane (taps (dt, df) in k order dt * 3 + df; the lane half that owns k >= 8
+// needs tap 8 only, its other seven slots meet zero weights and may hold any finite value).  Same integers as before,
+// so every output is bit-identical (tests/test_gpu_ort_mixed.py::test_frontend_integer_stages compares with the oracle).
 #define SQ_TT 4
 #define SQ_R1 (2 * SQ_TT + 1)
 #define SQ_RM (2 * SQ_R1 + 1)
 #define SQ_CG 64
+#define SQ_HW 84                 // halves per mel row in LDS: 80 bins + one padding bin on either side, even pitch
+#define SQ_NPOS (SQ_R1 * 40)     // conv.0 positions of a tile
 template <int PASS>
-__global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_mel,
+__global__ __launch_bounds__(256)
+#if PROBE_ABL & 4
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_mel,
                                                    const double *__restrict__ stats, const float *__restrict__ w0q, float w0_scale,
                                                    const float *__restrict__ b0, const int32_t *__restrict__ len1,
                                                    const float *__restrict__ w1q, float w1_scale, const float *__restrict__ b1,
                                                    const int32_t *__restrict__ len2, const uint32_t *__restrict__ mm_mel,
                                                    uint32_t *__restrict__ mm_c0, uint32_t *__restrict__ mm_c1,
                                                    float *__restrict__ out, int t2_max) {
-    __shared__ float rows[SQ_RM][QV_NMEL + 2];
+    __shared__ __attribute__((aligned(16))) half_t hrow[SQ_RM][SQ_HW];
     __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
-    __shared__ __attribute__((aligned(16))) half_t tile[SQ_R1][40][SQ_CG];
+    __shared__ __attribute__((aligned(16))) half_t tile[PASS == 1 ? SQ_NPOS : 1][SQ_CG];
     __shared__ float s_fold[8];
-    const int b = blockIdx.z, t2_0 = blockIdx.y * SQ_TT, cg = blockIdx.x * SQ_CG, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.z, t2_0 = blockIdx.y * SQ_TT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tin = len_mel[b], l1 = len1[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
     if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
@@ -302,67 +316,120 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     const QParam pm = dql_param(mm_mel + QV_MM_STRIDE * b);
     const int t1_0 = 2 * t2_0 - 1;         // first conv.0 row of the tile
     const int tm_0 = 2 * t1_0 - 1;         // first mel row
-    for (int i = tid; i < SQ_RM * (QV_NMEL + 2); i += 256) {
-        int r = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = tm_0 + r;
+    for (int i = tid; i < SQ_RM * SQ_HW; i += 256) {
+        int r = i / SQ_HW, f = i % SQ_HW - 1, t = tm_0 + r;
         // frames past the utterance and the conv padding are real zeros = the zero point
-        rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_c((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) : 0.f;
+        hrow[r][f + 1] = (half_t)((t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_c((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) : 0.f);
     }
-    const int c8 = (tid & 7) * 8, pl = tid >> 3;   // 8 channels per thread, 32 positions per pass
-    float w[9][8], bs[8];
-    auto load_w = [&](const float *wt, const float *bias) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            f32x4 wa = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8), wb = *(const f32x4 *)(wt + k * QV_SUBC + cg + c8 + 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { w[k][c] = wa[c]; w[k][4 + c] = wb[c]; }
-        }
-        f32x4 ba = *(const f32x4 *)(bias + cg + c8), bb = *(const f32x4 *)(bias + cg + c8 + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
-    };
-    load_w(w0q, b0);
-    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5;
     const float s0 = pm.scale * w0_scale;
     QParam p0 = {1.f, 0.f, 1.f};
     if (PASS == 1) p0 = dql_param(mm_c0 + QV_MM_STRIDE * b);
-    float mn = INFINITY, mx = -INFINITY;
-    // ---- conv.0 + ReLU (rows outside [0, l1) are the depthwise conv's zero padding)
-    for (int p = pl; p < SQ_R1 * 40; p += 32) {
-        int r = p / 40, f1 = p - r * 40, t1 = t1_0 + r;
-        half8 o;
-        if (t1 < 0 || t1 >= l1) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
-        } else {
-            float acc[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-                for (int df = 0; df < 3; ++df) {
-                    float v = rows[2 * r + dt][2 * f1 + df];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], v, acc[c]);
-                }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float yv = acc[c] * s0 + bs[c];
-                yv = yv > 0.f ? yv : 0.f;
-                if (PASS == 0) { mn = fminf(mn, yv); mx = fmaxf(mx, yv); }
-                else o[c] = (half_t)quant_c(yv, p0);
-            }
-        }
-        if (PASS == 1) *(half8 *)&tile[r][f1][c8] = o;
-    }
-    if (PASS == 0) {
-        block_fold(mm_c0 + QV_MM_STRIDE * b, mn, mx, s_fold);
-        return;
-    }
-    load_w(w1q, b1);
-    __syncthreads();
     const float s1 = p0.scale * w1_scale;
     const int l2 = len2[b];
+    float mn = INFINITY, mx = -INFINITY;     // PASS 0: range of ReLU(conv.0); PASS 1: range of conv.2
+    __syncthreads();
+    // One block runs all four 64-channel groups over the same mel rows (round 4: with a block per group the per-block
+    // fixed work -- the f64 feature statistics, the quantisation of 19 mel rows, two barriers -- was most of the kernel:
+    // 64 k blocks at B = 256).
+    for (int cg = 0; cg < QV_SUBC; cg += SQ_CG) {
+    // ---- conv.0 weights of this group's two 32-channel tiles as MFMA operands (rows = channels): lane (channel, hi)
+    // holds k = 8 hi .. 8 hi + 7 of k = dt * 3 + df, zero beyond tap 8
+    half8 wa[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 8 * hi + i;
+            wa[ct][i] = (half_t)(k < 9 ? w0q[k * QV_SUBC + cg + ct * 32 + l31] : 0.f);
+        }
+    // bias of the 16 channels this lane owns per tile: channel 8 q + 4 hi + e
+    f32x4 bia[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bia[ct][q] = *(const f32x4 *)(b0 + cg + ct * 32 + 8 * q + 4 * hi);
+    // ---- conv.0 + ReLU: 12 position tiles of 32 (360 positions), three per wave
+    for (int pt = wave; pt * 32 < ((PROBE_ABL & 32) ? 0 : SQ_NPOS); pt += 4) {
+        const int p = pt * 32 + l31;
+        const bool inside = p < SQ_NPOS;
+        const int pc = inside ? p : SQ_NPOS - 1;
+        const int r = pc / 40, f1 = pc - r * 40;
+        // taps: mel rows 2 r + dt, padded bins 2 f1 + df (bin -1 is index 0): halves at even index 2 f1 -> dword aligned
+#if PROBE_ABL & 2
+        const uint32_t *rw = (const uint32_t *)&hrow[0][0];
+        (void)r; (void)f1;
+#else
+        const uint32_t *rw = (const uint32_t *)&hrow[2 * r][2 * f1];
+#endif
+        const uint32_t d00 = rw[0], d01 = rw[1];
+        const uint32_t d10 = rw[SQ_HW / 2], d11 = rw[SQ_HW / 2 + 1];
+        const uint32_t d20 = rw[SQ_HW], d21 = rw[SQ_HW + 1];
+        // k 0..7 = (0,0) (0,1) (0,2) (1,0) (1,1) (1,2) (2,0) (2,1); k 8 = (2,2) in the other lane half
+        u32x4 bw;
+        bw[0] = hi ? d21 : d00;
+        bw[1] = hi ? d00 : ((d01 & 0xFFFFu) | (d10 << 16));
+        bw[2] = hi ? d00 : __builtin_amdgcn_alignbit(d11, d10, 16);
+        bw[3] = hi ? d00 : d20;
+        const half8 bf = __builtin_bit_cast(half8, bw);
+        const int t1 = t1_0 + r;
+        const bool live = inside && t1 >= 0 && t1 < l1;    // rows outside [0, l1) are the depthwise conv's zero padding
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x16 z = {};
+#if PROBE_ABL & 16
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = s0 * 0.f;
+#endif
+#if PROBE_ABL & 1
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (float)wa[ct][r & 7] * (float)bf[r & 7] + (float)r;
+#elif PROBE_ABL & 64
+            f32x16 acc;
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 15" : "=v"(acc) : "v"(wa[ct]), "v"(bf));
+#elif PROBE_ABL & 128
+            f32x16 acc = z;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)wa[ct][j], (float)bf[j], acc, 0, 0, 0);
+#else
+            const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ct], bf, z, 0, 0, 0);
+#endif
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float yv = acc[4 * q + e] * s0 + bia[ct][q][e];
+                    yv = yv > 0.f ? yv : 0.f;
+                    if (PASS == 0) { if (live) { mn = fminf(mn, yv); mx = fmaxf(mx, yv); } }
+                    else o[e] = (half_t)(live ? quant_c(yv, p0) : 0.f);
+                }
+                // tile[position][64 channels]: the 16-byte chunk c of a position sits at (c + position) & 7, so that the 32
+                // positions of a wave store spread over the banks while the depthwise conv's 8 threads per position still read
+                // one contiguous 128 bytes
+                if (PASS == 1 && inside) {
+                    const int c = ct * 4 + q;
+                    *(half4 *)&tile[p][(((c + p) & 7) << 3) + 4 * hi] = o;
+                }
+            }
+        }
+    }
+    if (PASS == 0) continue;
+    const int c8 = (tid & 7) * 8, pl = tid >> 3;   // depthwise conv: 8 channels per thread, 32 positions per pass
+    float w[9][8], bs[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        f32x4 wa4 = *(const f32x4 *)(w1q + k * QV_SUBC + cg + c8), wb4 = *(const f32x4 *)(w1q + k * QV_SUBC + cg + c8 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w[k][c] = wa4[c]; w[k][4 + c] = wb4[c]; }
+    }
+    {
+        f32x4 ba = *(const f32x4 *)(b1 + cg + c8), bb = *(const f32x4 *)(b1 + cg + c8 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
+    }
+    __syncthreads();
     // ---- depthwise 3x3 stride 2 over the tile
     for (int p = pl; p < SQ_TT * 20; p += 32) {
         int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
@@ -376,7 +443,8 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
             for (int df = 0; df < 3; ++df) {
                 int f = 2 * fo - 1 + df;
                 if (f < 0 || f >= 40) continue;
-                half8 v = *(const half8 *)&tile[2 * tl + dt][f][c8];
+                const int pos = (2 * tl + dt) * 40 + f;
+                half8 v = *(const half8 *)&tile[pos][(((c8 >> 3) + pos) & 7) << 3];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
             }
@@ -390,7 +458,13 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
         *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
-    block_fold(mm_c1 + QV_MM_STRIDE * b, mn, mx, s_fold);
+    __syncthreads();                       // the tile is rewritten by the next channel group
+    }
+#if PROBE_ABL & 8
+    if (mn == 12345.f) out[0] = mx;
+#else
+    block_fold((PASS == 0 ? mm_c0 : mm_c1) + QV_MM_STRIDE * b, mn, mx, s_fold);
+#endif
 }
 
 // conv.5: depthwise Conv2d(256, 3x3, s2, p1) as ConvInteger on the quantised f32 input (channels-last); rows
@@ -502,7 +576,7 @@ void launch_sub01_ort(int pass, const float *feats, int tm_max, const int32_t *l
                       float w0_scale, const float *b0, const int32_t *len1, const float *w1q, float w1_scale, const float *b1,
                       const int32_t *len2, const uint32_t *mm_mel, uint32_t *mm_c0, uint32_t *mm_c1, float *out, int t2_max,
                       int batch, hipStream_t s) {
-    const dim3 grid(QV_SUBC / SQ_CG, (t2_max + SQ_TT - 1) / SQ_TT, batch);
+    const dim3 grid(1, (t2_max + SQ_TT - 1) / SQ_TT, batch);   // (all four channel groups in one block)
     if (pass == 0)
         hipLaunchKernelGGL((k_sub01_ort<0>), grid, dim3(256), 0, s, feats, tm_max, len_mel, stats, w0q, w0_scale, b0, len1, w1q,
                            w1_scale, b1, len2, mm_mel, mm_c0, mm_c1, out, t2_max);
