@@ -28,6 +28,31 @@ __global__ void k_count_diff(const float *__restrict__ a, const float *__restric
     if (d) atomicAdd(cnt, d);
 }
 
+// other victims: which kind of kernel can be disturbed?  1: registers only (a dependent FMA / sqrt / log chain per thread);
+// 2: lanes exchange values through LDS without a barrier (wave-synchronous, like k_logmel's FFT); 3: the same exchange
+// with __syncthreads() between the write and the read
+template <int KIND>
+__global__ __launch_bounds__(256) void k_victim(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+    __shared__ float sh[4][64];
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (size_t i = i0; i < n; i += (size_t)gridDim.x * 256) {
+        float v = x[i], a = 0.5f;
+        for (int r = 0; r < 24; ++r) {
+            a = __builtin_fmaf(a, 0.75f, v);
+            a = sqrtf(a * a + 1.0f);
+            if (KIND >= 2) {
+                __builtin_amdgcn_wave_barrier();
+                sh[wave][lane] = a;
+                if (KIND == 3) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+                a += 0.25f * sh[wave][(lane + 1 + r) & 63];
+                if (KIND == 3) __syncthreads();
+            }
+        }
+        y[i] = logf(a);
+    }
+}
+
 template <class T> static T *dev(const std::vector<T> &h) {
     T *p = nullptr;
     if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return nullptr;
@@ -36,7 +61,7 @@ template <class T> static T *dev(const std::vector<T> &h) {
 }
 
 int main(int argc, char **argv) {
-    const int iters = argc > 1 ? atoi(argv[1]) : 400, aggr = argc > 2 ? atoi(argv[2]) : 3;
+    const int iters = argc > 1 ? atoi(argv[1]) : 400, aggr = argc > 2 ? atoi(argv[2]) : 3, victim = argc > 3 ? atoi(argv[3]) : 0;
     const int B = 58;
     const int64_t n_max = 480000;
     srand(7);
@@ -96,6 +121,15 @@ int main(int argc, char **argv) {
     hipStream_t sv, sa;
     CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     // undisturbed reference + the aggressor's own inputs
+    const size_t nv = 58ull * 3000 * 80;     // the other victims work on the first values of the audio, same output size
+    auto run_victim = [&](float *out) {
+        if (victim == 0) launch_logmel(d_audio, n_max, d_n, ft, out, tm_max, stats_v, B, sv);
+        else if (victim == 1) hipLaunchKernelGGL(k_victim<1>, dim3(4096), dim3(256), 0, sv, d_audio, out, std::min(nv, nf));
+        else if (victim == 2) hipLaunchKernelGGL(k_victim<2>, dim3(4096), dim3(256), 0, sv, d_audio, out, std::min(nv, nf) / 256 * 256);
+        else hipLaunchKernelGGL(k_victim<3>, dim3(4096), dim3(256), 0, sv, d_audio, out, std::min(nv, nf) / 256 * 256);
+    };
+    CK(hipMemset(feats_ref, 0, nf * 4)); CK(hipMemset(feats_v, 0, nf * 4));
+    if (victim) run_victim(feats_ref); else
     launch_logmel(d_audio, n_max, d_n, ft, feats_ref, tm_max, stats_v, B, sv);
     launch_logmel(d_audio, n_max, d_n, ft, feats_a, tm_max, stats_a, B, sv);
     CK(hipStreamSynchronize(sv));
@@ -114,7 +148,7 @@ int main(int argc, char **argv) {
             if (aggr & 4) launch_sub01(feats_a, tm_max, d_tm, stats_a, d_w0, d_b0, d_l1, d_w1, d_b1, (half_t *)out_a, t2_max, B, sa);
             if (aggr & 2) launch_sub01_ort(1, feats_a, tm_max, d_tm, stats_a, d_w0, 0.01f, d_b0, d_l1, d_w1, 0.01f, d_b1, d_l2, mm_mel, mm_c0, mm_c1, out_a, t2_max, B, sa);
         }
-        launch_logmel(d_audio, n_max, d_n, ft, feats_v, tm_max, stats_v, B, sv);
+        run_victim(feats_v);
         hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, sv, feats_v, feats_ref, nf, d_cnt);
         if (it % 8 == 7 || it == iters - 1) {
             CK(hipStreamSynchronize(sv));
@@ -124,13 +158,13 @@ int main(int argc, char **argv) {
         }
     }
     CK(hipDeviceSynchronize());
-    printf("%s k_sub01_ort, aggressor passes %d, %d iterations of k_logmel on %d clips (%d frames max): %llu differing values, "
+    printf("%s k_sub01_ort, aggressor passes %d, victim %d, %d iterations of k_logmel on %d clips (%d frames max): %llu differing values, "
            "seen in %d of %d checked groups of 8 iterations\n",
 #ifdef PROBE_WITHDRAWN
            "WITHDRAWN",
 #else
            "current",
 #endif
-           aggr, iters, B, tm_max, last, bad_iters, (iters + 7) / 8);
+           aggr, victim, iters, B, tm_max, last, bad_iters, (iters + 7) / 8);
     return 0;
 }
