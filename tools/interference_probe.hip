@@ -28,6 +28,84 @@ __global__ void k_count_diff(const float *__restrict__ a, const float *__restric
     if (d) atomicAdd(cnt, d);
 }
 
+// k_logmel itself with parts changed (victim 4: no wave leaves early -- frames past the end recompute the last frame;
+// victim 5: twiddle factors from global memory, so no LDS table and no block barrier; victim 6: the unchanged copy)
+template <int VAR>
+__global__ __launch_bounds__(256) void k_logmel_var(const float *__restrict__ audio, int64_t n_max,
+                                                const int32_t *__restrict__ n_samples, const FrontendTab ft,
+                                                float *__restrict__ feats, int tm_max) {
+    __shared__ float2 buf[4][2][256];
+    __shared__ float pw[4][264];
+    __shared__ float2 tw[256];   // the twiddle table: every FFT pass fetched its factors from global memory (waves parked 79 %)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, t = blockIdx.x * 4 + wave;
+    const int n = n_samples[b];
+    const int tm = n / 160 + 1;
+    if (VAR != 2) { tw[threadIdx.x] = ft.twiddle[threadIdx.x]; __syncthreads(); }
+    const bool past = t >= tm;
+    if (past && VAR != 1) return;
+    const int t_store = t;
+    const int tt = past ? tm - 1 : t;
+#define t tt
+    const float *x = audio + (size_t)b * n_max;
+    float2 *A = buf[wave][0], *Bf = buf[wave][1];
+    auto sample = [&](int i) {
+        int s = t * 160 - 256 + i;
+        if (s < 0) s = -s;
+        if (s >= n) s = 2 * (n - 1) - s;
+        s = s < 0 ? 0 : s;
+        float y = x[s] - (s > 0 ? 0.97f * x[s - 1] : 0.f);
+        return y * ft.window[i];
+    };
+    for (int i = lane; i < 256; i += 64) A[i] = make_float2(sample(2 * i), sample(2 * i + 1));
+    // Stockham autosort, radix 2, N = 256: pass p (len = 1 << p): out[j*2*len + k] , out[... + len]
+    float2 *src = A, *dst = Bf;
+    for (int p = 0; p < 8; ++p) {
+        int len = 1 << p;  // half-size of the butterflies produced so far
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 128; i += 64) {
+            int k = i & (len - 1), j = i >> p;  // j: group, k: index within group
+            float2 u = src[j * len + k], v = src[j * len + k + 128];
+            // twiddle w = exp(-2 pi i * k / (2 len)) from the 512-point table
+            float2 w = VAR == 2 ? ft.twiddle[k * (256 >> p)] : tw[k * (256 >> p)];
+            float2 vw = make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
+            dst[j * 2 * len + k] = make_float2(u.x + vw.x, u.y + vw.y);
+            dst[j * 2 * len + k + len] = make_float2(u.x - vw.x, u.y - vw.y);
+        }
+        float2 *tmp = src; src = dst; dst = tmp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // X[k] = E[k] - i W^k O[k],  E = (Z[k] + conj Z[256-k]) / 2,  O = (Z[k] - conj Z[256-k]) / 2,  W = exp(-2 pi i / 512)
+    for (int k = lane; k < 257; k += 64) {
+        float2 X;
+        if (k == 0 || k == 256) {
+            float2 z0 = src[0];
+            X = make_float2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.f);
+        } else {
+            float2 zk = src[k], zc = src[256 - k];
+            float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+            float2 O = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+            float2 w = VAR == 2 ? ft.twiddle[k] : tw[k];
+            float2 P = make_float2(__builtin_fmaf(w.x, O.x, -(w.y * O.y)), __builtin_fmaf(w.x, O.y, w.y * O.x));
+            X = make_float2(E.x + P.y, E.y - P.x);
+        }
+        float mag = sqrtf(X.x * X.x + X.y * X.y);
+        pw[wave][k] = mag * mag;
+    }
+    __builtin_amdgcn_wave_barrier();
+#undef t
+    if (past) return;
+    float *out = feats + ((size_t)b * tm_max + t_store) * QV_NMEL;
+    for (int m = lane; m < QV_NMEL; m += 64) {
+        int lo = ft.mel_lo[m], cnt = ft.mel_cnt[m];
+        const float *w = ft.mel_w + m;        // tap-major [32][80]
+        float acc = 0.f;
+        for (int k = 0; k < cnt; ++k) acc += w[k * QV_NMEL] * pw[wave][lo + k];
+        out[m] = logf(acc + 5.9604644775390625e-08f);
+    }
+}
+
+
 // other victims: which kind of kernel can be disturbed?  1: registers only (a dependent FMA / sqrt / log chain per thread);
 // 2: lanes exchange values through LDS without a barrier (wave-synchronous, like k_logmel's FFT); 3: the same exchange
 // with __syncthreads() between the write and the read
@@ -124,6 +202,12 @@ int main(int argc, char **argv) {
     const size_t nv = 58ull * 3000 * 80;     // the other victims work on the first values of the audio, same output size
     auto run_victim = [&](float *out) {
         if (victim == 0) launch_logmel(d_audio, n_max, d_n, ft, out, tm_max, stats_v, B, sv);
+        else if (victim >= 4) {
+            const dim3 g((tm_max + 3) / 4, B);
+            if (victim == 4) hipLaunchKernelGGL(k_logmel_var<1>, g, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
+            else if (victim == 5) hipLaunchKernelGGL(k_logmel_var<2>, g, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
+            else hipLaunchKernelGGL(k_logmel_var<0>, g, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
+        }
         else if (victim == 1) hipLaunchKernelGGL(k_victim<1>, dim3(4096), dim3(256), 0, sv, d_audio, out, std::min(nv, nf));
         else if (victim == 2) hipLaunchKernelGGL(k_victim<2>, dim3(4096), dim3(256), 0, sv, d_audio, out, std::min(nv, nf) / 256 * 256);
         else hipLaunchKernelGGL(k_victim<3>, dim3(4096), dim3(256), 0, sv, d_audio, out, std::min(nv, nf) / 256 * 256);

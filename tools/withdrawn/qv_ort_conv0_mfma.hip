@@ -12,7 +12,8 @@
 //   1 no MFMA (accumulator = operand sum)   2 B operand not read from LDS   4 at most 2 waves per SIMD
 //   8 no range fold at the end              16 accumulator input from a register instead of the inline 0
 //   32 no conv.0 loop at all (prologue + fold only)   64 the same MFMA through inline asm with a VGPR destination
-//   128 a float32 MFMA (v_mfma_f32_32x32x2_f32) in its place, destination left to the compiler)
+//   128 a float32 MFMA (v_mfma_f32_32x32x2_f32) in its place, destination left to the compiler
+//   256 operands replaced by pseudo-random values in [-1, 1)   512 four chained MFMAs instead of one)
 #ifndef PROBE_ABL
 #define PROBE_ABL 0
 #endif
@@ -392,6 +393,19 @@ void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__r
             f32x16 acc = z;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)wa[ct][j], (float)bf[j], acc, 0, 0, 0);
+#elif PROBE_ABL & 256
+            half8 ra, rb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t h1 = (uint32_t)(tid * 8 + i + pt * 977 + ct * 131) * 2654435761u, h2 = h1 * 2246822519u + 374761393u;
+                ra[i] = (half_t)((float)(h1 >> 9) * (1.0f / 4194304.0f) - 1.0f);
+                rb[i] = (half_t)((float)(h2 >> 9) * (1.0f / 4194304.0f) - 1.0f);
+            }
+            const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra, rb, z, 0, 0, 0);
+#elif PROBE_ABL & 512
+            f32x16 acc = z;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ct], bf, acc, 0, 0, 0);
 #else
             const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ct], bf, z, 0, 0, 0);
 #endif
