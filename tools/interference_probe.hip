@@ -139,7 +139,8 @@ template <class T> static T *dev(const std::vector<T> &h) {
 }
 
 int main(int argc, char **argv) {
-    const int iters = argc > 1 ? atoi(argv[1]) : 400, aggr = argc > 2 ? atoi(argv[2]) : 3, victim = argc > 3 ? atoi(argv[3]) : 0;
+    const int iters = argc > 1 ? atoi(argv[1]) : 400, aggr = argc > 2 ? atoi(argv[2]) : 3, victim = argc > 3 ? atoi(argv[3]) : 0,
+              wfrac = argc > 4 ? atoi(argv[4]) : 0;   // 1: the aggressor's conv.0 weights are fractions in (-1, 1) instead of integers
     const int B = 58;
     const int64_t n_max = 480000;
     srand(7);
@@ -178,7 +179,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&mm, (size_t)3 * B * QV_MM_STRIDE * 4)); CK(hipMalloc(&d_cnt, 8));
     CK(hipMemset(d_cnt, 0, 8));
     std::vector<float> w0(9 * QV_SUBC), w1(9 * QV_SUBC), b0(QV_SUBC), b1(QV_SUBC);
-    for (auto &x : w0) x = (float)(rand() % 255 - 127);
+    for (auto &x : w0) x = wfrac ? (rand() % 20001 - 10000) * 1e-4f : (float)(rand() % 255 - 127);
     for (auto &x : w1) x = (float)(rand() % 255 - 127);
     for (auto &x : b0) x = (rand() % 2001 - 1000) * 1e-3f;
     for (auto &x : b1) x = (rand() % 2001 - 1000) * 1e-3f;

@@ -13,7 +13,8 @@
 //   8 no range fold at the end              16 accumulator input from a register instead of the inline 0
 //   32 no conv.0 loop at all (prologue + fold only)   64 the same MFMA through inline asm with a VGPR destination
 //   128 a float32 MFMA (v_mfma_f32_32x32x2_f32) in its place, destination left to the compiler
-//   256 operands replaced by pseudo-random values in [-1, 1)   512 four chained MFMAs instead of one)
+//   256 operands replaced by pseudo-random values in [-1, 1)   512 four chained MFMAs instead of one
+//   1024 the quantised mel rows scaled into fractions (x / 256 + 0.3): same instructions, other operand DATA)
 #ifndef PROBE_ABL
 #define PROBE_ABL 0
 #endif
@@ -320,7 +321,11 @@ void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__r
     for (int i = tid; i < SQ_RM * SQ_HW; i += 256) {
         int r = i / SQ_HW, f = i % SQ_HW - 1, t = tm_0 + r;
         // frames past the utterance and the conv padding are real zeros = the zero point
+#if PROBE_ABL & 1024
+        hrow[r][f + 1] = (half_t)(((t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_c((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) : 0.f) * 0.00390625f + 0.3f);
+#else
         hrow[r][f + 1] = (half_t)((t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_c((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) : 0.f);
+#endif
     }
     const int l31 = lane & 31, hi = lane >> 5;
     const float s0 = pm.scale * w0_scale;
