@@ -14,7 +14,9 @@
 //   32 no conv.0 loop at all (prologue + fold only)   64 the same MFMA through inline asm with a VGPR destination
 //   128 a float32 MFMA (v_mfma_f32_32x32x2_f32) in its place, destination left to the compiler
 //   256 operands replaced by pseudo-random values in [-1, 1)   512 four chained MFMAs instead of one
-//   1024 the quantised mel rows scaled into fractions (x / 256 + 0.3): same instructions, other operand DATA)
+//   1024 the quantised mel rows scaled into fractions (x / 256 + 0.3): same instructions, other operand DATA
+//   2048 the original MFMA with ~150 extra dependent integer operations per MFMA (the rate of variant 256)
+//   4096 register-sourced pseudo-random operands computed ONCE per thread (the rate of the original))
 #ifndef PROBE_ABL
 #define PROBE_ABL 0
 #endif
@@ -398,6 +400,18 @@ void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__r
             f32x16 acc = z;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)wa[ct][j], (float)bf[j], acc, 0, 0, 0);
+#elif PROBE_ABL & 4096
+            half8 ra, rb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ra[i] = (half_t)(s0 * 0.f + 0.37f + 0.01f * i + 0.001f * (tid & 63)); rb[i] = (half_t)(0.61f - 0.02f * i - 0.002f * (tid & 31)); }
+            asm volatile("" : "+v"(ra), "+v"(rb));
+            const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra, rb, z, 0, 0, 0);
+#elif PROBE_ABL & 2048
+            uint32_t busy = (uint32_t)(tid + pt + ct);
+#pragma unroll
+            for (int i = 0; i < 150; ++i) busy = busy * 2654435761u + (busy >> 7);
+            if (busy == 0x12345u) mn = -1.f;
+            const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ct], bf, z, 0, 0, 0);
 #elif PROBE_ABL & 256
             half8 ra, rb;
 #pragma unroll
