@@ -16,7 +16,8 @@
 //   256 operands replaced by pseudo-random values in [-1, 1)   512 four chained MFMAs instead of one
 //   1024 the quantised mel rows scaled into fractions (x / 256 + 0.3): same instructions, other operand DATA
 //   2048 the original MFMA with ~150 extra dependent integer operations per MFMA (the rate of variant 256)
-//   4096 register-sourced pseudo-random operands computed ONCE per thread (the rate of the original))
+//   4096 register-sourced pseudo-random operands computed ONCE per thread (the rate of the original)
+//   8192 conv.0 as it would ship next: five v_mfma_f32_32x32x2_f32 on the same integer operands (exact, same results))
 #ifndef PROBE_ABL
 #define PROBE_ABL 0
 #endif
@@ -400,6 +401,15 @@ void k_sub01_ort(const float *__restrict__ feats, int tm_max, const int32_t *__r
             f32x16 acc = z;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)wa[ct][j], (float)bf[j], acc, 0, 0, 0);
+#elif PROBE_ABL & 8192
+            f32x16 acc = z;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int k = 2 * j + hi, kk = k < 9 ? k : 8;
+                const float xb = (float)hrow[2 * r + kk / 3][2 * f1 + kk % 3];
+                const float wv = k < 9 ? w0q[k * QV_SUBC + cg + ct * 32 + l31] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xb, acc, 0, 0, 0);
+            }
 #elif PROBE_ABL & 4096
             half8 ra, rb;
 #pragma unroll
