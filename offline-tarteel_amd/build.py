@@ -20,6 +20,18 @@ CSRC = PKG / "csrc"
 OBJ = PKG / "build"
 LIB = PKG / "libqverse.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# No packed-FP32 instructions (v_pk_add/mul/fma_f32) anywhere in the library.  Round 5 traced the "k_logmel computes a few
+# wrong power-spectrum bins while a kernel of another engine runs" disturbance of round 4 to them: next to a wave that
+# issues v_mfma_f32_32x32x16_f16 fed from LDS at full rate on the same SIMD, a v_pk_*_f32 of the victim wave delivers wrong
+# results in lanes 48-63 (tools/interference_probe, victims 12/13: the FFT output is right, the first wrong values are the
+# float2 arithmetic of the real-transform unpack, always the last lane quarter; with this switch every victim variant is
+# undisturbed, profiles/r05_a_interference_*.log).  Scalar v_mul/add/fma_f32 form the same IEEE results, so no bit changes,
+# and the library's kernels are memory- or matrix-pipe-bound: the bench lines do not move (profiles/r05_b_*).
+# The two GEMM translation units keep them: their kernels are tuned to the 128-VGPR budget of a 512-thread block, two W8A16
+# variants spill 5-7 registers without the packed forms (tests/test_capi_load.py forbids spills there: the loaders count
+# their own vector-memory operations), and a GEMM block shares its SIMDs with other kernels' waves only in its tail.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+PACKED_F32_TUS = {"qv_gemm", "qv_gemm256"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
@@ -42,7 +54,9 @@ def build(force: bool = False, verbose: bool = False, dev_hooks: bool = False) -
     # the objects of a --dev-hooks build must never be linked into a product build (and vice versa): a flavour stamp
     # forces a full rebuild when the flavour changes (tests/test_capi_load.py also checks the library for the hook names)
     stamp = OBJ / "flavour.txt"
-    flavour = "dev-hooks" if dev_hooks else "product"
+    import hashlib
+    flavour = ("dev-hooks" if dev_hooks else "product") + " flags " + hashlib.sha1(
+        repr((FLAGS, NO_PACKED_F32, sorted(PACKED_F32_TUS))).encode()).hexdigest()[:12]   # a flag change rebuilds everything
     if not stamp.exists() or stamp.read_text().strip() != flavour:
         force = True
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "qverse.h"]
@@ -54,7 +68,8 @@ def build(force: bool = False, verbose: bool = False, dev_hooks: bool = False) -
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC, *FLAGS, *(["-DQV_DEV_HOOKS"] if dev_hooks else []), "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *FLAGS, *([] if src.stem in PACKED_F32_TUS else NO_PACKED_F32), *(["-DQV_DEV_HOOKS"] if dev_hooks else []),
+               "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -947,6 +947,12 @@ extern "C" int qv_debug_attention_variant(int32_t mode) {
     return QV_OK;
 }
 
+extern "C" int qv_debug_kernel_variant(int32_t which, int32_t mode) {
+    if (which < 0 || which >= QV_KV_COUNT || mode < -1 || mode > 15) return QV_ERR_ARG;
+    qv_kernel_variant_set(which, mode);
+    return QV_OK;
+}
+
 extern "C" int qv_debug_gemm_tiles(int32_t mode) {
     if (mode < -1 || mode > 2) return QV_ERR_ARG;
     qv_gemm_set_t256(mode);

@@ -50,3 +50,22 @@ static __device__ __forceinline__ void ln_row_p(const float v[8], const LnParam 
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mu) * rs * p.g0[i] + p.b0[i]; o[4 + i] = (v[4 + i] - mu) * rs * p.g1[i] + p.b1[i]; }
 }
+
+// conv.0 (3 x 3, stride 2, pad 1 over [frames][80 bins]) on the f32 matrix pipe, v_mfma_f32_32x32x2_f32: two taps per
+// instruction, five instructions (the tenth tap meets a zero weight).  The B operand of lane (l31 = position, hi = tap
+// parity) for instruction j is the input sample of tap 2j + hi at that position.
+// the five B operands of one position: input rows r0 .. r0 + 2 (LDS row pitch QV_NMEL + 2, column f + 1), columns 2 f1 + kx.
+// koff[j] is the lane's offset of tap 2j + hi inside that 3 x 3 window (conv0_tap_offsets; the tenth tap reads the ninth's
+// sample against a zero weight), so the fetch is five plain LDS reads
+static __device__ __forceinline__ void conv0_tap_offsets(int hi, int koff[5]) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int k = 2 * j + hi < 9 ? 2 * j + hi : 8;
+        koff[j] = (k / 3) * (QV_NMEL + 2) + k % 3;
+    }
+}
+static __device__ __forceinline__ void conv0_taps(const float *rows, int r0, int f1, const int koff[5], float xb[5]) {
+    const float *base = rows + r0 * (QV_NMEL + 2) + 2 * f1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) xb[j] = base[koff[j]];
+}

@@ -114,6 +114,15 @@ void qv_gemm_set_t256(int mode);
 // the kernel launch_gemm picks for this call, e.g. "k_gemm256<f16_swish>" / "k_gemm<resid,128>" (thread-local buffer)
 const char *qv_gemm_kernel_name(int epi, const GemmArgs &g);
 
+// Cross-check variants of single kernels (qv_debug_kernel_variant): the override if one is set, else the environment
+// variable (read once per process), else the default.  Variants of one kernel give identical bits unless stated.
+//   QV_KV_LOGMEL  (QVERSE_LOGMEL)   1 = FFT in registers, cross-lane strides over DPP / v_permlane*_swap (default);
+//                                   0 = Stockham FFT through LDS (the kernel of rounds 1-4)
+//   QV_KV_ORT_SUB (QVERSE_ORT_SUB)  precision 2's conv.0: 1 = f32 matrix pipe, four channel groups per block (default); 0 = VALU
+enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_COUNT = 8 };
+int qv_kernel_variant(int which);
+void qv_kernel_variant_set(int which, int mode);   // mode < 0: back to the environment / default
+
 // measurement hooks (bench.py roofline): per-launch HIP-event timing of the GEMMs
 void qv_gemm_prof_enable(bool on);
 void qv_gemm_prof_collect(double *ms, double *flops, int *n);

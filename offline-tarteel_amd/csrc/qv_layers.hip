@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include "qv_dev_util.h"
+#include "qv_logmel_reg.h"
 
 #include <math.h>
 
@@ -158,21 +159,7 @@ __device__ __forceinline__ void conv0_weights(const float *__restrict__ wt /*[9]
 #pragma unroll
     for (int r = 0; r < 16; ++r) bc[r] = bias[ch0 + (r & 3) + 8 * (r >> 2) + 4 * hi];
 }
-// the five B operands of one position: input rows r0 .. r0 + 2 (LDS row pitch QV_NMEL + 2, column f + 1), columns 2 f1 + kx.
-// koff[j] is the lane's offset of tap 2j + hi inside that 3 x 3 window (conv0_tap_offsets; the tenth tap reads the ninth's
-// sample against a zero weight), so the fetch is five plain LDS reads
-__device__ __forceinline__ void conv0_tap_offsets(int hi, int koff[5]) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int k = 2 * j + hi < 9 ? 2 * j + hi : 8;
-        koff[j] = (k / 3) * (QV_NMEL + 2) + k % 3;
-    }
-}
-__device__ __forceinline__ void conv0_taps(const float *rows, int r0, int f1, const int koff[5], float xb[5]) {
-    const float *base = rows + r0 * (QV_NMEL + 2) + 2 * f1;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) xb[j] = base[koff[j]];
-}
+// (conv0_tap_offsets / conv0_taps, the B operand fetch, live in qv_dev_util.h: precision 2's front end uses them too)
 __device__ __forceinline__ f32x16 conv0_tile(const float wa[5], const float bc[16], const float xb[5]) {
     f32x16 acc;
 #pragma unroll
@@ -1226,10 +1213,31 @@ __global__ __launch_bounds__(256) void k_zero_pad_rows(float *__restrict__ out, 
 
 // stats: [batch][80][2] results, followed by room for the [batch][MS_CHUNKS][80][2] partial sums (qv_melstats_doubles)
 size_t qv_melstats_doubles(size_t max_batch) { return max_batch * 2 * QV_NMEL * (1 + MS_CHUNKS); }
+static std::atomic<int> g_kernel_variant[QV_KV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+void qv_kernel_variant_set(int which, int mode) {
+    if (which >= 0 && which < QV_KV_COUNT) g_kernel_variant[which].store(mode < 0 ? -1 : mode);
+}
+int qv_kernel_variant(int which) {
+    static const struct Env { int v[QV_KV_COUNT]; Env() {
+        const char *names[QV_KV_COUNT] = {"QVERSE_LOGMEL", "QVERSE_ORT_SUB", nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const int dflt[QV_KV_COUNT] = {0, 1, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < QV_KV_COUNT; ++i) {
+            const char *e = names[i] ? getenv(names[i]) : nullptr;
+            v[i] = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : dflt[i];
+        }
+    } } env;
+    if (which < 0 || which >= QV_KV_COUNT) return 0;
+    const int o = g_kernel_variant[which].load();
+    return o < 0 ? env.v[which] : o;
+}
+
 void launch_logmel(const float *audio, int64_t n_max, const int32_t *n_samples, const FrontendTab &ft, float *feats,
                    int tm_max, double *stats, int batch, hipStream_t s) {
     double *part = stats + (size_t)batch * 2 * QV_NMEL;
-    hipLaunchKernelGGL(k_logmel, dim3((tm_max + 3) / 4, batch), dim3(256), 0, s, audio, n_max, n_samples, ft, feats, tm_max);
+    if (qv_kernel_variant(QV_KV_LOGMEL) == 1)
+        hipLaunchKernelGGL(lmv::k_logmel_reg<0>, dim3((tm_max + 3) / 4, batch), dim3(256), 0, s, audio, n_max, n_samples, ft, feats, tm_max);
+    else
+        hipLaunchKernelGGL(k_logmel, dim3((tm_max + 3) / 4, batch), dim3(256), 0, s, audio, n_max, n_samples, ft, feats, tm_max);
     hipLaunchKernelGGL(k_melstats, dim3(MS_CHUNKS, batch), dim3(320), 0, s, feats, n_samples, tm_max, part);
     hipLaunchKernelGGL(k_melstats_sum, dim3(batch), dim3(2 * QV_NMEL), 0, s, part, stats);
 }

@@ -393,6 +393,144 @@ __global__ __launch_bounds__(256) void k_sub01_ort(const float *__restrict__ fea
     block_fold(mm_c1 + QV_MM_STRIDE * b, mn, mx, s_fold);
 }
 
+// Round 5: conv.0 on the FLOAT32 matrix pipe, all four channel groups in one block (the re-landed form of the withdrawn
+// kernel above: tools/withdrawn/qv_ort_conv0_mfma.hip with PROBE_ABL=8192, which leaves a co-running k_logmel undisturbed
+// in tools/interference_probe -- tests/test_gpu_interference.py runs that probe).  [channels] x [9 taps] x [positions] as
+// five v_mfma_f32_32x32x2_f32 per 32 x 32 tile like k_sub01 (qv_layers.hip), on the integer-valued operands x_q - zp and
+// w_q: every product and partial sum is an integer below 2^24, so the instruction's internal summation order cannot
+// change a bit and the VALU kernel above stays the bit-exact cross-check (QVERSE_ORT_SUB=0 /
+// qv_debug_kernel_variant(1, 0); tests/test_gpu_ort_mixed.py compares the two and both with the oracle).
+// One block walks the four 64-channel groups over the same 19 quantised mel rows: with a block per group the per-block
+// fixed work (the f64 feature statistics, the quantisation of the rows, two barriers) was most of the kernel.
+#define SQ_NPOS (SQ_R1 * 40)     // conv.0 positions of a tile
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sub01_ort_mx(const float *__restrict__ feats, int tm_max, const int32_t *__restrict__ len_mel,
+                                                      const double *__restrict__ stats, const float *__restrict__ w0q, float w0_scale,
+                                                      const float *__restrict__ b0, const int32_t *__restrict__ len1,
+                                                      const float *__restrict__ w1q, float w1_scale, const float *__restrict__ b1,
+                                                      const int32_t *__restrict__ len2, const uint32_t *__restrict__ mm_mel,
+                                                      uint32_t *__restrict__ mm_c0, uint32_t *__restrict__ mm_c1,
+                                                      float *__restrict__ out, int t2_max) {
+    __shared__ float rows[SQ_RM][QV_NMEL + 2];
+    __shared__ float mean_s[QV_NMEL], rstd_s[QV_NMEL];
+    // tile[position][64 channels]: the 16-byte chunk c of a position sits at (c + position) & 7, so that the 32 positions
+    // of a wave store spread over the banks while the depthwise conv's 8 threads per position still read one contiguous 128 bytes
+    __shared__ __attribute__((aligned(16))) half_t tile[PASS == 1 ? SQ_NPOS : 1][SQ_CG];
+    __shared__ float s_fold[8];
+    const int b = blockIdx.z, t2_0 = blockIdx.y * SQ_TT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tin = len_mel[b], l1 = len1[b];
+    const float *x = feats + (size_t)b * tm_max * QV_NMEL;
+    if (tid < QV_NMEL) mel_mean_rstd(stats, b, tid, tin, mean_s[tid], rstd_s[tid]);
+    __syncthreads();
+    const QParam pm = dql_param(mm_mel + QV_MM_STRIDE * b);
+    const int t1_0 = 2 * t2_0 - 1;         // first conv.0 row of the tile
+    const int tm_0 = 2 * t1_0 - 1;         // first mel row
+    for (int i = tid; i < SQ_RM * (QV_NMEL + 2); i += 256) {
+        int r = i / (QV_NMEL + 2), f = i % (QV_NMEL + 2) - 1, t = tm_0 + r;
+        // frames past the utterance and the conv padding are real zeros = the zero point
+        rows[r][f + 1] = (t >= 0 && t < tin && f >= 0 && f < QV_NMEL) ? quant_c((x[t * QV_NMEL + f] - mean_s[f]) * rstd_s[f], pm) : 0.f;
+    }
+    const int l31 = lane & 31, hi = lane >> 5;
+    int koff[5];
+    conv0_tap_offsets(hi, koff);
+    const float s0 = pm.scale * w0_scale;
+    QParam p0 = {1.f, 0.f, 1.f};
+    if (PASS == 1) p0 = dql_param(mm_c0 + QV_MM_STRIDE * b);
+    const float s1 = p0.scale * w1_scale;
+    const int l2 = len2[b];
+    float mn = INFINITY, mx = -INFINITY;     // PASS 0: range of ReLU(conv.0); PASS 1: range of conv.2
+    __syncthreads();
+    for (int cg = 0; cg < QV_SUBC; cg += SQ_CG) {
+        // ---- conv.0 weights of this group's two 32-channel tiles as A operands: lane (l31 = channel, hi) holds tap 2j + hi
+        float wa[2][5];
+        f32x4 bia[2][4];                     // bias of the 16 channels this lane owns per tile: channel 8 q + 4 hi + e
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) wa[ct][j] = 2 * j + hi < 9 ? w0q[(2 * j + hi) * QV_SUBC + cg + ct * 32 + l31] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bia[ct][q] = *(const f32x4 *)(b0 + cg + ct * 32 + 8 * q + 4 * hi);
+        }
+        // ---- conv.0 + ReLU: 12 position tiles of 32 (360 positions), three per wave
+        for (int pt = wave; pt * 32 < SQ_NPOS; pt += 4) {
+            const int p = pt * 32 + l31;
+            const bool inside = p < SQ_NPOS;
+            const int pc = inside ? p : SQ_NPOS - 1;
+            const int r = pc / 40, f1 = pc - r * 40;
+            float xb[5];
+            conv0_taps(&rows[0][0], 2 * r, f1, koff, xb);
+            const int t1 = t1_0 + r;
+            const bool live = inside && t1 >= 0 && t1 < l1;    // rows outside [0, l1) are the depthwise conv's zero padding
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x16 acc = {};
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct][j], xb[j], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float yv = acc[4 * q + e] * s0 + bia[ct][q][e];
+                        yv = yv > 0.f ? yv : 0.f;
+                        if (PASS == 0) { if (live) { mn = fminf(mn, yv); mx = fmaxf(mx, yv); } }
+                        else o[e] = (half_t)(live ? quant_c(yv, p0) : 0.f);
+                    }
+                    if (PASS == 1 && inside) {
+                        const int c = ct * 4 + q;
+                        *(half4 *)&tile[p][(((c + p) & 7) << 3) + 4 * hi] = o;
+                    }
+                }
+            }
+        }
+        if (PASS == 0) continue;
+        const int c8 = (tid & 7) * 8, pl = tid >> 3;   // depthwise conv: 8 channels per thread, 32 positions per pass
+        float w[9][8], bs[8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            f32x4 wa4 = *(const f32x4 *)(w1q + k * QV_SUBC + cg + c8), wb4 = *(const f32x4 *)(w1q + k * QV_SUBC + cg + c8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { w[k][c] = wa4[c]; w[k][4 + c] = wb4[c]; }
+        }
+        {
+            f32x4 ba = *(const f32x4 *)(b1 + cg + c8), bb = *(const f32x4 *)(b1 + cg + c8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { bs[c] = ba[c]; bs[4 + c] = bb[c]; }
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 stride 2 over the tile
+        for (int p = pl; p < SQ_TT * 20; p += 32) {
+            int tl = p / 20, fo = p - tl * 20, t2 = t2_0 + tl;
+            if (t2 >= t2_max) continue;
+            float acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    int f = 2 * fo - 1 + df;
+                    if (f < 0 || f >= 40) continue;
+                    const int pos = (2 * tl + dt) * 40 + f;
+                    half8 v = *(const half8 *)&tile[pos][(((c8 >> 3) + pos) & 7) << 3];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(w[dt * 3 + df][c], (float)v[c], acc[c]);
+                }
+            float o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                o[c] = acc[c] * s1 + bs[c];
+                if (t2 < l2) { mn = fminf(mn, o[c]); mx = fmaxf(mx, o[c]); }
+            }
+            float *q = out + (((size_t)b * t2_max + t2) * 20 + fo) * QV_SUBC + cg + c8;
+            *(f32x4 *)q = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4 *)(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+        __syncthreads();                       // the tile is rewritten by the next channel group
+    }
+    block_fold((PASS == 0 ? mm_c0 : mm_c1) + QV_MM_STRIDE * b, mn, mx, s_fold);
+}
+
 // conv.5: depthwise Conv2d(256, 3x3, s2, p1) as ConvInteger on the quantised f32 input (channels-last); rows
 // t >= len_in[b] read as the zero point.  Same ownership as k_dwconv2d: 8 channels per thread.
 #define DWQ2_TT 4
@@ -498,10 +636,22 @@ void launch_mel_minmax(const float *feats, const int32_t *n_samples, int tm_max,
     hipLaunchKernelGGL(k_mel_minmax, dim3(MMQ_CHUNKS, batch), dim3(320), 0, s, feats, n_samples, tm_max, stats, mm);
 }
 
+static int ort_sub_variant() { return qv_kernel_variant(QV_KV_ORT_SUB); }
+
 void launch_sub01_ort(int pass, const float *feats, int tm_max, const int32_t *len_mel, const double *stats, const float *w0q,
                       float w0_scale, const float *b0, const int32_t *len1, const float *w1q, float w1_scale, const float *b1,
                       const int32_t *len2, const uint32_t *mm_mel, uint32_t *mm_c0, uint32_t *mm_c1, float *out, int t2_max,
                       int batch, hipStream_t s) {
+    if (ort_sub_variant() == 1) {     // conv.0 on the f32 matrix pipe, four channel groups per block
+        const dim3 g1(1, (t2_max + SQ_TT - 1) / SQ_TT, batch);
+        if (pass == 0)
+            hipLaunchKernelGGL((k_sub01_ort_mx<0>), g1, dim3(256), 0, s, feats, tm_max, len_mel, stats, w0q, w0_scale, b0, len1, w1q,
+                               w1_scale, b1, len2, mm_mel, mm_c0, mm_c1, out, t2_max);
+        else
+            hipLaunchKernelGGL((k_sub01_ort_mx<1>), g1, dim3(256), 0, s, feats, tm_max, len_mel, stats, w0q, w0_scale, b0, len1, w1q,
+                               w1_scale, b1, len2, mm_mel, mm_c0, mm_c1, out, t2_max);
+        return;
+    }
     const dim3 grid(QV_SUBC / SQ_CG, (t2_max + SQ_TT - 1) / SQ_TT, batch);
     if (pass == 0)
         hipLaunchKernelGGL((k_sub01_ort<0>), grid, dim3(256), 0, s, feats, tm_max, len_mel, stats, w0q, w0_scale, b0, len1, w1q,

@@ -125,6 +125,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_replay_kernel.argtypes = [vp, i32, C.c_char_p, i32]
     lib.qv_debug_gemm_tiles.argtypes = [i32]
     lib.qv_debug_attention_variant.argtypes = [i32]
+    lib.qv_debug_kernel_variant.argtypes = [i32, i32]
     lib.qv_weights_info.argtypes = [vp, C.c_char_p, i32]
     lib.qv_profile_inject_logprobs.argtypes = [vp, vp, i32, vp, i32]
     lib.qv_profile_stages.argtypes = [vp, i32]
@@ -381,6 +382,11 @@ class Engine:
         the single-pass kernel, longer ones key-tiled), 0 = key-tiled with two heads per block for every utterance,
         1 = one head per block, 2 = one wave per query tile (0..2: identical bits), -1 = environment / default."""
         self._check(self.lib.qv_debug_attention_variant(int(mode)), "qv_debug_attention_variant")
+
+    def kernel_variant(self, which: int, mode: int):
+        """process-wide variant of one kernel (qv_debug_kernel_variant): which 0 = log-mel FFT (0 LDS, 1 registers),
+        1 = precision 2's conv.0 (0 VALU, 1 f32 matrix pipe); -1 = environment / default.  Identical bits either way."""
+        self._check(self.lib.qv_debug_kernel_variant(int(which), int(mode)), "qv_debug_kernel_variant")
 
     def profile_gemm(self, enable: bool):
         self._check(self.lib.qv_profile_gemm(self.h, int(enable)), "qv_profile_gemm")

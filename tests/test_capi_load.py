@@ -178,6 +178,43 @@ def test_no_product_kernel_spills_or_uses_scratch(tmp_path):
     assert all(any(t in k for t in ("k_lcs_full", "k_frag", "k_spans", "k_track")) for k in sgpr), sgpr
 
 
+def test_library_has_no_packed_fp32_instructions(tmp_path):
+    """No v_pk_add/mul/fma_f32 in any product kernel outside the two GEMM translation units: round 5 traced the cross-kernel disturbance of k_logmel (DESIGN.md
+    section 4, tests/test_gpu_interference.py) to packed-FP32 instructions of the victim wave delivering wrong results in
+    lanes 48-63 while a wave of another kernel runs f16 MFMAs fed from LDS on the same SIMD; offline-tarteel_amd/build.py
+    switches them off in the code generator (scalar f32 operations give the same bits)."""
+    import re
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "llvm-objdump").exists():
+        import pytest
+
+        pytest.skip("ROCm llvm tools not present")
+    lib = Path(__file__).resolve().parent.parent / "offline-tarteel_amd" / "libqverse.so"
+    shutil.copy(lib, tmp_path / "libqverse.so")
+    subprocess.run([str(llvm / "llvm-objdump"), "--offloading", "libqverse.so"], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(tmp_path.glob("libqverse.so.*gfx950"))
+    assert objs, "no gfx950 code object found in libqverse.so"
+    n_insn, with_pk = 0, []
+    for o in objs:
+        dis = subprocess.run([str(llvm / "llvm-objdump"), "-d", "--no-show-raw-insn", str(o)], capture_output=True, text=True, check=True).stdout
+        n_insn += dis.count("v_mfma_") + dis.count("v_fma_f32")
+        kernel = None
+        for ln in dis.splitlines():
+            m = re.match(r"[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                kernel = m.group(1)
+            elif re.search(r"\bv_pk_(add|mul|fma)_f32\b", ln) and kernel not in with_pk:
+                with_pk.append(kernel)
+    assert n_insn > 1000, "disassembly looks empty"
+    # the GEMM kernels (qv_gemm.hip, qv_gemm256.hip: k_gemm<...>, k_gemm256<...>) are the documented exception
+    bad = [k for k in with_pk if "k_gemm" not in k]
+    assert not bad, bad[:8]
+
+
 def test_integration_md_stub_matches_the_abi():
     """INTEGRATION.md section 1 is the binding a maintainer would copy: its qv_config / qv_result structures must be
     field for field what offline-tarteel_amd/engine.py binds (which the GPU tests exercise against the library), and

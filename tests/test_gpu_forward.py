@@ -328,6 +328,38 @@ def test_fused_subsampling_equals_two_kernel_path(setup, monkeypatch):
         eng.close()
 
 
+def test_register_fft_logmel_equals_the_lds_kernel_bit_for_bit():
+    """QV_KV_LOGMEL 0 (Stockham FFT through LDS) against 1 (FFT in registers, csrc/qv_logmel_reg.h): the same butterflies on
+    the same operands in the same order, so the raw features and the log-probs are identical -- on clips whose frames
+    exercise every branch of the sample fetch (reflection at both ends, the shortest clip the engine accepts)."""
+    from offline_tarteel_amd.engine import Engine
+
+    os.environ["QVERSE_DEBUG_TAPS"] = "1"
+    lens = [80000, 400, 401, 560, 799, 1000, 30001, 4000]
+    audio = torch.from_numpy(synth_audio(len(lens), 80000))
+    for b, n in enumerate(lens):
+        audio[b, n:] = 0
+    dev = audio.cuda().contiguous()
+    tm = [n // 160 + 1 for n in lens]
+    eng = Engine(device=0, with_model=True, seed=SEED, max_batch=8, max_samples=80000)
+    try:
+        got = {}
+        for var in (0, 1):
+            eng.kernel_variant(0, var)
+            lp, t = eng.forward(dev, lens)
+            torch.cuda.synchronize()
+            got[var] = (eng.forward_tap(0, 0, (len(lens), max(tm), 80)).clone(), lp.clone(), t)
+        assert got[0][2] == got[1][2]
+        assert torch.equal(got[0][0], got[1][0])
+        for i, n in enumerate(got[0][2]):
+            assert torch.equal(got[0][1][i, :n], got[1][1][i, :n]), i
+        assert bool(torch.isfinite(got[1][0]).all())
+    finally:
+        eng.kernel_variant(0, -1)
+        eng.close()
+        os.environ.pop("QVERSE_DEBUG_TAPS", None)
+
+
 def _forward_with_variant(eng, audio, lens, variant):
     eng.attention_variant(variant)
     try:

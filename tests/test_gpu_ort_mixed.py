@@ -91,6 +91,28 @@ def test_frontend_integer_stages(setup):
         _report(f"conv.6[{b}]", c2p[b, : l3[b]], y[0].permute(1, 2, 0).half().float(), 1e-6)   # stored as f16 (feeds the int4 Linear)
 
 
+def test_conv0_on_the_matrix_pipe_equals_the_valu_kernel(setup):
+    """QV_KV_ORT_SUB 1 (five v_mfma_f32_32x32x2_f32 per tile on the integer-valued operands, four channel groups per block)
+    against 0 (VALU, a block per channel group): every sum is an exact integer, so conv.0 + conv.2's output, the ranges
+    folded for the next quantisers and therefore the log-probs are bit-identical."""
+    eng = setup["eng"]
+    l2 = setup["l2"]
+    dev = setup["audio"].cuda().contiguous()
+    got = {}
+    try:
+        for var in (0, 1):
+            eng.kernel_variant(1, var)
+            lp, t = eng.forward(dev, LENS)
+            torch.cuda.synchronize()
+            got[var] = (eng.forward_tap(6, 0, (len(LENS), max(l2), 20, 256)).clone(), lp.clone(), t)
+    finally:
+        eng.kernel_variant(1, -1)
+    assert got[0][2] == got[1][2] == setup["t"]
+    for b in range(len(LENS)):
+        assert torch.equal(got[0][0][b, : l2[b]], got[1][0][b, : l2[b]]), b
+        assert torch.equal(got[0][1][b, : setup["t"][b]], got[1][1][b, : setup["t"][b]]), b
+
+
 @pytest.mark.parametrize("layer", [0, 8, 16])
 def test_conv_module_stages(setup, layer):
     """norm_conv output -> pointwise_conv1 + GLU | -> depthwise_conv + BatchNorm + Swish, on the device's own inputs."""

@@ -8,12 +8,22 @@
 //         [-DPROBE_WITHDRAWN] tools/interference_probe.hip -o tools/interference_probe_{current,withdrawn}
 //   tools/interference_probe_withdrawn [iterations] [aggressor: 0 none, 1 range pass, 2 real pass, 3 both, 4 the f16 path's k_sub01,
 //                                                                   8 k_attention_short (64 x 126 frames), 16 k_attention_ws (64 x 376 frames)]
+//                                  [victim: 0 the shipped k_logmel (+ statistics), 1-3 simple kernels, 4-6 copies of k_logmel (see k_logmel_var),
+//                                   7 register FFT (logmel_variants.h), 10 one frame per block + __syncthreads(), 11 split re / im arrays,
+//                                   12 shipped kernel dumping Z and the power spectrum: per-frame attribution of the differences,
+//                                   13 the same with X and the register power value dumped too (five stages, lane quarters),
+//                                   14 / 15 / 16 the unpack without a square root / raw v_sqrt_f32 + 32 idle cycles / raw v_sqrt_f32,
+//                                   99 print what the DPP / permlane primitives do on this chip and exit]
+// Round 5: every run prints the device's identity (uuid, PCI bus, clocks as HIP reports them), checks that a variant
+// reproduces the shipped kernel bit for bit before anything else runs, and times the victim kernel alone.
 #include "../offline-tarteel_amd/csrc/qv_layers.hip"
 #ifdef PROBE_WITHDRAWN
 #include "withdrawn/qv_ort_conv0_mfma.hip"
 #else
 #include "../offline-tarteel_amd/csrc/qv_ort.hip"
 #endif
+
+#include "logmel_variants.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -131,6 +141,22 @@ __global__ __launch_bounds__(256) void k_victim(const float *__restrict__ x, flo
     }
 }
 
+// what the cross-lane primitives do (ground truth for the register FFT): out[i][lane]
+__global__ void k_lane_primitives(int *out) {
+    const int lane = threadIdx.x;
+    out[0 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x104, 0xf, 0xf, true);   // row_shl:4
+    out[1 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x114, 0xf, 0xf, true);   // row_shr:4
+    out[2 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x13C, 0xf, 0xf, true);   // wave_ror:1
+    out[3 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x134, 0xf, 0xf, true);   // wave_rol:1
+    out[4 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x140, 0xf, 0xf, true);   // row_mirror
+    out[5 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)lane, (unsigned)(lane + 100), false, false);
+    out[6 * 64 + lane] = (int)a[0]; out[7 * 64 + lane] = (int)a[1];
+    const auto c = __builtin_amdgcn_permlane32_swap((unsigned)lane, (unsigned)(lane + 100), false, false);
+    out[8 * 64 + lane] = (int)c[0]; out[9 * 64 + lane] = (int)c[1];
+    out[10 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x128, 0xf, 0xf, true);  // row_ror:8
+}
+
 template <class T> static T *dev(const std::vector<T> &h) {
     T *p = nullptr;
     if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return nullptr;
@@ -141,6 +167,29 @@ template <class T> static T *dev(const std::vector<T> &h) {
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 400, aggr = argc > 2 ? atoi(argv[2]) : 3, victim = argc > 3 ? atoi(argv[3]) : 0,
               wfrac = argc > 4 ? atoi(argv[4]) : 0;   // 1: the aggressor's conv.0 weights are fractions in (-1, 1) instead of integers
+    {
+        hipDeviceProp_t pr;
+        CK(hipGetDeviceProperties(&pr, 0));
+        printf("device %s uuid ", pr.gcnArchName);
+        for (int i = 0; i < 16; ++i) printf("%02x", (unsigned char)pr.uuid.bytes[i]);
+        printf(" pci %04x:%02x:%02x clock %d kHz mem clock %d kHz CUs %d\n", pr.pciDomainID, pr.pciBusID, pr.pciDeviceID, pr.clockRate,
+               pr.memoryClockRate, pr.multiProcessorCount);
+    }
+    if (victim == 99) {
+        int *d_o;
+        CK(hipMalloc(&d_o, 11 * 64 * 4));
+        hipLaunchKernelGGL(k_lane_primitives, dim3(1), dim3(64), 0, 0, d_o);
+        std::vector<int> h(11 * 64);
+        CK(hipMemcpy(h.data(), d_o, h.size() * 4, hipMemcpyDeviceToHost));
+        const char *nm[11] = {"row_shl:4", "row_shr:4", "wave_ror:1", "wave_rol:1", "row_mirror", "row_half_mirror", "permlane16_swap(lane, lane + 100) [0]",
+                              "permlane16_swap [1]", "permlane32_swap(lane, lane + 100) [0]", "permlane32_swap [1]", "row_ror:8"};
+        for (int i = 0; i < 11; ++i) {
+            printf("%-40s", nm[i]);
+            for (int l = 0; l < 64; ++l) printf(" %d", h[i * 64 + l]);
+            printf("\n");
+        }
+        return 0;
+    }
     const int B = 58;
     const int64_t n_max = 480000;
     srand(7);
@@ -201,8 +250,44 @@ int main(int argc, char **argv) {
     CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     // undisturbed reference + the aggressor's own inputs
     const size_t nv = 58ull * 3000 * 80;     // the other victims work on the first values of the audio, same output size
+    // victim 12: Z and the power spectrum of every frame, undisturbed (ref) and in the loop (v)
+    float2 *z_ref = nullptr, *z_v = nullptr;
+    float *p_ref = nullptr, *p_v = nullptr;
+    unsigned long long *d_cls = nullptr;
+    int *d_ex = nullptr;
+    const size_t frames = (size_t)B * tm_max;
+    float2 *x_ref = nullptr, *x_v = nullptr;
+    float *r_ref = nullptr, *r_v = nullptr;
+    if (victim == 13) {
+        CK(hipMalloc(&x_ref, frames * 264 * 8)); CK(hipMalloc(&x_v, frames * 264 * 8));
+        CK(hipMalloc(&r_ref, frames * 264 * 4)); CK(hipMalloc(&r_v, frames * 264 * 4));
+        CK(hipMemset(x_ref, 0, frames * 264 * 8)); CK(hipMemset(x_v, 0, frames * 264 * 8));
+        CK(hipMemset(r_ref, 0, frames * 264 * 4)); CK(hipMemset(r_v, 0, frames * 264 * 4));
+    }
+    if (victim == 12 || victim == 13) {
+        CK(hipMalloc(&z_ref, frames * 256 * 8)); CK(hipMalloc(&z_v, frames * 256 * 8));
+        CK(hipMalloc(&p_ref, frames * 264 * 4)); CK(hipMalloc(&p_v, frames * 264 * 4));
+        CK(hipMalloc(&d_cls, 32 * 8)); CK(hipMalloc(&d_ex, 16 * 6 * 4));
+        CK(hipMemset(z_ref, 0, frames * 256 * 8)); CK(hipMemset(z_v, 0, frames * 256 * 8));
+        CK(hipMemset(p_ref, 0, frames * 264 * 4)); CK(hipMemset(p_v, 0, frames * 264 * 4));
+        CK(hipMemset(d_cls, 0, 32 * 8)); CK(hipMemset(d_ex, 0, 16 * 6 * 4));
+    }
     auto run_victim = [&](float *out) {
+        const dim3 g4((tm_max + 3) / 4, B);
         if (victim == 0) launch_logmel(d_audio, n_max, d_n, ft, out, tm_max, stats_v, B, sv);
+        else if (victim == 7) hipLaunchKernelGGL(lmv::k_logmel_reg<0>, g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
+        else if (victim == 10) hipLaunchKernelGGL((lmv::k_logmel_lds<true, false, false>), dim3(tm_max, B), dim3(64), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr);
+        else if (victim == 11) hipLaunchKernelGGL((lmv::k_logmel_lds<false, true, false>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr);
+        else if (victim == 12) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, true>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max,
+                                                  out == feats_ref ? z_ref : z_v, out == feats_ref ? p_ref : p_v);
+        else if (victim == 13) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, true>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max,
+                                                  out == feats_ref ? z_ref : z_v, out == feats_ref ? p_ref : p_v, out == feats_ref ? x_ref : x_v,
+                                                  out == feats_ref ? r_ref : r_v);
+        else if (victim >= 14 && victim <= 16) {     // the unpack's square root: none / raw + 32 idle cycles / raw
+            if (victim == 14) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, false, 1>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr, (float2 *)nullptr, (float *)nullptr);
+            if (victim == 15) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, false, 2>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr, (float2 *)nullptr, (float *)nullptr);
+            if (victim == 16) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, false, 3>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr, (float2 *)nullptr, (float *)nullptr);
+        }
         else if (victim >= 4) {
             const dim3 g((tm_max + 3) / 4, B);
             if (victim == 4) hipLaunchKernelGGL(k_logmel_var<1>, g, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
@@ -218,6 +303,26 @@ int main(int argc, char **argv) {
     launch_logmel(d_audio, n_max, d_n, ft, feats_ref, tm_max, stats_v, B, sv);
     launch_logmel(d_audio, n_max, d_n, ft, feats_a, tm_max, stats_a, B, sv);
     CK(hipStreamSynchronize(sv));
+    if (victim >= 4 && !(victim >= 14 && victim <= 16)) {     // a copy of k_logmel has to reproduce the shipped kernel bit for bit (feats_a is the shipped kernel's output)
+        hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, sv, feats_ref, feats_a, nf, d_cnt);
+        CK(hipStreamSynchronize(sv));
+        unsigned long long c;
+        CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+        printf("victim %d against the shipped k_logmel, nothing else running: %llu differing values of %zu\n", victim, c, nf);
+        CK(hipMemset(d_cnt, 0, 8));
+    }
+    {   // the victim kernel alone: average of 20 launches
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        run_victim(feats_v);
+        CK(hipEventRecord(e0, sv));
+        for (int i = 0; i < 20; ++i) run_victim(feats_v);
+        CK(hipEventRecord(e1, sv));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("victim %d alone: %.1f us per launch (%d clips, %d frames max%s)\n", victim, ms * 50.f, B, tm_max, victim == 0 ? ", with the statistics kernels" : "");
+    }
     uint32_t *mm_mel = mm, *mm_c0 = mm + (size_t)B * QV_MM_STRIDE, *mm_c1 = mm + (size_t)2 * B * QV_MM_STRIDE;
     unsigned long long last = 0;
     int bad_iters = 0;
@@ -235,6 +340,10 @@ int main(int argc, char **argv) {
         }
         run_victim(feats_v);
         hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, sv, feats_v, feats_ref, nf, d_cnt);
+        if (victim == 12)
+            hipLaunchKernelGGL(lmv::k_classify, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, sv, z_v, z_ref, p_v, p_ref, feats_v, feats_ref, tm_max, frames, d_cls, d_ex);
+        if (victim == 13)
+            hipLaunchKernelGGL(lmv::k_classify5, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, sv, z_v, z_ref, x_v, x_ref, r_v, r_ref, p_v, p_ref, feats_v, feats_ref, frames, d_cls);
         if (it % 8 == 7 || it == iters - 1) {
             CK(hipStreamSynchronize(sv));
             unsigned long long c;
@@ -251,5 +360,29 @@ int main(int argc, char **argv) {
            "current",
 #endif
            aggr, victim, iters, B, tm_max, last, bad_iters, (iters + 7) / 8);
+    if (victim == 13) {
+        unsigned long long c[32];
+        CK(hipMemcpy(c, d_cls, sizeof c, hipMemcpyDeviceToHost));
+        const char *st[5] = {"FFT output Z", "X (real transform, before the magnitude)", "power value in registers", "power value read back from LDS", "features"};
+        for (int i = 0; i < 5; ++i)
+            printf("first differing stage %-45s %8llu frames; its differing values by lane quarter (0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu\n", st[i],
+                   c[i], c[8 + 4 * i], c[9 + 4 * i], c[10 + 4 * i], c[11 + 4 * i]);
+    }
+    if (victim == 12) {
+        unsigned long long c[32];
+        int ex[96];
+        CK(hipMemcpy(c, d_cls, sizeof c, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ex, d_ex, sizeof ex, hipMemcpyDeviceToHost));
+        printf("attribution: %llu frames differ; %llu already in the FFT output Z, %llu first in the power spectrum, %llu first in the features\n",
+               c[3], c[0], c[1], c[2]);
+        printf("  differing Z values per such frame (1, 2, 3-4, 5-8, ... 129-256):");
+        for (int i = 0; i < 9; ++i) printf(" %llu", c[4 + i]);
+        printf("\n  differing power bins per frame (1, 2, 3-4, 5-8, ...):");
+        for (int i = 0; i < 10; ++i) printf(" %llu", c[16 + i]);
+        printf("\n");
+        for (int i = 0; i < 16 && (unsigned long long)i < c[31]; ++i)
+            printf("  e.g. clip %d frame %d: %d Z values, %d power bins (first %d), %d features\n", ex[i * 6], ex[i * 6 + 1], ex[i * 6 + 2], ex[i * 6 + 3],
+                   ex[i * 6 + 5], ex[i * 6 + 4]);
+    }
     return 0;
 }
