@@ -624,9 +624,27 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     }
 }
 
+// (tools/gemm256q.h: a four-wave variant of this kernel, measured slower in round 5; only tools/gemm_bench compiles it)
+#ifdef QV_GEMM_Q_VARIANT
+#include QV_GEMM_Q_VARIANT
+#endif
+
 template <int EPI, int WQ>
 static void launch256(const GemmArgs &g, hipStream_t s) {
     constexpr int LDS = 2 * (256 * 64 * 2) * 2;   // two stages of f16 A + W tiles = 128 KB = the eight epilogue slices
+#ifdef QV_GEMM_Q_VARIANT
+    if constexpr (WQ != 88) {
+        if (gemm_q()) {
+            static bool opted_q = false;
+            if (!opted_q) {
+                (void)hipFuncSetAttribute((const void *)k_gemm256q<EPI, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                opted_q = true;
+            }
+            hipLaunchKernelGGL((k_gemm256q<EPI, WQ>), dim3(g.N / 256, (g.M + 255) / 256), dim3(256), LDS, s, g);
+            return;
+        }
+    }
+#endif
     static bool opted = false;
     if (!opted) {
         (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -111,6 +111,8 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);
 bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s);
 // tile policy of launch_gemm: 0 = 128-wide tiles only, 1 = 256 x 256 where the grid has >= 160 tiles (default), 2 = 256 x 256 wherever the shape allows; -1 = back to QVERSE_GEMM_T256 / the default
 void qv_gemm_set_t256(int mode);
+// tools/gemm_bench only (QV_GEMM_Q_VARIANT builds): 256 x 256 tiles with four waves of 128 x 128 (tools/gemm256q.h)
+void qv_gemm_set_q(int mode);
 // the kernel launch_gemm picks for this call, e.g. "k_gemm256<f16_swish>" / "k_gemm<resid,128>" (thread-local buffer)
 const char *qv_gemm_kernel_name(int epi, const GemmArgs &g);
 

@@ -1,7 +1,9 @@
 // gemm_bench.hip -- standalone timing + correctness harness for csrc/qv_gemm.hip (dev tool).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_bench.hip -o tools/gemm_bench
-//   tools/gemm_bench [iters] [M] [t256 mode: 0 = 128-wide tiles, 1 = default policy, 2 = 256 x 256 wherever N % 256 == 0]
+//   tools/gemm_bench [iters] [M] [t256 mode: 0 = 128-wide tiles, 1 = default policy, 2 = 256 x 256 wherever N % 256 == 0,
+//                                 3 = like 2 with the four-wave kernel k_gemm256q (128 x 128 per wave)]
 // Every shape the 256 x 256 kernel accepts is also compared BIT FOR BIT with the 128-wide kernel (all outputs).
+#define QV_GEMM_Q_VARIANT "../../tools/gemm256q.h"
 #include "../offline-tarteel_amd/csrc/qv_gemm.hip"
 #include "../offline-tarteel_amd/csrc/qv_gemm256.hip"
 
@@ -20,7 +22,9 @@ static float frand(uint64_t &s) {
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 50;
     const int M = argc > 2 ? atoi(argv[2]) : 8064;
-    const int mode = argc > 3 ? atoi(argv[3]) : 1;
+    const int mode_arg = argc > 3 ? atoi(argv[3]) : 1;
+    const int mode = mode_arg == 3 ? 2 : mode_arg;
+    qv_gemm_set_q(mode_arg == 3 ? 1 : 0);
     struct Sh { const char *name; int epi, N, K, ldo; float alpha; } shapes[] = {
         {"ff_up    swish N2048 K512 ", EPI_F16_SWISH, 2048, 512, 2048, 1.f},
         {"ff_down  resid N512 K2048 ", EPI_RESID, 512, 2048, 512, 0.5f},

@@ -111,6 +111,15 @@ ab_nopk)   # the library built without packed-FP32 instructions (offline-tarteel
     bench1 tta30_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --workload tta30 --steps 6 --warmup 2
   done
   ;;
+skip_ln)   # dev-hook library (offline-tarteel_amd/libqverse_dev.so, -DQV_DEV_HOOKS): what the stand-alone LayerNorm launches cost, i.e. the most a fusion could win
+  for rep in 1 2; do
+    for cfg in "b64_ctx4:--steps 60" "b64_ctx1:--steps 60 --contexts 1" "b256_ctx4:--batch 256 --steps 16" "b256_ctx1:--batch 256 --steps 16 --contexts 1"; do
+      n=${cfg%%:*}; a=${cfg#*:}
+      bench1 ${n}_base_$rep QVERSE_LIB=$R/offline-tarteel_amd/libqverse_dev.so -- $a
+      bench1 ${n}_skipln_$rep QVERSE_LIB=$R/offline-tarteel_amd/libqverse_dev.so QVERSE_SKIP=1 -- $a
+    done
+  done
+  ;;
 soak)
   for p in 0 1 2; do timeout 400 python tools/soak.py --batches ${SOAK_BATCHES:-3000} --seed $((11 + p)) --precision $p --third 2>&1 | filt; done > "$O/soak_three_precisions.log" 2>&1
   timeout 300 python tools/dev_ort_race.py --batches 400 2>&1 | filt | tail -3 >> "$O/soak_three_precisions.log"
