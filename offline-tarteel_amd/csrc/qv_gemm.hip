@@ -817,9 +817,12 @@ void qv_pack_w4(const float *w, int N, int K, uint8_t *q_out, half_t *scale_out)
 // The same device layout from a grid that is GIVEN (a weight file converted from the reference's quantised ONNX carries
 // MatMulNBits' own block scales and zero points, tools/convert_weights.py): w[n][k] = (q - zp[n][kb]) * scale[n][kb] holds
 // exactly in float32, so q = rint(w / scale + zp) returns the file's integer verbatim.  The device then multiplies by
-// half(scale) -- the file's float32 scale rounded once, 2.4e-4 relative at most -- and subtracts the file's zero point
+// half(scale) -- the file's float32 scale rounded once, 2^-11 = 4.9e-4 relative at most -- and subtracts the file's zero point
 // (asymmetric blocks included: the {scale, 1024 + zp} pair format always carried one).  Returns the number of elements
-// whose recovered q was not an integer in [0, 15] to 1e-3 (0 for a consistent file).
+// that cannot be represented this way (0 for a consistent file): a recovered q that is not an integer in [0, 15] to 1e-3,
+// and every element of a block whose zero point is not an integer in [0, 15] (half(1024 + zp) would round it) or whose
+// scale leaves the normal range of f16 (it would be flushed or overflow on the device).  The caller keeps the dequantised
+// f16 path for such a tensor (tools/convert_weights.py) instead of running it on a grid the file does not have.
 int64_t qv_pack_w4_given(const float *w, int N, int K, const float *scale, const float *zp, uint8_t *q_out, half_t *scale_out) {
     const int nk = K / 64, nkb = K / 128;
     int64_t bad = 0;
@@ -829,6 +832,8 @@ int64_t qv_pack_w4_given(const float *w, int N, int K, const float *scale, const
             const float sc = scale[(size_t)n * nkb + kb], z = zp[(size_t)n * nkb + kb];
             scale_out[((size_t)kb * N + n) * 2] = (half_t)sc;
             scale_out[((size_t)kb * N + n) * 2 + 1] = (half_t)(1024.f + z);
+            const float asc = fabsf(sc);
+            if (z != nearbyintf(z) || z < 0.f || z > 15.f || (sc != 0.f && (asc < 6.103515625e-05f || asc > 65504.f))) bad += 128;
             for (int k = 0; k < 128; ++k) {
                 const float t = sc != 0.f ? row[kb * 128 + k] / sc + z : z;
                 int q = (int)nearbyintf(t);

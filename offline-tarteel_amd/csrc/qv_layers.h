@@ -32,7 +32,8 @@ void launch_to_half(const float *x, half_t *y, size_t n, hipStream_t s);
 void launch_to_float(const half_t *x, float *y, size_t n, hipStream_t s);
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_min, int t_pad, int batch,
-                      hipStream_t s);
+                      hipStream_t s, int variant = -1);
+int qv_attention_variant();   // the process-wide variant as launch_attention would read it now
 // -1 environment / default (= 3); 0 two heads per block for every utterance, 1 one head per block, 2 one wave per query tile
 // (0..2 bit-identical); 3 = utterances of <= 128 frames on k_attention_short, longer ones as 0
 void qv_attention_set_variant(int mode);

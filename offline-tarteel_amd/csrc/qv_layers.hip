@@ -97,10 +97,9 @@ __global__ __launch_bounds__(256) void k_logmel(const float *__restrict__ audio,
 // while it loads its input rows, so the features make no extra round trip through HBM.
 // Each of the MS_CHUNKS blocks of an utterance writes its partial sums and k_melstats_sum adds them in chunk order.  (Until
 // round 4 the blocks added their partials to the result with f64 atomics, i.e. in whatever order they finished: the last
-// bit of a sum then depends on what else the GPU is running, and over a 30 s clip that flips the float32 rounding of a
-// feature's mean or 1 / std often enough to be seen -- 38 of 1,500 soak batches under QV_PREC_ORT_MIXED, whose quantisers
-// amplify a one-ulp feature column into a 1 % change of a score.  Found by the soak against a one-context engine while
-// other batches were in flight.)
+// bit of a sum then depends on what else the GPU is running.  This was the SECOND, independent source of run-to-run
+// differences found while chasing the 38-of-1,500 soak mismatches of round 4; the first and larger one was the packed-FP32
+// hazard in k_logmel's unpack step that round 5 pinned down -- build.py, tests/test_gpu_interference.py.)
 #define MS_CHUNKS 16
 __global__ __launch_bounds__(320) void k_melstats(const float *__restrict__ feats, const int32_t *__restrict__ n_samples,
                                                   int tm_max, double *__restrict__ part /*[B][MS_CHUNKS][80][2]*/) {
@@ -299,6 +298,9 @@ __global__ __launch_bounds__(256) void k_sub01(const float *__restrict__ feats, 
     // rows' latency (per channel group from global memory they were 72 load instructions per thread and a latency in
     // front of every group's matrix products)
     __shared__ __attribute__((aligned(16))) float w0s[10][QV_SUBC], w1s[10][QV_SUBC];
+    // ~73 KB of static LDS: gfx950 only (160 KB per CU, two blocks resident); every other target stops at 64 KB per block
+    static_assert(sizeof(rows) + sizeof(tile) + sizeof(w0s) + sizeof(w1s) + sizeof(mean_s) + sizeof(rstd_s) <= 80 * 1024,
+                  "k_sub01: two blocks per CU need <= 80 KB of LDS each");
     const int b = blockIdx.z, t2_0 = blockIdx.y * SUB_TT, tid = threadIdx.x;
     const int tin = len_mel[b], l1 = len1[b];
     const float *x = feats + (size_t)b * tm_max * QV_NMEL;
@@ -1220,7 +1222,7 @@ void qv_kernel_variant_set(int which, int mode) {
 int qv_kernel_variant(int which) {
     static const struct Env { int v[QV_KV_COUNT]; Env() {
         const char *names[QV_KV_COUNT] = {"QVERSE_LOGMEL", "QVERSE_ORT_SUB", nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        const int dflt[QV_KV_COUNT] = {0, 1, 0, 0, 0, 0, 0, 0};
+        const int dflt[QV_KV_COUNT] = {1, 1, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < QV_KV_COUNT; ++i) {
             const char *e = names[i] ? getenv(names[i]) : nullptr;
             v[i] = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : dflt[i];
@@ -1288,9 +1290,10 @@ void launch_to_float(const half_t *x, float *y, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
 }
 
-// Cross-check variants of the attention kernel (tests/test_gpu_forward.py), all bit-identical: 0 = two heads per block
-// (default), 1 = one head per block (3 K/V stages, 256-row ring), 2 = the one-wave-per-query-tile kernel the specialised
-// one replaced.  The environment (QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1) is read ONCE per process; tests switch with
+// Cross-check variants of the attention kernel (tests/test_gpu_forward.py): 3 = the default (an utterance of at most
+// ATT_SHORT_T frames on k_attention_short, a longer one key-tiled), 0 = key-tiled with two heads per block for every
+// utterance, 1 = one head per block (3 K/V stages, 256-row ring), 2 = the one-wave-per-query-tile kernel the specialised
+// one replaced; 0..2 are bit-identical.  The environment (QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1) is read ONCE per process; tests switch with
 // qv_debug_attention_variant() instead of setenv, which is not safe against launches from another thread.
 static std::atomic<int> g_att_variant{-1};
 void qv_attention_set_variant(int mode) { g_att_variant.store(mode); }
@@ -1305,10 +1308,14 @@ static int attention_variant() {
     return v < 0 ? env : v;
 }
 
+int qv_attention_variant() { return attention_variant(); }
+
 void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int pos_ld, const float *bu, const float *bv,
                       const int32_t *len, const int32_t *row_off, half_t *out, int t_max, int t_min, int t_pad, int batch,
-                      hipStream_t s) {
-    const int variant = attention_variant();
+                      hipStream_t s, int variant_in) {
+    // a forward pass passes the variant it read ONCE (qv_model.hip): a test that flips the process-wide switch while
+    // batches of other contexts are in flight cannot change kernels between the layers of one forward
+    const int variant = variant_in >= 0 ? variant_in : attention_variant();
     if (variant == 2) {
         hipLaunchKernelGGL(k_attention, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off, out, t_max,
                            t_pad);

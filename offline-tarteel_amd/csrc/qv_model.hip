@@ -338,7 +338,7 @@ int up_mat(qv_engine *eng, QvModel *m, const std::vector<float> &w, int N, int K
     std::vector<half_t> sc((size_t)N * (K / 128) * 2);
     if (grid) {
         const int64_t bad = qv_pack_w4_given(w.data(), N, K, gs->data(), gz->data(), q.data(), sc.data());
-        if (bad) { qv_set_error(eng, "pre-quantised weight file: a Linear weight does not sit on the int4 grid it declares"); return QV_ERR_IO; }
+        if (bad) { qv_set_error(eng, "pre-quantised weight file: a Linear weight does not sit on the int4 grid it declares (or a block has a non-integer zero point / a scale outside f16's normal range)"); return QV_ERR_IO; }
         ++m->prequant_w4_linears;
     } else
     qv_pack_w4(w.data(), N, K, q.data(), sc.data());
@@ -911,6 +911,7 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     if (m->save_taps) QV_HIP(hipMemcpyAsync(m->tap_x, m->x, sizeof(float) * (size_t)M * QV_D, hipMemcpyDeviceToDevice, s));
 
     if (!(skip & 1)) launch_layernorm(m->x, m->L[0].ln_g[0], m->L[0].ln_b[0], m->ln, M, s);
+    const int att_variant = qv_attention_variant();   // read once per forward: all 17 layers use the same kernel
     for (int l = 0; l < N_LAYERS; ++l) {
         const LayerW &L = m->L[l];
         auto gemm = [&](int epi, const half_t *A, int K, const WMat &W, const float *bias, void *out, int N, int ldo,
@@ -929,8 +930,8 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         if (!(skip & 1)) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         if (dup & 1) launch_layernorm(m->x, L.ln_g[1], L.ln_b[1], m->ln, M, s);
         gemm(EPI_QKV, m->ln, QV_D, L.qkv_w, L.qkv_b, m->qk, 3 * QV_D, 2 * QV_D, 1.f);
-        if (!(skip & 4)) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t3min, t_pad, B, s);
-        if (dup & 4) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t3min, t_pad, B, s);
+        if (!(skip & 4)) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t3min, t_pad, B, s, att_variant);
+        if (dup & 4) launch_attention(m->qk, m->vt, posp + (size_t)l * QV_D, N_LAYERS * QV_D, L.bias_u, L.bias_v, d_l3, d_off, m->att, T, t3min, t_pad, B, s, att_variant);
         gemm(EPI_RESID, m->att, QV_D, L.out_w, L.out_b, m->x, QV_D, QV_D, 1.f);
         // conv module
         if (m->ort) {

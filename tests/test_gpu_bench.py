@@ -64,6 +64,22 @@ def test_bench_under_torchrun_with_collective_path():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["batches_in_flight"] == 4
 
 
+def test_bench_tta30_under_torchrun_with_collective_path():
+    """configs[4]'s workload through the torch.distributed path (one rank, collective forced on): anchor pass, gate, the
+    GPU-resampled copies, the decision rule, then the combined rows packed on the host and all-gathered over RCCL on the
+    side stream (bench.py tta_done) -- the one multi-GPU path no test had executed."""
+    env = dict(os.environ, QVERSE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", str(ROOT / "bench.py"), "--gpus", "1",
+                        "--workload", "tta30", "--steps", "3", "--warmup", "1", "--batch", "4", "--seconds", "6",
+                        "--no-cpu-baseline", "--no-post-logits"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "TTA" in d["metric"]
+    assert d["config"]["tta_gated_fraction"] == 1.0 and d["config"]["batches_in_flight"] == 3
+
+
 _CTX_PROG = r"""
 import os, sys, json, time
 sys.path.insert(0, %r); sys.path.insert(0, %r)

@@ -235,3 +235,55 @@ def test_all_gather_results_gloo_world2(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
 
+
+
+_GLOO_TTA_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import offline_tarteel_amd
+from offline_tarteel_amd.dist import pack_results, unpack_results
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+B = 6
+gathered = torch.empty((world * B, 4), dtype=torch.int32)
+# what bench.py's tta_done() gathers per step (configs[4]): the rows of the TTA decision rule's result dicts -- clips the
+# gate let through keep their anchor result, gated clips carry the majority / best-score pick and a "tta" record, spans
+# have an ayah_end, an unrecognised clip is all zeros with ayah_end None
+def tta_results(r, step):
+    out = []
+    for i in range(B):
+        k = r * 100 + step * 10 + i
+        d = {"surah": k % 114 + 1, "ayah": k % 7 + 1, "ayah_end": (k % 7 + 3 if i % 3 == 0 else None), "score": 0.25 + 0.001 * k}
+        if i % 2:
+            d["tta"] = {"speeds": [0.9, 1.0, 1.1], "votes": 2}
+        if i == B - 1:
+            d = {"surah": 0, "ayah": 0, "ayah_end": None, "score": 0.0}
+        out.append(d)
+    return out
+for step in range(3):      # one gather per step, as in the bench loop
+    rows = torch.from_numpy(pack_results(tta_results(rank, step)))
+    dist.all_gather_into_tensor(gathered, rows)
+    got = unpack_results(gathered.numpy())
+    want = [d for r in range(world) for d in tta_results(r, step)]
+    assert len(got) == world * B
+    for g, w in zip(got, want):
+        assert (g["surah"], g["ayah"]) == (w["surah"], w["ayah"]), (g, w)
+        assert g["ayah_end"] == ((w["ayah_end"] or w["ayah"]) if w["surah"] else None), (g, w)
+        assert abs(g["score"] - np.float32(w["score"])) == 0.0, (g, w)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_tta_rows_all_gather_gloo_world2(tmp_path):
+    """configs[4]'s exchange (bench.py tta_done): the decision rule's combined rows, packed on the host, one all-gather per
+    step -- world size 2 on gloo; every rank must see every rank's rows in rank order, scores bit-exact."""
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_TTA_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script), str(ROOT)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2

@@ -120,6 +120,13 @@ skip_ln)   # dev-hook library (offline-tarteel_amd/libqverse_dev.so, -DQV_DEV_HO
     done
   done
   ;;
+ctx_sweep)
+  for c in 2 3 4 5 6 8; do bench1 b64_contexts$c X=0 -- --steps 60 --contexts $c; done
+  for c in 2 4 6 8; do bench1 b256_contexts$c X=0 -- --batch 256 --steps 16 --contexts $c; done
+  ;;
+hwq_sweep)
+  for q in 8 12 16; do for c in 4 6 8; do bench1 b64_hwq${q}_contexts$c GPU_MAX_HW_QUEUES=$q -- --steps 60 --contexts $c; done; done
+  ;;
 soak)
   for p in 0 1 2; do timeout 400 python tools/soak.py --batches ${SOAK_BATCHES:-3000} --seed $((11 + p)) --precision $p --third 2>&1 | filt; done > "$O/soak_three_precisions.log" 2>&1
   timeout 300 python tools/dev_ort_race.py --batches 400 2>&1 | filt | tail -3 >> "$O/soak_three_precisions.log"
