@@ -531,6 +531,24 @@ def main():
     if not tta and not use_dist:
         assert fetched["batches"] == args.steps and fetched["rows"] == B * args.steps, fetched   # every timed batch came back
 
+    # The driver's timed region is K = 20 steps (~73 ms): the same loop over a region two orders of magnitude longer, in
+    # the same process on the same engine, so that the short region's number is corroborated in the same output line
+    # (default line only: one GPU, configs[1]).
+    long_region = None
+    if (world == 1 and not tta and not use_dist and args.precision == "fp16" and B == 64 and args.seconds == 10.0
+            and not args.no_extra):
+        n_long = 2000
+        fetched["batches"] = fetched["rows"] = 0
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(n_long):
+            step()
+        sync_all()
+        dt_long = time.perf_counter() - t1
+        assert fetched["batches"] == n_long, fetched
+        long_region = {"steps": n_long, "ms_per_step": round(dt_long / n_long * 1e3, 3), "value": round(B * n_long / dt_long, 2),
+                       "unit": "utterances/s", "note": "same step() as the timed region, run after it"}
+
     # sanity: results come back and look like predictions
     res = eng.predict_batch(audio, lengths, want_text=False)
     if not os.environ.get("QVERSE_SKIP"):   # (timing experiments drop kernels: results are meaningless then)
@@ -695,7 +713,7 @@ def main():
                        "skip_unused_passes": not args.literal, "weights": args.precision, "weights_effective": weights_info,
                        "batches_in_flight": n_ctx, "engine_capacity_seconds": round(cap / 16000.0, 2),
                        "concurrent_streams_probe": int(eng.lib.qv_probe_concurrent_streams())},
-            "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "realistic_mix": mix, "extra": extra,
+            "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "realistic_mix": mix, "long_region": long_region, "extra": extra,
         }
         if tta:
             out["config"]["tta_gated_fraction"] = round(tta_stats["gated"] / max(1, tta_stats["clips"]), 3)

@@ -24,8 +24,8 @@ timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut 
 timeout 200 python tools/tracker_bench.py --cpu-texts 4 > "$O/tracker_bench.jsonl" 2>/dev/null; tail -n 2 "$O/tracker_bench.jsonl"
 timeout 300 python tools/ort_delta.py --seconds 10 --out "$O/ort_semantics_delta.json" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof3" -o p -- python "$R/bench.py" --steps 20 --no-cpu-baseline --no-post-logits > "$O/bench_under_rocprof.json" 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof1" -o p -- python "$R/bench.py" --steps 20 --contexts 1 --no-cpu-baseline --no-post-logits > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof3" -o p -- python "$R/bench.py" --steps 20 --no-cpu-baseline --no-post-logits --no-extra > "$O/bench_under_rocprof.json" 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof1" -o p -- python "$R/bench.py" --steps 20 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/profpost" -o p -- python "$R/tools/post_bench.py" --steps 5 > /dev/null 2>&1
 for prec in fp16 mixed ort; do   # B = 256 (configs[2] / the per-rank slice of configs[3]), one batch at a time: which kernels the step is made of
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b256_$prec" -o p -- python "$R/bench.py" --precision $prec --batch 256 --steps 8 --warmup 2 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
