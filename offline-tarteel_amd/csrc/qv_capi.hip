@@ -286,6 +286,20 @@ static int load_tables(qv_engine *eng, const char *path) {
             }
         }
     }
+    {
+        std::vector<uint8_t> c8;
+        std::vector<uint32_t> o8(N + 1);
+        for (int v = 0; v < N; ++v) {
+            o8[v] = (uint32_t)c8.size();
+            c8.push_back(0);
+            c8.insert(c8.end(), ctxt + coff[v], ctxt + coff[v + 1]);
+            while (c8.size() & 7) c8.push_back(0xFF);
+        }
+        o8[N] = (uint32_t)c8.size();
+        c8.resize(c8.size() + 64, 0xFF);
+        QV_TRY(upload(eng, c8.data(), c8.size(), &t.clean8));
+        QV_TRY(upload(eng, o8.data(), (size_t)N + 1, &t.clean8_off));
+    }
     cpad.resize(cpad.size() + 64, 0);
     QV_TRY(upload(eng, cpad.data(), cpad.size(), &t.clean));
     QV_TRY(upload(eng, cpo.data(), (size_t)N, &t.clean_off));

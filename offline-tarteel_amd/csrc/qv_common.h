@@ -53,6 +53,11 @@ struct QvTables {
     const uint32_t *clean_off;   // [N]
     const uint16_t *clean_len;   // [N]
     const uint16_t *nobsm_len;   // [N] 0 = none; text = last nobsm_len codes of clean[v]
+    // the same texts once more for the prefix-shared span pass (k_spans2): verse v is the block [clean8_off[v],
+    // clean8_off[v + 1]) = one ' ', its codes, then filler codes (0xFF: match nothing, leave the LCS recurrence alone) up
+    // to a multiple of 8 -- every ayah END falls on the end of an 8-code chunk.  Built at qv_create.
+    const uint8_t *clean8;
+    const uint32_t *clean8_off;  // [N+1], multiples of 8
     const uint8_t *alt;
     const uint32_t *alt_off;     // [N]
     const uint16_t *alt_len;     // [N]

@@ -121,7 +121,8 @@ const char *qv_gemm_kernel_name(int epi, const GemmArgs &g);
 //   QV_KV_LOGMEL  (QVERSE_LOGMEL)   1 = FFT in registers, cross-lane strides over DPP / v_permlane*_swap (default);
 //                                   0 = Stockham FFT through LDS (the kernel of rounds 1-4)
 //   QV_KV_ORT_SUB (QVERSE_ORT_SUB)  precision 2's conv.0: 1 = f32 matrix pipe, four channel groups per block (default); 0 = VALU
-enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_COUNT = 8 };
+//   QV_KV_SPANS   (QVERSE_SPANS)    match_verse's span pass: 1 = prefix-shared walk per start verse (k_spans2, default); 0 = one walk per span
+enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_SPANS = 2, QV_KV_COUNT = 8 };
 int qv_kernel_variant(int which);
 void qv_kernel_variant_set(int which, int mode);   // mode < 0: back to the environment / default
 

@@ -16,6 +16,7 @@
 // so scores are bit-identical to the reference's Python floats.
 
 #include "qv_common.h"
+#include "qv_kernels.h"   // qv_kernel_variant
 
 #include <math.h>
 
@@ -1130,6 +1131,191 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     }
 }
 
+// ---- k_spans2 (round 5): the span pass with PREFIX SHARING.  The spans that start at verse v0 -- 2, 3, .. max_span ayat --
+// are prefixes of one another, and the bit-parallel LCS state after n codes of a text IS the state of its n-code prefix:
+// one walk over the longest surviving span of a start verse, with the LCS read off at every ayah end on the way, replaces
+// (max_span - 1) walks of 2 + 3 + .. ayat (3.3 x fewer word-steps at max_span = 6).  The walk runs over tab.clean8, where
+// every verse is padded to whole 8-code chunks with codes that match nothing, so that an ayah end is a chunk end; a span
+// whose first verse loses its bismillah starts inside a chunk and masks the codes in front of it.  Same spans, same
+// exact bound, same scores and tie-break keys as k_spans (qv_debug_kernel_variant(2, 0) selects the old kernel;
+// tests/test_gpu_postlogits.py compares the two).
+struct SpanJob {
+    int v0, emax;              // start verse; longest span (in ayat) that survives the bound, 0 = none
+    unsigned surv;             // bit e: the span of e ayat survives
+    uint32_t start;            // its text in tab.clean
+    uint32_t a0;               // first chunk in tab.clean8 (multiple of 8)
+    int lead;                  // codes of that chunk in front of the text
+    double bonus;
+    unsigned long long key0;   // tie-break key of the span of 2 ayat (the span of e: key0 + e - 2)
+};
+
+// the pattern's words spread over G lanes as in lcs_systolic, but skewed by whole CHUNKS: at chunk-step t lane w runs the
+// 8 codes of chunk t - w with the 8 carries lane w - 1 produced for that chunk one step earlier (one DPP per chunk instead
+// of one per code; every lane is chunk-aligned, so "an ayah ends here" is one compare per chunk).  snap packs the lane's
+// zero counts at the ends of ayat 2 .. (7 bits each); all G lanes pass the same job.
+template <int G>
+__device__ __forceinline__ uint64_t lcs_systolic_chunks(const uint64_t *__restrict__ pm, int stride, const uint8_t *__restrict__ c8,
+                                                        const uint32_t *__restrict__ off8, const SpanJob &j, int m, int W, int w) {
+    uint64_t V = ~0ull, snap = 0;
+    unsigned cout8 = 0;
+    const bool act = w < W;
+    const int lo = w * 64;
+    const uint64_t zmask = !act ? 0ull : (m >= lo + 64 ? ~0ull : (m > lo ? ((1ull << (m - lo)) - 1ull) : 0ull));
+    const int nch = (int)(off8[j.v0 + j.emax] - j.a0) >> 3;
+    int e = 1, next_end = (int)(off8[j.v0 + 1] - j.a0) >> 3;       // chunks up to the end of ayah e
+    for (int t = 0; t < nch + G - 1; ++t) {
+        const int c = t - w;
+        unsigned cin8 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)cout8, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+        if (w == 0) cin8 = 0;
+        uint64_t chunk = ~0ull;                 // filler: matches nothing
+        if (c >= 0 && c < nch) chunk = *(const uint64_t *)(c8 + j.a0 + 8 * (size_t)c);
+        if (c == 0 && j.lead) chunk |= (1ull << (8 * j.lead)) - 1ull;
+        uint64_t mk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int code = (int)((chunk >> (8 * k)) & 0xFF);
+            const bool valid = act && code < QV_NSYM;
+            const uint64_t x = pm[(size_t)(valid ? code : 0) * stride + (act ? w : 0)];
+            mk[k] = valid ? x : 0ull;           // a zero mask leaves V alone and produces no carry
+        }
+        cout8 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned long long carry;
+            const uint64_t s2 = __builtin_addcll(V, V & mk[k], (unsigned long long)((cin8 >> k) & 1u), &carry);
+            V = s2 | (V & ~mk[k]);
+            cout8 |= (unsigned)carry << k;
+        }
+        if (c + 1 == next_end) {                // the ayah ends with this chunk (rare: <= max_span times per walk)
+            if (e >= 2) snap |= (uint64_t)__popcll(~V & zmask) << (7 * (e - 2));
+            ++e;
+            // (past the longest surviving span nothing is read off any more: the skewed lanes keep stepping for up to G - 1
+            // chunks after the walk's last one, and further ayah ends there must not shift into the fields above)
+            next_end = e <= j.emax ? (int)(off8[j.v0 + e] - j.a0) >> 3 : 0x7FFFFFFF;
+        }
+    }
+    return snap;
+}
+
+__global__ __launch_bounds__(256) void k_spans2(QvTables tab, QvWork wk, QvKnobs kn) {
+    __shared__ double sh_s[8];
+    __shared__ unsigned long long sh_k[8];
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
+    // pass 1's window scans are done, search()'s have not started: empty the fragment work list
+    if (blk == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
+    const QvUtt &u = wk.utt[b];
+    double best = -1.0;
+    unsigned long long bkey = ~0ull;
+    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
+    load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
+    if (u.q_len > 0) {
+        const int m = u.q_len, W = (m + 63) >> 6;
+        const uint64_t *pm = spm;
+        const int per = kn.max_span - 1;
+        // job space: one job per START verse of the surahs of the top 20; cum1 counts jobs, cumk the old kernel's
+        // (start, span) ranks that the tie-break keys are made of
+        int cum1[21];
+        cum1[0] = 0;
+#pragma unroll
+        for (int si = 0; si < 20; ++si) cum1[si + 1] = cum1[si] + (si < u.n_surah20 ? tab.surah_len[u.surah20[si] - 1] : 0);
+        const int total = cum1[20];
+        auto job = [&](int g, SpanJob &j) -> bool {
+            int si = 0, base = 0;
+#pragma unroll
+            for (int k = 1; k < 20; ++k)
+                if (g >= cum1[k]) { si = k; base = cum1[k]; }
+            const int s = u.surah20[si];
+            const int s0 = tab.surah_start[s - 1], sl = tab.surah_len[s - 1];
+            const int i = g - base;
+            j.v0 = s0 + i;
+            const int nl = tab.nobsm_len[j.v0];
+            const uint32_t skip = nl ? tab.clean_len[j.v0] - nl : 0;
+            j.start = tab.clean_off[j.v0] + skip;
+            j.bonus = 0.0;                        // of the span's first verse (quran_db.py:352-353)
+            for (int k = 0; k < u.hint_n; ++k)
+                if (j.v0 == u.hint_v[k]) j.bonus = u.hint_bonus[k];
+            j.surv = 0; j.emax = 0;
+            for (int e = 2; e <= kn.max_span && i + e <= sl; ++e) {
+                const int v1 = j.v0 + e - 1;
+                const int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - j.start);
+                const int mn = m < n ? m : n;
+                const double ub = __dadd_rn(ratio_from(mn, m, n), j.bonus);
+                if ((ub < 1.0 ? ub : 1.0) > u.best1_score) { j.surv |= 1u << e; j.emax = e; }
+            }
+            if (!j.emax) return false;
+            const uint32_t s8 = tab.clean8_off[j.v0] + 1 + skip;
+            j.a0 = s8 & ~7u;
+            j.lead = (int)(s8 - j.a0);
+            j.key0 = (unsigned long long)(base * per) + (unsigned long long)(i * per);
+            return true;
+        };
+        auto score = [&](int l, const SpanJob &j, int e) {
+            const int v1 = j.v0 + e - 1;
+            const int n = (int)(tab.clean_off[v1] + tab.clean_len[v1] - j.start);
+            const double raw = __dadd_rn(ratio_from(l, m, n), j.bonus);
+            const double sc = raw < 1.0 ? raw : 1.0;
+            const unsigned long long key = j.key0 + (unsigned long long)(e - 2);
+            if (better(sc, key, best, bkey)) { best = sc; bkey = key; }
+        };
+        if (W <= 2) {
+            // short transcripts: one start verse per lane
+            auto walk = [&](auto w_c) {
+                constexpr int WW = decltype(w_c)::value;
+                for (int g = blk * 256 + tid; g < total; g += nblk * 256) {
+                    SpanJob j;
+                    if (!job(g, j)) continue;
+                    uint64_t V[WW];
+#pragma unroll
+                    for (int k = 0; k < WW; ++k) V[k] = ~0ull;
+                    uint32_t pos = j.a0;
+                    uint64_t next = *(const uint64_t *)(tab.clean8 + pos);
+                    if (j.lead) next |= (1ull << (8 * j.lead)) - 1ull;
+                    for (int e = 1; e <= j.emax; ++e) {
+                        const uint32_t end = tab.clean8_off[j.v0 + e];
+                        for (; pos < end; pos += 8) {
+                            const uint64_t chunk = next;
+                            next = *(const uint64_t *)(tab.clean8 + pos + 8);       // (the array is padded by 64 filler codes)
+                            lcs_chunk<WW>(V, pm, QV_PMS, chunk, 8);
+                        }
+                        if (j.surv >> e & 1u) score(lcs_count<WW>(V, m), j, e);
+                    }
+                }
+            };
+            if (W <= 1) walk(std::integral_constant<int, 1>{});
+            else walk(std::integral_constant<int, 2>{});
+        } else {
+            // long transcripts: G lanes per start verse; every group first walks to its next job that survives the bound,
+            // so that the groups of a wave enter the recurrence together
+            auto run = [&](auto g_c) {
+                constexpr int G = decltype(g_c)::value;
+                const int w = tid & (G - 1), ngroups = nblk * (256 / G);
+                for (int g = blk * (256 / G) + tid / G; g < total; g += ngroups) {
+                    SpanJob j;
+                    bool ok = false;
+                    for (; g < total; g += ngroups)
+                        if ((ok = job(g, j))) break;
+                    if (!ok) break;
+                    uint64_t snap = lcs_systolic_chunks<G>(pm, QV_PMS, tab.clean8, tab.clean8_off, j, m, W, w);
+                    for (int e = 2; e <= j.emax; ++e) {
+                        int cnt = (int)((snap >> (7 * (e - 2))) & 0x7F);
+#pragma unroll
+                        for (int o = G / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+                        if (w == 0 && (j.surv >> e & 1u)) score(cnt, j, e);
+                    }
+                }
+            };
+            if (W <= 4) run(std::integral_constant<int, 4>{});
+            else if (W <= 8) run(std::integral_constant<int, 8>{});
+            else run(std::integral_constant<int, 16>{});
+        }
+    }
+    block_best(best, bkey, sh_s, sh_k);
+    if (tid == 0) {
+        wk.span_part_score[(size_t)b * QV_SPAN_BLOCKS + blk] = best;
+        wk.span_part_key[(size_t)b * QV_SPAN_BLOCKS + blk] = bkey;
+    }
+}
+
 __device__ void base_final_one(const QvTables &tab, const QvWork &wk, const QvKnobs &kn, int b, int force_ctc);
 
 // (Measured and rejected: folding this -- and the candidate assembly, and the final decision -- into the tail of the
@@ -1734,7 +1920,8 @@ static int launch_retrieval(qv_engine *eng, int batch, int force_ctc, hipStream_
     hipLaunchKernelGGL(k_frag, dim3(FRAG_GRID), dim3(256), 0, stream, tab, wk);
     size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
     hipLaunchKernelGGL(k_pass1_final, dim3(batch), dim3(256), sm_p1, stream, tab, wk, kn);
-    hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
+    if (qv_kernel_variant(QV_KV_SPANS) == 1) hipLaunchKernelGGL(k_spans2, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
+    else hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, batch), dim3(256), 0, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_base_final, dim3((batch + 63) / 64), dim3(64), 0, stream, tab, wk, kn, batch, force_ctc);
     // gate-failed utterances only (device-side list; blocks past n_fail exit at once)
     hipLaunchKernelGGL(k_lcs_full, dim3(batch, 74), dim3(256), 0, stream, tab, wk, 1);   // 3 jobs per verse: one round of 74 x 256 lanes
@@ -1924,7 +2111,8 @@ int qv_post_match_verse(qv_engine *eng, const uint8_t *codes_host, int n, int n_
     if (n_bonus > 0) hipLaunchKernelGGL(k_hint_sp, dim3(1), dim3(64), 0, stream, tab, wk, 0);
     size_t sm_p1 = (size_t)N * 8 + 128 * 8 + 128 * 4 + 272 * 4 + 128 * 4 + 128 * 8 + 64;
     hipLaunchKernelGGL(k_pass1_final, dim3(1), dim3(256), sm_p1, stream, tab, wk, kn);
-    hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, 1), dim3(256), 0, stream, tab, wk, kn);
+    if (qv_kernel_variant(QV_KV_SPANS) == 1) hipLaunchKernelGGL(k_spans2, dim3(QV_SPAN_BLOCKS, 1), dim3(256), 0, stream, tab, wk, kn);
+    else hipLaunchKernelGGL(k_spans, dim3(QV_SPAN_BLOCKS, 1), dim3(256), 0, stream, tab, wk, kn);
     hipLaunchKernelGGL(k_base_final, dim3(1), dim3(64), 0, stream, tab, wk, kn, 1, 0);
     QV_HIP(hipGetLastError());
     QV_HIP(hipStreamSynchronize(stream));

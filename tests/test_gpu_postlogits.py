@@ -283,6 +283,65 @@ def test_span_pass_with_the_pattern_spread_over_lanes(engine, oracle):
     assert {3, 4, 5, 8, 9, 16} <= seen_w, seen_w      # both ends of G = 4, 8 and 16
 
 
+def test_prefix_shared_span_pass_equals_one_walk_per_span(engine, oracle):
+    """k_spans2 (one walk per START verse over the 8-code-padded text, LCS read off at every ayah end: the default) against
+    k_spans (one walk per span): the same spans survive the same exact bound and score the same integers, so base match,
+    candidate list and scores are identical -- short transcripts (one start verse per lane) and long ones (4 / 8 / 16 lanes
+    per start verse, chunk-skewed), spans that start with a bismillah-less first verse included."""
+    import random
+
+    from oracle.oracle import normalize_arabic
+
+    rnd = random.Random(77)
+    texts = []
+    for v0, k in ((0, 3), (7, 4), (1, 6), (293, 2), (6225, 5), (6230, 6), (255, 3), (2000, 4), (4000, 6), (5000, 2)):
+        words = []
+        for d in range(k):
+            words += oracle.verse_text(v0 + d).split()
+        full = " ".join(words)
+        for cut in (40, 100, 127, 128, 129, 200, 400, 900):
+            out = [ch for ch in full[:cut] if rnd.random() > 0.06]
+            t = normalize_arabic(" ".join("".join(out).split())).strip()
+            if len(t) >= 12:
+                texts.append(t)
+    assert len({(len(t) + 63) // 64 for t in texts}) >= 5
+    try:
+        got = {}
+        for var in (0, 1):
+            engine.kernel_variant(2, var)
+            got[var] = [engine.debug_retrieve(t) for t in texts]
+    finally:
+        engine.kernel_variant(2, -1)
+    for t, a, c in zip(texts, got[0], got[1]):
+        assert (a["base_start"], a["base_span"], a["base_score"]) == (c["base_start"], c["base_span"], c["base_score"]), t
+        assert a["cand_start"].tolist() == c["cand_start"].tolist() and a["cand_span"].tolist() == c["cand_span"].tolist(), t
+        assert a["cand_score"].tolist() == c["cand_score"].tolist(), t
+    # and against the oracle for a few of them
+    for t, c in list(zip(texts, got[1]))[::7]:
+        cs, cp, sc, m = oracle.build_candidates(t)
+        assert (c["base_start"], c["base_span"], c["base_score"]) == (m.start, m.span, m.score), t
+
+
+def test_prefix_shared_span_pass_under_match_verse_with_spans_of_eight(engine, golden_dir):
+    """qv_match_verse (no trigram restriction, max_span = 8) on long low-confidence transcripts whose candidate starts sit in
+    runs of very short ayat (surah 74: two 8-code chunks per ayah): the skewed lanes of k_spans2 step past the end of the
+    walk and must not read further ayah ends into the snapshot fields (a first version did: 74:31-32 at score 1.0)."""
+    import json
+
+    cases = json.loads((golden_dir / "longtx_cases.json").read_text(encoding="utf-8"))
+    words = cases[1]["text"].split()
+    texts = [" ".join(words[:k]) for k in (40, 60, 90, 120, 150, 200, 259, len(words))] + [" ".join(cases[0]["text"].split()[:k]) for k in (50, 130, 220)]
+    try:
+        got = {}
+        for var in (0, 1):
+            engine.kernel_variant(2, var)
+            got[var] = [engine.match_verse(t, threshold=0.0, max_span=8) for t in texts]
+    finally:
+        engine.kernel_variant(2, -1)
+    assert got[0] == got[1]
+    assert all(g is not None and g["score"] < 1.0 for g in got[1][:8])
+
+
 def test_text_weight_fixtures(golden_dir):
     """CTC_DIRECT_TEXT_WEIGHT != 0 on the device: the reference's winner (and exp(-norm_loss) score) for weights 0.35 and
     2.0 -- one of the three recipes changes its winner between the two."""

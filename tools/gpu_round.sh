@@ -120,6 +120,13 @@ skip_ln)   # dev-hook library (offline-tarteel_amd/libqverse_dev.so, -DQV_DEV_HO
     done
   done
   ;;
+spans)   # the prefix-shared span pass: tests that exercise match_verse, then the post-logits replay with both kernels
+  timeout 900 python -m pytest tests/test_gpu_postlogits.py tests/test_gpu_tracker.py tests/test_gpu_tta.py -m gpu -x -q > "$O/spans_tests.log" 2>&1; tail -n 4 "$O/spans_tests.log"
+  for v in 0 1; do QVERSE_SPANS=$v timeout 200 python tools/post_bench.py > "$O/post_bench_spans$v.jsonl" 2>/dev/null; echo "QVERSE_SPANS=$v"; cut -c1-110 "$O/post_bench_spans$v.jsonl"; done
+  cd /tmp && export TMPDIR=/tmp
+  for v in 0 1; do QVERSE_SPANS=$v timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/profpost_spans$v" -o p -- python "$R/tools/post_bench.py" --steps 5 > /dev/null 2>&1; grep -i "k_spans" "$O/profpost_spans$v/p_kernel_stats.csv" | cut -c1-160; done
+  find "$O" -name "*_kernel_trace.csv" -delete; cd "$R"
+  ;;
 ctx_sweep)
   for c in 2 3 4 5 6 8; do bench1 b64_contexts$c X=0 -- --steps 60 --contexts $c; done
   for c in 2 4 6 8; do bench1 b256_contexts$c X=0 -- --batch 256 --steps 16 --contexts $c; done
