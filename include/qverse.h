@@ -308,8 +308,9 @@ int qv_debug_attention_variant(int32_t mode);
 /* Process-wide variant of a single kernel, for the tests that compare two implementations of one stage bit for bit
  * (-1 = back to the environment / default).  which 0 (QVERSE_LOGMEL): the log-mel kernel's 256-point FFT -- 0 = Stockham
  * through LDS, 1 = in registers with DPP / v_permlane*_swap exchanges; which 1 (QVERSE_ORT_SUB): conv.0 of
- * QV_PREC_ORT_MIXED's front end -- 0 = VALU, 1 = v_mfma_f32_32x32x2_f32 on the integer-valued operands.
- * Both variants of either kernel produce identical bits. */
+ * QV_PREC_ORT_MIXED's front end -- 0 = VALU, 1 = v_mfma_f32_32x32x2_f32 on the integer-valued operands; which 2
+ * (QVERSE_SPANS): match_verse's span pass -- 0 = one LCS walk per span, 1 = one walk per start verse with the count read
+ * off at every ayah end.  The variants of a kernel produce identical bits. */
 int qv_debug_kernel_variant(int32_t which, int32_t mode);
 
 /* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty
