@@ -53,13 +53,17 @@ def main():
         res = eng.decode_retrieve_rerank(lp, [T] * B)
         for _ in range(3):
             eng.decode_retrieve_rerank(lp, [T] * B, want_text=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.decode_retrieve_rerank(lp, [T] * B, want_text=False)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
+        regions = []
+        for _ in range(3):      # a region is ~60 ms of synchronous calls: one host hiccup doubles it (seen in round 5) -> median of three
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.decode_retrieve_rerank(lp, [T] * B, want_text=False)
+            torch.cuda.synchronize()
+            regions.append((time.perf_counter() - t0) / args.steps)
+        dt = sorted(regions)[1]
         row = {"case": name, "batch": B, "frames": T, "ms_per_batch": round(dt * 1e3, 3),
+               "regions_ms": [round(r * 1e3, 3) for r in regions],
                "gate_failed": sum(r["use_ctc"] for r in res),
                "mean_candidates": round(sum(r["n_candidates"] for r in res) / B, 1),
                "mean_transcript_chars": round(sum(len(r["transcript"]) for r in res) / B, 1)}
