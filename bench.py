@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default 10; 30 for --workload tta30)")
     ap.add_argument("--workload", choices=("clips", "tta30"), default="clips",
                     help="clips: the plain hot path; tta30: c2c-direct-mixed-tta on 30 s clips (configs[4])")
+    ap.add_argument("--tta-mix", action="store_true",
+                    help="tta30 only: the anchor pass's post-logits stages read verse-shaped log-probs at the reference's branch "
+                         "ratio (7 of its 53 v1 clips scored < 0.80; qv_profile_inject_logprobs), so that about one clip in eight "
+                         "fails the 0.5 TTA gate instead of every clip; the forward still runs on every clip")
     ap.add_argument("--no-post-logits", action="store_true", help="skip the verse-shaped post-logits replay legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
@@ -343,6 +347,8 @@ def extra_legs():
         "configs2_b256_ort_mixed": ["--precision", "ort", "--batch", "256", "--steps", "10", "--warmup", "3"],
         "configs2_b256_mixed_f16_operands": ["--precision", "mixed", "--batch", "256", "--steps", "10", "--warmup", "3"],
         "configs4_tta30_per_gpu": ["--workload", "tta30", "--steps", "5", "--warmup", "2"],
+        # ... and with the anchor pass gating clips at the reference's ratio instead of every clip (seeded random weights gate all)
+        "configs4_tta30_per_gpu_ref_gate_ratio": ["--workload", "tta30", "--tta-mix", "--steps", "8", "--warmup", "3"],
         # north_star quotes clips of 5-30 s: the short end, where a batch of 64 is half the rows of the headline batch, at
         # the headline's batch and at the batch that restores its row count (one call holds up to max_batch clips)
         "short_clips_5s_b64": ["--seconds", "5", "--steps", "30", "--warmup", "8"],
@@ -467,6 +473,25 @@ def main():
             (gather if use_dist else fetch)(pending.pop(0))
 
     tta_prev = []   # the previous step's TTA state while its perturbed batches are still in flight
+    tta_lp = None
+    if tta and args.tta_mix:
+        # anchor passes read verse-shaped log-probs: clean ones (text match >= 0.80, far above the 0.5 gate) and corrupted
+        # ones at the v1 golden run's 46 : 7 ratio (they go through search + CTC rerank and come back below 0.5)
+        import numpy as np
+
+        rng = np.random.default_rng(20260630)
+        n_fail = max(1, round(B * 7 / 53))
+        lps = verse_shaped_logprobs(eng, B - n_fail, t_frames, 1.0, 8.0, rng, 5000) + verse_shaped_logprobs(eng, n_fail, t_frames, 3.5, 4.0, rng, 9000)
+        tta_lp = torch.stack([lps[i] for i in rng.permutation(B)]).cuda(local_rank).contiguous()
+
+    def anchor_pass():
+        if tta_lp is None:
+            return eng.predict_batch_async(audio, lengths)
+        eng.inject_logprobs(tta_lp, [t_frames] * B)
+        try:
+            return eng.predict_batch_async(audio, lengths)
+        finally:
+            eng.inject_logprobs(None)      # the perturbed copies of the gated clips run on their own forward outputs
 
     def tta_done(st):
         from offline_tarteel_amd import dist as qdist
@@ -489,12 +514,13 @@ def main():
         from offline_tarteel_amd.plugin import tta_start
 
         if n_ctx >= 3:
-            ctx = eng.predict_batch_async(audio, lengths)
+            ctx = anchor_pass()
             if tta_prev:
                 tta_done(tta_prev.pop())
             tta_prev.append(tta_start(eng, audio, lengths, want_text=False, anchor_ctx=ctx))
         else:
-            tta_done(tta_start(eng, audio, lengths, want_text=False))
+            ctx = anchor_pass()
+            tta_done(tta_start(eng, audio, lengths, want_text=False, anchor_ctx=ctx))
 
     step = step_tta if tta else step_clips
 
@@ -687,7 +713,9 @@ def main():
             cfg_name = "BASELINE.json configs[4]" + ("" if world == 8 else f" workload on {world} GPU(s)")
             workload = (f"c2c-direct-mixed-tta hot path, batch={B}/GPU synthetic {args.seconds:g} s/16 kHz clips: anchor pass, "
                         "0.5 confidence gate, GPU 0.9x/1.1x speed-perturbed copies of the gated clips, majority / best-score "
-                        f"pick, {wdesc} ({cfg_name}); seeded random weights (real ONNX absent) gate every clip")
+                        f"pick, {wdesc} ({cfg_name}); " +
+                        ("anchor passes read verse-shaped log-probs at the v1 golden run's 46 : 7 branch ratio (--tta-mix), the forward runs on every clip"
+                         if args.tta_mix else "seeded random weights (real ONNX absent) gate every clip"))
         else:
             if not mixed and B == 64 and args.seconds == 10.0 and world < 8:
                 cfg_name = "BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU, {world} GPUs")

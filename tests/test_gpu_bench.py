@@ -53,6 +53,18 @@ def test_bench_tta30_workload_small():
     assert "configs[4]" in d["config"]["workload"] and d["config"]["batches_in_flight"] == 3
 
 
+def test_bench_tta30_with_the_reference_gate_ratio_small():
+    """--tta-mix: the anchor pass reads verse-shaped log-probs at the v1 run's 46 : 7 branch ratio, so only about one clip in
+    eight fails the 0.5 gate and gets its 0.9x / 1.1x copies (seeded random weights alone gate every clip)."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tta30", "--tta-mix", "--steps", "3", "--warmup", "1",
+                        "--batch", "16", "--seconds", "8", "--no-cpu-baseline", "--no-post-logits"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert "TTA" in d["metric"] and d["value"] > 0
+    assert 0.0 < d["config"]["tta_gated_fraction"] <= 0.25, d["config"]["tta_gated_fraction"]
+
+
 def test_bench_under_torchrun_with_collective_path():
     env = dict(os.environ, QVERSE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
