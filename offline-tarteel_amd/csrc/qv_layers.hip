@@ -430,7 +430,9 @@ __device__ __forceinline__ void ln_row(const float v[8], const float *__restrict
 
 // One wave normalises LN_ROWS consecutive rows: all their loads (and the parameters) are in flight
 // before the first reduction, and a wave lives for LN_ROWS rows instead of one.
+#ifndef LN_ROWS
 #define LN_ROWS 2
+#endif
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ gam,
                                                    const float *__restrict__ bet, half_t *__restrict__ y, int M) {
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;

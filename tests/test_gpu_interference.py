@@ -69,6 +69,16 @@ def test_shipped_logmel_is_undisturbed_by_the_shipped_precision2_front_end(probe
     assert diff == 0 and groups == 0, (diff, groups)
 
 
+@pytest.mark.parametrize("victim", [20, 21, 22, 23])
+def test_gemm_kernels_with_their_packed_fp32_epilogues_are_undisturbed(probes, victim):
+    """The two GEMM translation units keep packed-FP32 instructions (offline-tarteel_amd/build.py says why).  Victims 20-23 are
+    the FFN-up and the long-K GEMM on 256 x 256 and on 128-wide tiles, compiled as shipped (the `_pk` flavour), next to
+    the withdrawn aggressor: every output word must stay identical over 400 launches."""
+    for aggr in (1, 3):
+        diff, groups, _ = _run(probes["withdrawn_pk"], 400, aggr, victim)
+        assert diff == 0 and groups == 0, (victim, aggr, diff, groups)
+
+
 @pytest.mark.parametrize("victim", [6, 7, 10, 11])
 def test_logmel_variants_reproduce_the_shipped_kernel(probes, victim):
     """6 = a plain copy, 7 = FFT in registers (csrc/qv_logmel_reg.h), 10 = one frame per block with __syncthreads(),

@@ -127,6 +127,14 @@ spans)   # the prefix-shared span pass: tests that exercise match_verse, then th
   for v in 0 1; do QVERSE_SPANS=$v timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/profpost_spans$v" -o p -- python "$R/tools/post_bench.py" --steps 5 > /dev/null 2>&1; grep -i "k_spans" "$O/profpost_spans$v/p_kernel_stats.csv" | cut -c1-160; done
   find "$O" -name "*_kernel_trace.csv" -delete; cd "$R"
   ;;
+ab_lib)   # A/B of a second library build: AB_LIB=<file under offline-tarteel_amd/> tools/gpu_round.sh <tag> ab_lib
+  for rep in 1 2; do for lib in libqverse.so ${AB_LIB:?}; do
+    n=${lib%.so}_$rep
+    bench1 contexts1_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --steps 60 --contexts 1
+    bench1 headline_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --steps 60
+    bench1 b256_fp16_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --batch 256 --steps 16
+  done; done
+  ;;
 ctx_sweep)
   for c in 2 3 4 5 6 8; do bench1 b64_contexts$c X=0 -- --steps 60 --contexts $c; done
   for c in 2 4 6 8; do bench1 b256_contexts$c X=0 -- --batch 256 --steps 16 --contexts $c; done

@@ -13,6 +13,8 @@
 //                                   12 shipped kernel dumping Z and the power spectrum: per-frame attribution of the differences,
 //                                   13 the same with X and the register power value dumped too (five stages, lane quarters),
 //                                   14 / 15 / 16 the unpack without a square root / raw v_sqrt_f32 + 32 idle cycles / raw v_sqrt_f32,
+//                                   20 / 21 FFN-up GEMM [8064,512]x[512,2048]+Swish on 256 x 256 tiles / on 128-wide tiles, 22 / 23 the
+//                                   long-K GEMM [8064,2048]x[2048,512] (f32 out) on 256 x 256 / 128-wide tiles (outputs compared word by word),
 //                                   99 print what the DPP / permlane primitives do on this chip and exit]
 // Round 5: every run prints the device's identity (uuid, PCI bus, clocks as HIP reports them), checks that a variant
 // reproduces the shipped kernel bit for bit before anything else runs, and times the victim kernel alone.
@@ -24,6 +26,12 @@
 #endif
 
 #include "logmel_variants.h"
+// victims 20-23: the GEMM kernels (their two translation units keep packed-FP32 instructions in the product build; only the
+// `_pk` flavour of the probe compiles them as shipped)
+#define sigmoidf_ sigmoidf_gemm_tu_
+#include "../offline-tarteel_amd/csrc/qv_gemm.hip"
+#include "../offline-tarteel_amd/csrc/qv_gemm256.hip"
+#undef sigmoidf_
 
 #include <cstdio>
 #include <cstdlib>
@@ -272,8 +280,30 @@ int main(int argc, char **argv) {
         CK(hipMemset(p_ref, 0, frames * 264 * 4)); CK(hipMemset(p_v, 0, frames * 264 * 4));
         CK(hipMemset(d_cls, 0, 32 * 8)); CK(hipMemset(d_ex, 0, 16 * 6 * 4));
     }
+    // GEMM victims: operands of gemm_bench's kind, outputs into the feature buffers (13.9 M words >= 8064 x 2048 halves)
+    half_t *g_A = nullptr, *g_W = nullptr;
+    float *g_bias = nullptr;
+    if (victim >= 20 && victim <= 23) {
+        const int GM = 8064;
+        std::vector<half_t> hA((size_t)GM * 2048), hW((size_t)2048 * 2048);
+        uint32_t gs = 99;
+        for (auto &x : hA) { gs = gs * 1664525u + 1013904223u; x = (half_t)(((int)(gs >> 9) % 2001 - 1000) * 1e-3f); }
+        for (auto &x : hW) { gs = gs * 1664525u + 1013904223u; x = (half_t)(((int)(gs >> 9) % 2001 - 1000) * 5e-5f); }
+        std::vector<float> hb(4096);
+        for (auto &x : hb) { gs = gs * 1664525u + 1013904223u; x = ((int)(gs >> 9) % 2001 - 1000) * 1e-4f; }
+        g_A = dev(hA); g_W = dev(hW); g_bias = dev(hb);
+    }
+    auto run_gemm_victim = [&](float *out) {
+        GemmArgs g = {};
+        const bool up = victim <= 21;
+        g.A = g_A; g.W = g_W; g.bias = g_bias; g.out = out;
+        g.M = 8064; g.N = up ? 2048 : 512; g.K = up ? 512 : 2048; g.lda = g.K; g.ldw = g.K; g.ldo = g.N; g.alpha = 1.f;
+        qv_gemm_set_t256((victim & 1) ? 0 : 2);
+        launch_gemm(up ? EPI_F16_SWISH : EPI_F32, g, sv);
+    };
     auto run_victim = [&](float *out) {
         const dim3 g4((tm_max + 3) / 4, B);
+        if (victim >= 20 && victim <= 23) { run_gemm_victim(out); return; }
         if (victim == 0) launch_logmel(d_audio, n_max, d_n, ft, out, tm_max, stats_v, B, sv);
         else if (victim == 7) hipLaunchKernelGGL(lmv::k_logmel_reg<0>, g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
         else if (victim == 10) hipLaunchKernelGGL((lmv::k_logmel_lds<true, false, false>), dim3(tm_max, B), dim3(64), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr);
@@ -303,7 +333,7 @@ int main(int argc, char **argv) {
     launch_logmel(d_audio, n_max, d_n, ft, feats_ref, tm_max, stats_v, B, sv);
     launch_logmel(d_audio, n_max, d_n, ft, feats_a, tm_max, stats_a, B, sv);
     CK(hipStreamSynchronize(sv));
-    if (victim >= 4 && !(victim >= 14 && victim <= 16)) {     // a copy of k_logmel has to reproduce the shipped kernel bit for bit (feats_a is the shipped kernel's output)
+    if (victim >= 4 && !(victim >= 14 && victim <= 16) && victim < 20) {     // a copy of k_logmel has to reproduce the shipped kernel bit for bit (feats_a is the shipped kernel's output)
         hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, sv, feats_ref, feats_a, nf, d_cnt);
         CK(hipStreamSynchronize(sv));
         unsigned long long c;
