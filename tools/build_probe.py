@@ -22,7 +22,9 @@ DEPS = [Path(__file__).resolve(), ROOT / "offline-tarteel_amd" / "build.py", SRC
 
 
 def build(force: bool = False) -> list[Path]:
-    outs = []
+    from concurrent.futures import ThreadPoolExecutor
+
+    outs, jobs = [], []
     newest = max(d.stat().st_mtime for d in DEPS)
     # current / withdrawn are compiled like the product's non-GEMM translation units (offline-tarteel_amd/build.py: no packed-FP32 instructions);
     # withdrawn_pk is the positive control: the same translation unit with v_pk_add/mul/fma_f32 left on, i.e. the victims as
@@ -36,9 +38,17 @@ def build(force: bool = False) -> list[Path]:
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", str(ROOT / "offline-tarteel_amd" / "csrc"),
                "-I", str(ROOT / "include"), *(["-DPROBE_WITHDRAWN"] if flavour.startswith("withdrawn") else []),
                *([] if flavour.endswith("_pk") else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]), str(SRC), "-o", str(out)]
+        jobs.append((out, cmd))
+
+    def cc(job):
+        out, cmd = job
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {out.name}:\n{r.stderr[-4000:]}")
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(cc, jobs))
     return outs
 
 
