@@ -342,6 +342,18 @@ def test_prefix_shared_span_pass_under_match_verse_with_spans_of_eight(engine, g
     assert all(g is not None and g["score"] < 1.0 for g in got[1][:8])
 
 
+def test_span_pass_differential_fuzz_small():
+    """tools/fuzz_spans.py at a size that runs in seconds (the full runs: profiles/r05_l_fuzz_spans.log, 33,000 texts, 0
+    mismatches): k_spans2 against k_spans through the hot path's retrieval and through qv_match_verse (max_span 8, hints)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "tools" / "fuzz_spans.py"), "--n", "400", "--seed", "9"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "400 texts, 0 mismatches" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_text_weight_fixtures(golden_dir):
     """CTC_DIRECT_TEXT_WEIGHT != 0 on the device: the reference's winner (and exp(-norm_loss) score) for weights 0.35 and
     2.0 -- one of the three recipes changes its winner between the two."""
