@@ -435,7 +435,7 @@ __device__ __forceinline__ void ln_row(const float v[8], const float *__restrict
 #endif
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ gam,
                                                    const float *__restrict__ bet, half_t *__restrict__ y, int M) {
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;
+    const int row0 = (xcd_order(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;
     if (row0 >= M) return;
     f32x4 a[LN_ROWS], c[LN_ROWS];
 #pragma unroll
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 __global__ __launch_bounds__(256) void k_layernorm2(float *__restrict__ x, const float *__restrict__ g1, const float *__restrict__ b1,
                                                     const float *__restrict__ g2, const float *__restrict__ b2,
                                                     half_t *__restrict__ y, int M) {
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;
+    const int row0 = (xcd_order(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6)) * LN_ROWS, lane = threadIdx.x & 63;
     if (row0 >= M) return;
     f32x4 a[LN_ROWS], c[LN_ROWS];
 #pragma unroll
@@ -716,6 +716,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // The four skew slabs (34,304 B) reuse [0, 48 K) once every wave has its K / position products.
     __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
     half_t *sK = (half_t *)smem, *sP = (half_t *)(smem + 16 * 1024), *sV = (half_t *)(smem + 48 * 1024);
+    // (round 5: handing XCD k the k-th eighth of the (utterance, head) pairs -- xcd_order, as in the LayerNorms -- was
+    // measured: 16.46 -> 16.72 us; the kernel is not waiting for its K / V rows.  Kept head-major.)
     const int b = blockIdx.y, h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int T = len[b];
     if (T > ATT_SHORT_T) return;                // whole block: a long utterance belongs to k_attention_ws
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
     __shared__ __attribute__((aligned(16))) half_t sV[HPB][NST][64 * 32];    // [d][key], 16-B chunks swizzled by (d >> 2) & 3
     __shared__ __attribute__((aligned(16))) half_t sP[HPB][RING * 64];       // ring of position rows, swizzled like sK
     __shared__ float slab[4 * HPB][32 * ATT_LDS_LD];
-    const int b = blockIdx.z, qg = blockIdx.y;
+    const int b = blockIdx.z, qg = blockIdx.y, hg = blockIdx.x;
     const int T = len[b];
     if (qg * 128 >= T || T <= t_short) return;       // whole block: no query of this group exists / k_attention_short's utterance
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
             const int j0 = kt * 32, buf = kt % NST;
 #pragma unroll
             for (int hh = 0; hh < HPB; ++hh) {
-                const int h = blockIdx.x * HPB + hh;
+                const int h = hg * HPB + hh;
                 const half_t *kb = qk + row0 * (2 * QV_D) + QV_D + h * QV_DK;
                 const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;
                 {   // K: 8 keys x 128 B per wave
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
                 rr = rr < 0 ? 0 : (rr > 2 * t_max - 2 ? 2 * t_max - 2 : rr);
 #pragma unroll
                 for (int hh = 0; hh < HPB; ++hh)
-                    att_glds16(pos + (blockIdx.x * HPB + hh) * QV_DK + (size_t)rr * pos_ld + c * 8,
+                    att_glds16(pos + (hg * HPB + hh) * QV_DK + (size_t)rr * pos_ld + c * 8,
                                sP[hh] + (size_t)((first + q * 8) % RING) * 64);
             }
         };
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
     }
 
     // ---------------------------------------------------------------- consumers ----------
-    const int hh = wave >> 2, h = blockIdx.x * HPB + hh;
+    const int hh = wave >> 2, h = hg * HPB + hh;
     const int i0 = qg * 128 + w4 * 32;
     const bool active = i0 < T;
     const half_t *qb = qk + row0 * (2 * QV_D) + h * QV_DK;
@@ -1124,7 +1126,9 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
 __global__ __launch_bounds__(256) void k_dwconv1d(const half_t *__restrict__ x, const float *__restrict__ wt /*[9][512]*/,
                                                   const float *__restrict__ bias, const int32_t *__restrict__ len,
                                                   const int32_t *__restrict__ row_off, half_t *__restrict__ y) {
-    const int b = blockIdx.y, t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DW_TT, lane = threadIdx.x & 63;
+    // blocks in (utterance, frame chunk) order, XCD k takes the k-th eighth of them (xcd_order)
+    const int wg = xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = wg / gridDim.x, t0 = ((wg - b * gridDim.x) * 4 + (threadIdx.x >> 6)) * DW_TT, lane = threadIdx.x & 63;
     const int T = len[b], c0 = lane * 8;
     if (t0 >= T) return;
     const size_t row0 = (size_t)row_off[b];   // packed rows of utterance b

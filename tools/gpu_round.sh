@@ -128,7 +128,7 @@ spans)   # the prefix-shared span pass: tests that exercise match_verse, then th
   find "$O" -name "*_kernel_trace.csv" -delete; cd "$R"
   ;;
 ab_lib)   # A/B of a second library build: AB_LIB=<file under offline-tarteel_amd/> tools/gpu_round.sh <tag> ab_lib
-  for rep in 1 2; do for lib in libqverse.so ${AB_LIB:?}; do
+  for rep in 1 2 3; do for lib in libqverse.so ${AB_LIB:?}; do
     n=${lib%.so}_$rep
     bench1 contexts1_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --steps 60 --contexts 1
     bench1 headline_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --steps 60
