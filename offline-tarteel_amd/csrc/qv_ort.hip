@@ -54,7 +54,7 @@ __device__ __forceinline__ void rows_fold(uint32_t *mm_site, const int *s_utt, c
 __global__ __launch_bounds__(256) void k_quant_rows(const float *__restrict__ x, int rows, int C, const RowOwner own,
                                                     const uint32_t *__restrict__ mm, int8_t *__restrict__ y) {
     const int cpr = C >> 4;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t idx = (size_t)xcd_order(blockIdx.x, gridDim.x) * 256 + threadIdx.x;   // rows in XCD-affine order (qv_dev_util.h)
     if (idx >= (size_t)rows * cpr) return;
     const int row = (int)(idx / cpr), c = (int)(idx - (size_t)row * cpr) << 4;
     const QParam p = dql_param(mm + QV_MM_STRIDE * owner_utt(own, row));
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_ln_ort(const float *__restrict__ x, con
     __shared__ int s_utt[4 * LNQ_ROWS];
     __shared__ float s_mn[4 * LNQ_ROWS], s_mx[4 * LNQ_ROWS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + wave) * LNQ_ROWS;
+    const int row0 = (xcd_order(blockIdx.x, gridDim.x) * 4 + wave) * LNQ_ROWS;   // XCD-affine row order (qv_dev_util.h)
     f32x4 a[LNQ_ROWS], c[LNQ_ROWS];
 #pragma unroll
     for (int r = 0; r < LNQ_ROWS; ++r) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_rows_minmax(const float *__restrict__ x
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int r = 0; r < RMM_ROWS; ++r) {
-        const int row = (blockIdx.x * 4 + wave) * RMM_ROWS + r;
+        const int row = (xcd_order(blockIdx.x, gridDim.x) * 4 + wave) * RMM_ROWS + r;
         float mn = INFINITY, mx = -INFINITY;
         if (row < M) {
             const float *p = x + (size_t)row * QV_D + lane * 8;
@@ -176,9 +176,10 @@ __global__ __launch_bounds__(256) void k_dwconv1d_ort(const float *__restrict__ 
                                                       const int32_t *__restrict__ row_off, const uint32_t *__restrict__ mm_in,
                                                       uint32_t *__restrict__ mm_out, float *__restrict__ y) {
     __shared__ float s_fold[8];
-    const int b = blockIdx.y, t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DWQ_TT, lane = threadIdx.x & 63;
+    const int wg = xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // (utterance, chunk) order, XCD-affine
+    const int b = wg / gridDim.x, bx = wg - b * gridDim.x, t0 = (bx * 4 + (threadIdx.x >> 6)) * DWQ_TT, lane = threadIdx.x & 63;
     const int T = len[b], c0 = lane * 8;
-    if (blockIdx.x * 4 * DWQ_TT >= T) return;   // (whole block)
+    if (bx * 4 * DWQ_TT >= T) return;   // (whole block)
     const size_t row0 = (size_t)row_off[b];
     const QParam p = dql_param(mm_in + QV_MM_STRIDE * b);
     const float sxw = p.scale * w_scale;

@@ -8,7 +8,7 @@ for lib in ${LIBS:?}; do
   python - "$lib" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/ka/**/p_kernel_stats.csv", recursive=True)[0]
-want = ("k_layernormE", "k_layernorm2", "k_attention_short", "k_dwconv1d", "k_gemm256<1", "k_gemm256<6", "k_gemm<4", "k_gemm<3", "k_gemm256<4", "k_gemm256<3")
+want = ("k_quant_rows", "k_ln_ort", "k_rows_minmax", "k_dwconv1d_ort", "k_layernormE", "k_layernorm2", "k_attention_short", "k_dwconv1d", "k_gemm256<1", "k_gemm256<6", "k_gemm<4", "k_gemm<3", "k_gemm256<4", "k_gemm256<3")
 row = {}
 for r in csv.DictReader(open(f)):
     for w in want:
