@@ -23,7 +23,9 @@ namespace lmv {
 //   SPLIT: real and imaginary parts in separate arrays
 //   DUMP:  Z and the power spectrum also go to zdump [frame][256] / pdump [frame][264]
 //   UNP:   how the unpack step takes the magnitude: 0 sqrtf (shipped), 1 no square root at all (|X|^2 directly), 2 the raw
-//          v_sqrt_f32 followed by 32 idle cycles before its result is used, 3 the raw v_sqrt_f32 alone
+//          v_sqrt_f32 followed by 32 idle cycles before its result is used, 3 the raw v_sqrt_f32 alone, 4 sqrtf with the
+//          unpack arithmetic run for every lane (no divergent branch around it), 5 sqrtf, the shipped branch, 16 idle cycles
+//          in front of the EXEC write that closes it
 //   DUMP additionally writes X (the real transform's bins, before the magnitude) to xdump [frame][264] and the power value
 //   AS COMPUTED IN REGISTERS to rdump [frame][264] (pdump is what the next stage reads back from LDS)
 template <bool SYNC, bool SPLIT, bool DUMP, int UNP = 0>
@@ -78,6 +80,20 @@ __global__ __launch_bounds__(256) void k_logmel_lds(const float *__restrict__ au
     if (DUMP) for (int k = lane; k < 256; k += 64) zdump[frame * 256 + k] = ld(src, k);
     for (int k = lane; k < 257; k += 64) {
         float2 X;
+        if (UNP == 4) {
+            // the general formula for EVERY lane (bins 0 and 256 read Z[0] twice and are overwritten afterwards): the packed
+            // arithmetic runs under a full EXEC mask in the four full iterations
+            const int kk = k & 255;
+            float2 zk = ld(src, kk), zc = ld(src, (256 - kk) & 255);
+            float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+            float2 O = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+            float2 w = tw[kk];
+            float2 P = make_float2(__builtin_fmaf(w.x, O.x, -(w.y * O.y)), __builtin_fmaf(w.x, O.y, w.y * O.x));
+            X = make_float2(E.x + P.y, E.y - P.x);
+            const float2 z0 = ld(src, 0);
+            if (k == 0) X = make_float2(z0.x + z0.y, 0.f);
+            if (k == 256) X = make_float2(z0.x - z0.y, 0.f);
+        } else
         if (k == 0 || k == 256) {
             float2 z0 = ld(src, 0);
             X = make_float2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.f);
@@ -88,6 +104,14 @@ __global__ __launch_bounds__(256) void k_logmel_lds(const float *__restrict__ au
             float2 w = tw[k];
             float2 P = make_float2(__builtin_fmaf(w.x, O.x, -(w.y * O.y)), __builtin_fmaf(w.x, O.y, w.y * O.x));
             X = make_float2(E.x + P.y, E.y - P.x);
+            // UNP 5: the shipped branch structure, but 16 idle cycles between the branch's last (packed) operation and the
+            // scalar instruction that rewrites EXEC at the end of the branch
+            if (UNP == 5) {
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                f32x2_t xp = {X.x, X.y};
+                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(xp));
+                X = make_float2(xp[0], xp[1]);
+            }
         }
         const float m2 = X.x * X.x + X.y * X.y;
         float pv;
