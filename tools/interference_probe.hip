@@ -14,7 +14,7 @@
 //                                   13 the same with X and the register power value dumped too (five stages, lane quarters),
 //                                   14 / 15 / 16 the unpack without a square root / raw v_sqrt_f32 + 32 idle cycles / raw v_sqrt_f32,
 //                                   17 the unpack arithmetic for every lane (full EXEC mask in the full iterations), 18 the shipped branch with
-//                                   16 idle cycles in front of the EXEC write that closes it,
+//                                   16 idle cycles in front of the EXEC write that closes it, 19 the LDS reads in front of the branch and only the arithmetic inside,
 //                                   20 / 21 FFN-up GEMM [8064,512]x[512,2048]+Swish on 256 x 256 tiles / on 128-wide tiles, 22 / 23 the
 //                                   long-K GEMM [8064,2048]x[2048,512] (f32 out) on 256 x 256 / 128-wide tiles (outputs compared word by word),
 //                                   99 print what the DPP / permlane primitives do on this chip and exit]
@@ -315,6 +315,7 @@ int main(int argc, char **argv) {
         else if (victim == 13) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, true>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max,
                                                   out == feats_ref ? z_ref : z_v, out == feats_ref ? p_ref : p_v, out == feats_ref ? x_ref : x_v,
                                                   out == feats_ref ? r_ref : r_v);
+        else if (victim == 19) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, false, 6>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr, (float2 *)nullptr, (float *)nullptr);
         else if (victim == 18) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, false, 5>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr, (float2 *)nullptr, (float *)nullptr);
         else if (victim == 17) hipLaunchKernelGGL((lmv::k_logmel_lds<false, false, false, 4>), g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr, (float2 *)nullptr, (float *)nullptr);
         else if (victim >= 14 && victim <= 16) {     // the unpack's square root: none / raw + 32 idle cycles / raw

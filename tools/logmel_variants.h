@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256) void k_logmel_lds(const float *__restrict__ au
             const float2 z0 = ld(src, 0);
             if (k == 0) X = make_float2(z0.x + z0.y, 0.f);
             if (k == 256) X = make_float2(z0.x - z0.y, 0.f);
+        } else if (UNP == 6) {
+            // the LDS reads in front of the divergent region (pinned there), only the packed arithmetic inside it
+            const int kk = k & 255;
+            float2 zk = ld(src, kk), zc = ld(src, (256 - kk) & 255), w = tw[kk], z0 = ld(src, 0);
+            asm volatile("" : "+v"(zk.x), "+v"(zk.y), "+v"(zc.x), "+v"(zc.y), "+v"(w.x), "+v"(w.y), "+v"(z0.x), "+v"(z0.y));
+            if (k == 0 || k == 256) X = make_float2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.f);
+            else {
+                float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+                float2 O = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+                float2 P = make_float2(__builtin_fmaf(w.x, O.x, -(w.y * O.y)), __builtin_fmaf(w.x, O.y, w.y * O.x));
+                X = make_float2(E.x + P.y, E.y - P.x);
+            }
         } else
         if (k == 0 || k == 256) {
             float2 z0 = ld(src, 0);
