@@ -310,7 +310,9 @@ int qv_debug_attention_variant(int32_t mode);
  * through LDS, 1 = in registers with DPP / v_permlane*_swap exchanges; which 1 (QVERSE_ORT_SUB): conv.0 of
  * QV_PREC_ORT_MIXED's front end -- 0 = VALU, 1 = v_mfma_f32_32x32x2_f32 on the integer-valued operands; which 2
  * (QVERSE_SPANS): match_verse's span pass -- 0 = one LCS walk per span, 1 = one walk per start verse with the count read
- * off at every ayah end.  The variants of a kernel produce identical bits. */
+ * off at every ayah end; which 3 (QVERSE_FWD_GRAPH): the forward of an engine with more than one context -- 0 = plain
+ * launches, 1 = a shape that repeats on a context is captured once and replayed as one hipGraph launch.  The variants
+ * of a kernel produce identical bits. */
 int qv_debug_kernel_variant(int32_t which, int32_t mode);
 
 /* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty

@@ -723,7 +723,7 @@ extern "C" int qv_predict_batch_async(qv_engine *eng, const float *audio_dev, co
     }
     qv_stage_mark(eng, 0, run);
     int rc = qv_model_forward(eng, eng->model, audio_dev, lengths_host, batch, n_max, eng->logprobs_ws, t_max,
-                              t_out.data(), run);
+                              t_out.data(), run, /*zero_pad_rows=*/false, /*may_graph=*/eng->n_ctx > 1);
     if (rc) return rc;
     qv_stage_mark(eng, 1, run);
     if (eng->inject_lp) {

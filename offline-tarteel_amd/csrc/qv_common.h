@@ -195,7 +195,8 @@ int qv_model_create(qv_engine *eng, const qv_config *cfg, QvModel **out);
 void qv_model_destroy(QvModel *m);
 int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio_dev, const int64_t *len_host, int batch,
                      int64_t n_max, float *logprobs_dev, int t_max, int32_t *t_out_host, hipStream_t stream,
-                     bool zero_pad_rows = false);   // true: rows t >= T[b] of logprobs_dev are zeroed (the public qv_forward)
+                     bool zero_pad_rows = false,    // true: rows t >= T[b] of logprobs_dev are zeroed (the public qv_forward)
+                     bool may_graph = false);       // true: `stream` is one of the engine's own (capturable) context streams
 int qv_model_tap(qv_engine *eng, QvModel *m, int what, int layer, float *out_dev, hipStream_t stream);
 int qv_model_replay_gemm(qv_engine *eng, QvModel *m, int which, int iters, double *avg_us, double *flops, hipStream_t s);
 int qv_model_replay_kernel(qv_engine *eng, QvModel *m, int which, char *name_out, int cap);

@@ -882,6 +882,8 @@ struct GemmProf {
 } g_prof;
 }  // namespace
 
+bool qv_gemm_prof_on() { return g_prof.on; }
+
 void qv_gemm_prof_enable(bool on) {
     g_prof.on = on;
     g_prof.cls.clear();

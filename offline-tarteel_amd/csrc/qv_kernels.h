@@ -122,10 +122,13 @@ const char *qv_gemm_kernel_name(int epi, const GemmArgs &g);
 //                                   0 = Stockham FFT through LDS (the kernel of rounds 1-4)
 //   QV_KV_ORT_SUB (QVERSE_ORT_SUB)  precision 2's conv.0: 1 = f32 matrix pipe, four channel groups per block (default); 0 = VALU
 //   QV_KV_SPANS   (QVERSE_SPANS)    match_verse's span pass: 1 = prefix-shared walk per start verse (k_spans2, default); 0 = one walk per span
-enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_SPANS = 2, QV_KV_COUNT = 8 };
+//   QV_KV_FWD_GRAPH (QVERSE_FWD_GRAPH) multi-context engines: 1 = a forward whose shape repeats on a context is replayed as one hipGraph
+//                                   launch (default); 0 = always the plain launches
+enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_SPANS = 2, QV_KV_FWD_GRAPH = 3, QV_KV_COUNT = 8 };
 int qv_kernel_variant(int which);
 void qv_kernel_variant_set(int which, int mode);   // mode < 0: back to the environment / default
 
 // measurement hooks (bench.py roofline): per-launch HIP-event timing of the GEMMs
 void qv_gemm_prof_enable(bool on);
+bool qv_gemm_prof_on();   // per-launch event timing is active: the forward must issue real launches (no graph replay)
 void qv_gemm_prof_collect(double *ms, double *flops, int *n);

@@ -385,7 +385,8 @@ class Engine:
 
     def kernel_variant(self, which: int, mode: int):
         """process-wide variant of one kernel (qv_debug_kernel_variant): which 0 = log-mel FFT (0 LDS, 1 registers),
-        1 = precision 2's conv.0 (0 VALU, 1 f32 matrix pipe), 2 = span pass (0 one walk per span, 1 prefix-shared);
+        1 = precision 2's conv.0 (0 VALU, 1 f32 matrix pipe), 2 = span pass (0 one walk per span, 1 prefix-shared),
+        3 = forward of a multi-context engine (0 plain launches, 1 hipGraph replay of a repeating shape);
         -1 = environment / default.  Identical bits either way."""
         self._check(self.lib.qv_debug_kernel_variant(int(which), int(mode)), "qv_debug_kernel_variant")
 

@@ -607,3 +607,46 @@ def test_randomised_soak_of_batches_in_flight(precision):
     r = subprocess.run([sys.executable, str(root / "tools" / "soak.py"), "--batches", "250", "--seed", str(11 + precision),
                         "--precision", str(precision), "--third"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 mismatching batches" in r.stdout, (r.stdout[-1200:], r.stderr[-400:])
+
+
+def test_forward_graph_replay_equals_the_plain_launches():
+    """Multi-context engines replay a forward whose shape repeats on a context as ONE hipGraph launch (QV_KV_FWD_GRAPH,
+    qv_model.hip): the second run in a row of a shape captures it, later ones replay it.  Same kernels on the same
+    buffers, so every result row -- greedy ids, scores, CTC losses -- must equal the plain launches': with the lengths
+    permuted inside one captured shape (the kernels read them from device memory, not from the capture), with shapes
+    alternating, and after more shapes than a context keeps graphs for."""
+    from offline_tarteel_amd.engine import Engine
+
+    N = 80000
+    base = torch.from_numpy(synth_audio(8, N, seed=41))
+    lens_a = [80000, 64000, 48000, 80000, 32000, 56000, 72000, 40000]
+    lens_p = [64000, 80000, 80000, 48000, 56000, 32000, 40000, 72000]   # a permutation: same batch, rows, longest, shortest
+    cases = {"a": (base, lens_a), "p": (base.flip(0).contiguous(), lens_p)}
+    for nb in (1, 2, 3, 5, 6, 7):                                       # six more shapes (different batch sizes)
+        cases[f"b{nb}"] = (base[:nb].contiguous(), lens_a[:nb])
+    dev = torch.zeros(8, N, device="cuda")
+    eng = Engine(device=0, with_model=True, seed=SEED, max_batch=8, max_samples=N, contexts=2)
+
+    def run(name):
+        audio, lens = cases[name]
+        dev.zero_()
+        dev[: len(lens)].copy_(audio)
+        for b, n in enumerate(lens):
+            dev[b, n:] = 0
+        torch.cuda.synchronize()
+        return eng.predict_batch(dev[: len(lens)], lens, want_text=True)
+
+    try:
+        eng.kernel_variant(3, 0)
+        ref = {name: run(name) for name in cases}
+        assert ref["a"] != ref["p"]
+        eng.kernel_variant(3, 1)
+        order = ["a"] * 6 + ["p"] * 4 + ["a", "p"] * 3
+        for nb in (1, 2, 3, 5, 6, 7):
+            order += [f"b{nb}"] * 4                                     # 2 per context: the second one captures
+        order += ["a"] * 4 + ["b1", "p", "b7", "a", "a", "p", "p"]
+        for i, name in enumerate(order):
+            assert run(name) == ref[name], (i, name)
+    finally:
+        eng.kernel_variant(3, -1)
+        eng.close()

@@ -135,6 +135,17 @@ ab_lib)   # A/B of a second library build: AB_LIB=<file under offline-tarteel_am
     bench1 b256_fp16_$n QVERSE_LIB=$R/offline-tarteel_amd/$lib -- --batch 256 --steps 16
   done; done
   ;;
+fwd_graph)
+  timeout 600 python -m pytest tests/test_gpu_forward.py -x -q -m gpu -k "graph_replay" 2>&1 | tail -15
+  for rep in 1 2 3; do for g in 0 1; do bench1 headline_fwdgraph${g}_$rep QVERSE_FWD_GRAPH=$g -- --steps 60; done; done
+  bench1 ctx2_fwdgraph0 QVERSE_FWD_GRAPH=0 -- --steps 60 --contexts 2
+  bench1 ctx2_fwdgraph1 QVERSE_FWD_GRAPH=1 -- --steps 60 --contexts 2
+  bench1 ort_fwdgraph0 QVERSE_FWD_GRAPH=0 -- --steps 40 --precision ort
+  bench1 ort_fwdgraph1 QVERSE_FWD_GRAPH=1 -- --steps 40 --precision ort
+  ;;
+post_graph)
+  for rep in 1 2 3; do for g in 0 1; do bench1 headline_postgraph${g}_$rep QVERSE_POST_GRAPH=$g -- --steps 60; done; done
+  ;;
 ctx_sweep)
   for c in 2 3 4 5 6 8; do bench1 b64_contexts$c X=0 -- --steps 60 --contexts $c; done
   for c in 2 4 6 8; do bench1 b256_contexts$c X=0 -- --batch 256 --steps 16 --contexts $c; done
