@@ -542,12 +542,18 @@ def main():
 
     gc.collect()
     gc.disable()          # the timed region is tens of milliseconds of host-driven launches: no collector pause inside it
+    graph0 = eng.forward_graph_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     dt = time.perf_counter() - t0
     gc.enable()
+    graph1 = eng.forward_graph_stats()
+    # how the timed region's forwards were issued: as hipGraph replays (multi-context engines, shape seen before -- the
+    # warm-up captures it) or as ~300 plain launches each (single-context engines, QVERSE_FWD_GRAPH=0)
+    forward_graph = {"replays_in_timed_region": graph1["replays"] - graph0["replays"],
+                     "captures_in_timed_region": graph1["captures"] - graph0["captures"], "captures_before": graph0["captures"]}
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -739,7 +745,7 @@ def main():
                        "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
                        "skip_unused_passes": not args.literal, "weights": args.precision, "weights_effective": weights_info,
-                       "batches_in_flight": n_ctx, "engine_capacity_seconds": round(cap / 16000.0, 2),
+                       "batches_in_flight": n_ctx, "forward_graph": forward_graph, "engine_capacity_seconds": round(cap / 16000.0, 2),
                        "concurrent_streams_probe": int(eng.lib.qv_probe_concurrent_streams())},
             "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "realistic_mix": mix, "long_region": long_region, "extra": extra,
         }

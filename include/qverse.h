@@ -315,6 +315,10 @@ int qv_debug_attention_variant(int32_t mode);
  * of a kernel produce identical bits. */
 int qv_debug_kernel_variant(int32_t which, int32_t mode);
 
+/* How many forwards of this engine were replayed as a hipGraph launch, and how many graphs were captured, since creation
+ * (tests / bench.py: shows that the replay path -- and not the plain launches -- is what ran). */
+int qv_debug_forward_graph_stats(qv_engine *eng, int64_t *replays, int64_t *captures);
+
 /* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty
  * transcript, so the headline workload never sees a recitation the text match recognises.  While log-probs are injected,
  * qv_predict_batch_async() still runs the WHOLE forward pass on the audio it is given, but its post-logits stages read the

@@ -967,6 +967,13 @@ extern "C" int qv_debug_kernel_variant(int32_t which, int32_t mode) {
     return QV_OK;
 }
 
+extern "C" int qv_debug_forward_graph_stats(qv_engine *eng, int64_t *replays, int64_t *captures) {
+    QV_SERIALISE(eng);
+    if (!eng || !eng->model || !replays || !captures) return QV_ERR_ARG;
+    qv_model_graph_stats(eng->model, replays, captures);
+    return QV_OK;
+}
+
 extern "C" int qv_debug_gemm_tiles(int32_t mode) {
     if (mode < -1 || mode > 2) return QV_ERR_ARG;
     qv_gemm_set_t256(mode);

@@ -289,7 +289,9 @@ struct QvModel : QvActs {
     };
     struct FwdGraph { FwdKey key; hipGraphExec_t exec; } fwd_graph[QV_MAX_CTX][QV_FWD_GRAPHS];
     int n_fwd_graph[QV_MAX_CTX] = {}, fwd_evict[QV_MAX_CTX] = {};
-    FwdKey fwd_last[QV_MAX_CTX] = {};   // key of the context's previous forward: a shape is captured on its SECOND run in a row
+    FwdKey fwd_seen[QV_MAX_CTX][QV_FWD_GRAPHS] = {};   // keys of the context's last few uncaptured forwards: a shape is captured when it comes back
+    int fwd_seen_at[QV_MAX_CTX] = {};
+    int64_t fwd_replays = 0, fwd_captures = 0;   // graph launches / captures since creation (qv_debug_forward_graph_stats)
 };
 
 void qv_model_select_ctx(QvModel *m, int k) {
@@ -1022,8 +1024,11 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     // One graph launch for the whole forward when this context has already run a batch of exactly this shape from
     // these buffers (a serving loop over a fixed staging buffer with equal-length or equally-ragged batches): the
     // ~300 launches replay as one submission -- +1.2 % at four batches in flight, +2 % at two (profiles/r05_q_*).
-    // A shape is captured the second time in a row a context sees it, so a stream of ever-changing ragged batches
-    // never pays for a capture; the oldest of QV_FWD_GRAPHS graphs makes room.  Anything else -- caller streams
+    // A context captures the first QV_FWD_GRAPHS shapes it sees straight away (a serving loop is at full speed from its
+    // second batch); once those slots are taken, a new shape is captured only when it comes back within the context's
+    // last QV_FWD_GRAPHS uncaptured forwards (a loop over a few staging buffers, the three passes of the 30 s path) and
+    // the oldest graph makes room -- a stream of ever-changing ragged batches pays for QV_FWD_GRAPHS captures per
+    // context over its lifetime and no more.  Anything else -- caller streams
     // (single-context engines), debug taps, stage / GEMM profiling -- takes the plain launches.  QVERSE_FWD_GRAPH=0
     // (or qv_debug_kernel_variant(QV_KV_FWD_GRAPH, 0)) turns it off.
     if (qv_kernel_variant(QV_KV_FWD_GRAPH) == 1 && may_graph && !m->save_taps && !eng->profile_stages && !qv_gemm_prof_on()) {
@@ -1034,7 +1039,13 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
         QvModel::FwdGraph *hit = nullptr;
         for (int i = 0; i < m->n_fwd_graph[k]; ++i)
             if (m->fwd_graph[k][i].key == key) hit = &m->fwd_graph[k][i];
-        if (!hit && m->fwd_last[k] == key) {
+        bool seen = false;
+        for (const QvModel::FwdKey &o : m->fwd_seen[k]) seen = seen || o == key;
+        if (!hit && !seen) {
+            m->fwd_seen[k][m->fwd_seen_at[k]] = key;
+            m->fwd_seen_at[k] = (m->fwd_seen_at[k] + 1) % QV_FWD_GRAPHS;
+        }
+        if (!hit && (seen || m->n_fwd_graph[k] < QV_FWD_GRAPHS)) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             QV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1050,13 +1061,14 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             else {
                 slot = m->fwd_evict[k];
                 m->fwd_evict[k] = (slot + 1) % QV_FWD_GRAPHS;
-                (void)hipGraphExecDestroy(m->fwd_graph[k][slot].exec);   // (deferred by the runtime until a launch in flight has finished)
+                QV_HIP(hipStreamSynchronize(s));   // its last replay may still be queued on this stream (rare: a fifth repeating shape)
+                (void)hipGraphExecDestroy(m->fwd_graph[k][slot].exec);
             }
             m->fwd_graph[k][slot] = {key, exec};
+            m->fwd_captures++;
             hit = &m->fwd_graph[k][slot];
         }
-        m->fwd_last[k] = key;
-        if (hit) QV_HIP(hipGraphLaunch(hit->exec, s));
+        if (hit) { QV_HIP(hipGraphLaunch(hit->exec, s)); m->fwd_replays++; }
         else TRY(launch_all());
     } else {
         TRY(launch_all());
@@ -1097,6 +1109,11 @@ static int replay_args(qv_engine *eng, QvModel *m, int which, GemmArgs &a, int &
         a.mm_in = m->mm + (size_t)MM_LAYER(0) * m->max_batch * QV_MM_STRIDE; a.mm_out = (uint32_t *)a.mm_in + (size_t)m->max_batch * QV_MM_STRIDE;
     }
     return QV_OK;
+}
+
+void qv_model_graph_stats(const QvModel *m, int64_t *replays, int64_t *captures) {
+    *replays = m->fwd_replays;
+    *captures = m->fwd_captures;
 }
 
 void qv_model_weights_info(const QvModel *m, char *out, int cap) {

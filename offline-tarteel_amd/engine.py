@@ -126,6 +126,7 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_debug_gemm_tiles.argtypes = [i32]
     lib.qv_debug_attention_variant.argtypes = [i32]
     lib.qv_debug_kernel_variant.argtypes = [i32, i32]
+    lib.qv_debug_forward_graph_stats.argtypes = [vp, vp, vp]
     lib.qv_weights_info.argtypes = [vp, C.c_char_p, i32]
     lib.qv_profile_inject_logprobs.argtypes = [vp, vp, i32, vp, i32]
     lib.qv_profile_stages.argtypes = [vp, i32]
@@ -389,6 +390,12 @@ class Engine:
         3 = forward of a multi-context engine (0 plain launches, 1 hipGraph replay of a repeating shape);
         -1 = environment / default.  Identical bits either way."""
         self._check(self.lib.qv_debug_kernel_variant(int(which), int(mode)), "qv_debug_kernel_variant")
+
+    def forward_graph_stats(self) -> dict:
+        """forwards replayed as one hipGraph launch / graphs captured since the engine was created."""
+        r, c = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.qv_debug_forward_graph_stats(self.h, C.byref(r), C.byref(c)), "qv_debug_forward_graph_stats")
+        return {"replays": int(r.value), "captures": int(c.value)}
 
     def profile_gemm(self, enable: bool):
         self._check(self.lib.qv_profile_gemm(self.h, int(enable)), "qv_profile_gemm")

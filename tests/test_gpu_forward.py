@@ -611,7 +611,8 @@ def test_randomised_soak_of_batches_in_flight(precision):
 
 def test_forward_graph_replay_equals_the_plain_launches():
     """Multi-context engines replay a forward whose shape repeats on a context as ONE hipGraph launch (QV_KV_FWD_GRAPH,
-    qv_model.hip): the second run in a row of a shape captures it, later ones replay it.  Same kernels on the same
+    qv_model.hip): a context's first few shapes are captured as they arrive, later ones when they come back; runs of a
+    captured shape replay it.  Same kernels on the same
     buffers, so every result row -- greedy ids, scores, CTC losses -- must equal the plain launches': with the lengths
     permuted inside one captured shape (the kernels read them from device memory, not from the capture), with shapes
     alternating, and after more shapes than a context keeps graphs for."""
@@ -644,9 +645,13 @@ def test_forward_graph_replay_equals_the_plain_launches():
         order = ["a"] * 6 + ["p"] * 4 + ["a", "p"] * 3
         for nb in (1, 2, 3, 5, 6, 7):
             order += [f"b{nb}"] * 4                                     # 2 per context: the second one captures
-        order += ["a"] * 4 + ["b1", "p", "b7", "a", "a", "p", "p"]
+        order += ["a"] * 4 + ["b1", "p", "b7", "a", "a", "p", "p"] + ["b1", "b2", "b3"] * 5
+        assert eng.forward_graph_stats() == {"replays": 0, "captures": 0}
         for i, name in enumerate(order):
             assert run(name) == ref[name], (i, name)
+        st = eng.forward_graph_stats()
+        # 7 distinct keys ("a" and "p" share one), 4 graphs kept per context: captures beyond 2 x 7 are re-captures after eviction
+        assert st["captures"] >= 14 and st["replays"] >= len(order) // 2, st
     finally:
         eng.kernel_variant(3, -1)
         eng.close()

@@ -143,6 +143,11 @@ fwd_graph)
   bench1 ort_fwdgraph0 QVERSE_FWD_GRAPH=0 -- --steps 40 --precision ort
   bench1 ort_fwdgraph1 QVERSE_FWD_GRAPH=1 -- --steps 40 --precision ort
   ;;
+ctx_graph)
+  timeout 600 python -m pytest tests/test_gpu_forward.py -x -q -m gpu -k "graph_replay" 2>&1 | tail -3
+  for rep in 1 2 3; do for g in 0 1; do bench1 driver_cmd_fwdgraph${g}_$rep QVERSE_FWD_GRAPH=$g -- --gpus 1 --steps 20 --warmup 5; done; done
+  grep -o '"forward_graph": {[^}]*}' "$O"/bench_driver_cmd_fwdgraph*_1.json
+  ;;
 post_graph)
   for rep in 1 2 3; do for g in 0 1; do bench1 headline_postgraph${g}_$rep QVERSE_POST_GRAPH=$g -- --steps 60; done; done
   ;;
