@@ -559,6 +559,16 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     }
     if (hipSetDevice(cfg->device) != hipSuccess) { qv_set_error(eng, "hipSetDevice failed"); return fail(QV_ERR_HIP); }
     eng->device = cfg->device;
+    // The legacy default stream must own its hardware queue BEFORE the engine creates streams of its own.  A caller that
+    // enqueues from the default stream (torch's current stream unless told otherwise) has qv_predict_batch_async record
+    // an event there per batch; in a process whose first device work is this function, the runtime used to hand the
+    // default stream -- first used later, by the table upload below -- a queue one of the context streams ends up on as
+    // well, so that event sat behind ~300 queued kernels of an older batch and every new batch waited for it:
+    // 4.7-4.8 ms per batch of 64 x 10 s instead of 3.5 (profiles/r05_r_init_order.log; tools/sweep.py, which creates
+    // its engine first, under-reported every row since round 2).  One kernel on the default stream, before the probe
+    // below creates the process's first other streams, is what a process that touched the device earlier had anyway.
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, nullptr, 1LL);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { qv_set_error(eng, "default-stream warm-up kernel failed"); return fail(QV_ERR_HIP); }
     // four and more batches in flight only pay with a hardware queue per context stream (and one for the caller); when
     // the runtime runs fewer streams side by side than that -- GPU_MAX_HW_QUEUES unset or set after HIP initialised --
     // three contexts is the best measured setting (17.0 k utt/s on 4 or 8 queues; four contexts on 4 queues: 14.8 k)
