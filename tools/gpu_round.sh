@@ -167,6 +167,9 @@ suite)
   timeout 1500 python -m pytest tests -m gpu -x -q > "$O/gpu_tests.log" 2>&1; tail -n 3 "$O/gpu_tests.log"
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -n 1 "$O/smoke.log"
   ;;
+sweep)
+  timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; cut -c1-200 "$O/sweep.log" | tail -n 7
+  ;;
 final)
   bash tools/final_round.sh "$TAG"
   ;;

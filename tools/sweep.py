@@ -91,7 +91,7 @@ def main():
                  "note": "anchor + 0.9x + 1.1x passes of all 64 clips, 128 resampler launches per batch"})
     print(json.dumps(rows[-1]), flush=True)
     doc = {"what": "c2c-direct-mixed hot path, one MI355X, synthetic clips resident in HBM, whole path per batch",
-           "batches_in_flight": args.contexts, "weights": args.precision, "steps": args.steps, "rows": rows}
+           "batches_in_flight": eng.contexts, "weights": args.precision, "steps": args.steps, "rows": rows}
     if args.out:
         Path(args.out).write_text(json.dumps(doc, indent=1) + "\n")
     eng.close()
