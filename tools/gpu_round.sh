@@ -163,6 +163,10 @@ soak)
   timeout 300 python tools/dev_ort_race.py --batches 400 2>&1 | filt | tail -3 >> "$O/soak_three_precisions.log"
   cat "$O/soak_three_precisions.log"
   ;;
+soak_graph)   # keys repeat (7 recipes, 4 graph slots per context): the forward-graph replay / eviction path against a one-context engine
+  for p in ${SOAK_PRECISIONS:-0 2}; do timeout 200 python tools/soak.py --batches ${SOAK_BATCHES:-400} --seed $((21 + p + ${SOAK_BATCHES:-400})) --precision $p --recipes 7 2>&1 | filt; done > "$O/soak_graph_replay_${SOAK_BATCHES:-400}.log" 2>&1
+  cat "$O/soak_graph_replay_${SOAK_BATCHES:-400}.log"
+  ;;
 suite)
   timeout 1500 python -m pytest tests -m gpu -x -q > "$O/gpu_tests.log" 2>&1; tail -n 3 "$O/gpu_tests.log"
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -n 1 "$O/smoke.log"

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", type=int, default=0)
     ap.add_argument("--contexts", type=int, default=4)
+    ap.add_argument("--recipes", type=int, default=0,
+                    help="draw every batch from this many fixed (batch size, length multiset) recipes, each with its own staging buffer, "
+                         "lengths permuted and audio rotated per batch: the forward-graph replay path (keys repeat, more recipes than graph slots evict)")
     ap.add_argument("--third", action="store_true", help="a second one-context engine says which side of a mismatch is the odd one")
     args = ap.parse_args()
     import numpy as np
@@ -37,14 +40,28 @@ def main():
     e1b = Engine(device=0, with_model=True, seed=5, precision=args.precision, max_batch=64, max_samples=cap, contexts=1) if args.third else None
     key = lambda r: (r["surah"], r["ayah"], r["ayah_end"], r["source"], r["score"], r["t_frames"], r["n_candidates"])  # noqa: E731
     inflight, bad, t0, utts = [], 0, time.perf_counter(), 0
+    recipes = []
+    for _ in range(args.recipes):
+        B = int(rng.integers(2, 65))
+        hi = 160000 if rng.random() < 0.7 else cap
+        lens = [int(x) for x in rng.integers(800, hi + 1, size=B)]
+        recipes.append({"lens": lens, "buf": torch.zeros(B, max(lens), device="cuda")})
     try:
         for i in range(args.batches):
-            B = int(rng.integers(1, 65))
-            kind = rng.random()
-            hi = 16000 if kind < 0.2 else 160000 if kind < 0.8 else cap
-            lens = [int(x) for x in rng.integers(800, hi + 1, size=B)]
-            n = max(lens)
-            a = pool[:B, :n].contiguous()
+            if recipes:
+                busy = {id(x[1]) for x in inflight}
+                free = [r for r in recipes if id(r["buf"]) not in busy]      # a staging buffer is rewritten only once its batch has been joined
+                r = free[int(rng.integers(0, len(free)))]
+                lens = [r["lens"][j] for j in rng.permutation(len(r["lens"]))]
+                B, n, a = len(lens), max(lens), r["buf"]
+                a.copy_(pool.roll(int(rng.integers(0, 64)), 0)[:B, :n])
+            else:
+                B = int(rng.integers(1, 65))
+                kind = rng.random()
+                hi = 16000 if kind < 0.2 else 160000 if kind < 0.8 else cap
+                lens = [int(x) for x in rng.integers(800, hi + 1, size=B)]
+                n = max(lens)
+                a = pool[:B, :n].contiguous()
             for b, L in enumerate(lens):
                 a[b, L:] = 0
             ctx = e4.predict_batch_async(a, lens)
@@ -70,10 +87,12 @@ def main():
             want = [key(r) for r in e1.predict_batch(aa, ll, want_text=False)]
             bad += got != want
     finally:
+        graph = e4.forward_graph_stats()
         e4.close(); e1.close()
         if e1b is not None:
             e1b.close()
-    print(f"soak: {args.batches} ragged batches, {utts} utterances, {bad} mismatching batches, {time.perf_counter() - t0:.1f} s")
+    print(f"soak: {args.batches} ragged batches, {utts} utterances, {bad} mismatching batches, {time.perf_counter() - t0:.1f} s"
+          + (f"; {args.recipes} recipes" if args.recipes else "") + f"; forward graph of the multi-context engine: {graph}")
     return 1 if bad else 0
 
 
