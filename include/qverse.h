@@ -296,6 +296,11 @@ int qv_profile_replay_kernel(qv_engine *e, int32_t which, char *name_out, int32_
  * the shape allows, -1 = back to the environment (QVERSE_GEMM_T256) / default.  The tile shape never changes
  * a result: both kernels form the same products in the same accumulation order. */
 int qv_debug_gemm_tiles(int32_t mode);
+/* Tile HEIGHT of the 256-wide kernel: 0 = 256 rows always, 1 = the default (192-row tiles where they save a round of tiles
+ * over the 256 CUs and fewer than three batches are in flight), 2 = that rule whatever is in flight, 3 = 192 rows wherever
+ * the wide kernel runs, -1 = back to the environment (QVERSE_GEMM_BM) / default.  Same products, same accumulation order:
+ * the tile height never changes a result either.  Both switches bump an epoch that is part of the forward-graph key. */
+int qv_debug_gemm_tile_height(int32_t mode);
 /* Process-wide attention kernel variant, for the tests: 3 = the default: an utterance of at most 128 encoder frames
  * (10.2 s) is served by the single-pass short-utterance kernel, a longer one by the key-tiled kernel -- by its OWN length,
  * so the bits of an utterance never depend on the batch it travels in; 0 = the key-tiled kernel (two heads per block)
@@ -311,13 +316,17 @@ int qv_debug_attention_variant(int32_t mode);
  * QV_PREC_ORT_MIXED's front end -- 0 = VALU, 1 = v_mfma_f32_32x32x2_f32 on the integer-valued operands; which 2
  * (QVERSE_SPANS): match_verse's span pass -- 0 = one LCS walk per span, 1 = one walk per start verse with the count read
  * off at every ayah end; which 3 (QVERSE_FWD_GRAPH): the forward of an engine with more than one context -- 0 = plain
- * launches, 1 = a shape that repeats on a context is captured once and replayed as one hipGraph launch.  The variants
- * of a kernel produce identical bits. */
+ * launches, 1 = a shape that repeats on a context is captured once and replayed as one hipGraph launch; which 4
+ * (QVERSE_CTC): the alpha recursion of the CTC rerank -- 0 = the wave program of rounds 1-5, 1 = the parity-specialised
+ * one (two-term log-sum-exp for blank states).  The variants of a kernel produce identical bits. */
 int qv_debug_kernel_variant(int32_t which, int32_t mode);
 
 /* How many forwards of this engine were replayed as a hipGraph launch, and how many graphs were captured, since creation
  * (tests / bench.py: shows that the replay path -- and not the plain launches -- is what ran). */
 int qv_debug_forward_graph_stats(qv_engine *eng, int64_t *replays, int64_t *captures);
+/* Captures / graph instantiations that failed since creation (a capture-unsafe call of the host invalidated one, ...): the
+ * batch is then issued as plain launches and the context stops capturing -- never an error of the batch.  -1: no model. */
+int64_t qv_debug_forward_graph_failures(qv_engine *eng);
 
 /* Measurement hook for bench.py's `realistic_mix` leg.  Seeded random weights decode every synthetic clip to a near-empty
  * transcript, so the headline workload never sees a recitation the text match recognises.  While log-probs are injected,

@@ -62,6 +62,35 @@ def _read_wav(path: Path):
     return x.astype(np.float32), sr
 
 
+def probe_samples(path: str, sr: int = TARGET_SR) -> int:
+    """Length of a file in samples at ``sr`` WITHOUT decoding it (RIFF header walk): what the sharded runner sorts by
+    (dist.shard_plan).  Unknown containers fall back to the file size -- any monotone proxy of the duration will do."""
+    p = Path(path)
+    try:
+        with open(p, "rb") as f:
+            head = f.read(12)
+            if len(head) == 12 and head[:4] == b"RIFF" and head[8:12] == b"WAVE":
+                fmt = None
+                while True:
+                    ch = f.read(8)
+                    if len(ch) < 8:
+                        break
+                    cid, size = ch[:4], struct.unpack("<I", ch[4:8])[0]
+                    if cid == b"fmt ":
+                        body = f.read(size + (size & 1))
+                        _, nch, native, _, align, _ = struct.unpack("<HHIIHH", body[:16])
+                        fmt = (native, max(1, align))
+                    elif cid == b"data":
+                        if fmt:
+                            return int(size // fmt[1] * sr // max(1, fmt[0]))
+                        break
+                    else:
+                        f.seek(size + (size & 1), 1)
+        return int(p.stat().st_size)
+    except OSError:
+        return 0
+
+
 def resample(audio: np.ndarray, orig_sr: int, target_sr: int) -> np.ndarray:
     if orig_sr == target_sr:
         return audio.astype(np.float32)

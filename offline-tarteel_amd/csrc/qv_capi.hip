@@ -567,8 +567,21 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     // 4.7-4.8 ms per batch of 64 x 10 s instead of 3.5 (profiles/r05_r_init_order.log; tools/sweep.py, which creates
     // its engine first, under-reported every row since round 2).  One kernel on the default stream, before the probe
     // below creates the process's first other streams, is what a process that touched the device earlier had anyway.
-    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, nullptr, 1LL);
-    if (hipStreamSynchronize(nullptr) != hipSuccess) { qv_set_error(eng, "default-stream warm-up kernel failed"); return fail(QV_ERR_HIP); }
+    // (A host thread that is inside a stream capture must not touch the legacy stream -- it would invalidate the capture or
+    // be illegal in global mode -- so the warm-up is skipped then; such a host has used the device already.  The wait blocks
+    // on whatever the host queued on blocking streams before: INTEGRATION.md "Creating the engine".)
+    {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool capturing_ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;   // relaxed for the probe below
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const bool legacy_capturing = hipStreamIsCapturing(nullptr, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+        if (capturing_ok) (void)hipThreadExchangeStreamCaptureMode(&mode);                    // restore the host's mode
+        (void)hipGetLastError();
+        if (!legacy_capturing) {
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, nullptr, 1LL);
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { qv_set_error(eng, "default-stream warm-up kernel failed"); return fail(QV_ERR_HIP); }
+        }
+    }
     // four and more batches in flight only pay with a hardware queue per context stream (and one for the caller); when
     // the runtime runs fewer streams side by side than that -- GPU_MAX_HW_QUEUES unset or set after HIP initialised --
     // three contexts is the best measured setting (17.0 k utt/s on 4 or 8 queues; four contexts on 4 queues: 14.8 k)
@@ -984,9 +997,20 @@ extern "C" int qv_debug_forward_graph_stats(qv_engine *eng, int64_t *replays, in
     return QV_OK;
 }
 
+extern "C" int64_t qv_debug_forward_graph_failures(qv_engine *eng) {
+    QV_SERIALISE(eng);
+    return (eng && eng->model) ? qv_model_graph_failures(eng->model) : -1;
+}
+
 extern "C" int qv_debug_gemm_tiles(int32_t mode) {
     if (mode < -1 || mode > 2) return QV_ERR_ARG;
     qv_gemm_set_t256(mode);
+    return QV_OK;
+}
+
+extern "C" int qv_debug_gemm_tile_height(int32_t mode) {
+    if (mode < -1 || mode > 3) return QV_ERR_ARG;
+    qv_gemm_set_bm(mode);
     return QV_OK;
 }
 

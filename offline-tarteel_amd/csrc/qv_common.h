@@ -203,6 +203,7 @@ int qv_model_replay_kernel(qv_engine *eng, QvModel *m, int which, char *name_out
 
 void qv_model_weights_info(const QvModel *m, char *out, int cap);
 void qv_model_graph_stats(const QvModel *m, int64_t *replays, int64_t *captures);
+int64_t qv_model_graph_failures(const QvModel *m);   // captures / instantiations that failed (the context then runs plain launches)
 void qv_model_select_ctx(QvModel *m, int k);
 // records stage event `i` of the current context on `s` when stage profiling is on (qv_capi.hip)
 void qv_stage_mark(qv_engine *eng, int i, hipStream_t s);

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -953,11 +954,13 @@ static void launch_gemm_inner(int epi, const GemmArgs &g, hipStream_t s, bool na
     }
 }
 
-static int g_t256 = -1;
-void qv_gemm_set_t256(int mode) { g_t256 = mode; }
+static std::atomic<int> g_t256{-1}, g_bm{-1}, g_policy_epoch{0};
+void qv_gemm_set_t256(int mode) { g_t256.store(mode); g_policy_epoch.fetch_add(1); }
+void qv_gemm_set_bm(int mode) { g_bm.store(mode); g_policy_epoch.fetch_add(1); }
+int qv_gemm_policy_epoch() { return g_policy_epoch.load(); }
 
 namespace {
-struct GemmPlan { bool wide, narrow; int nst; };
+struct GemmPlan { bool wide, narrow; int nst, bm; };
 
 // Tile and pipeline choice (measured per shape, tools/gemm_bench.hip):
 //  * 256 x 256 tiles, one block per CU (qv_gemm256.hip), when N % 256 == 0 and the grid is large enough (see below:
@@ -981,8 +984,9 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
     if (p.narrow && p.nst > 3) p.nst = 3;
     if (env_nst >= 2 && env_nst <= (p.narrow ? 3 : 4)) p.nst = env_nst;
     if (env_ld == 1) p.nst = 0;
-    const int t256 = g_t256 >= 0 ? g_t256 : env_t256;
+    const int t256v = g_t256.load(), t256 = t256v >= 0 ? t256v : env_t256;
     p.wide = false;
+    p.bm = 256;
     if (t256 > 0 && g.N % 256 == 0 && g.bias && !(g.Wq && (g.K % 128 != 0 || g.K > 4096))) {
         const int tiles256 = (g.N / 256) * ((g.M + 255) / 256);
         // one batch at a time: a 256 x 256 grid must cover most of the chip (>= 160 tiles) or the 128-wide kernel's
@@ -996,6 +1000,18 @@ GemmPlan gemm_plan(int epi, const GemmArgs &g) {
         const int min_tiles = env_min > 0 ? env_min : g.in_flight >= 4 ? 1 : busy ? 128 : 160;
         const int min_tiles_longk = env_min_longk > 0 ? env_min_longk : busy ? 1 : 160;
         p.wide = t256 >= 2 || tiles256 >= (g.K >= 2048 ? min_tiles_longk : min_tiles);
+        // Tile height (round 6).  A 192-row tile moves 17 % more operand bytes per flop, so it is only worth its rounds:
+        // one batch at a time a GEMM takes ceil(tiles / 256 CUs) rounds of one tile time each (M = 24,064 = 64 clips x
+        // 30 s, N = 512: 188 tiles of 256 rows = one round with 68 CUs idle, 252 tiles of 192 rows = one round of 3/4 the
+        // length).  With three or more batches in flight the other batches' kernels take the idle CUs and CU time per
+        // GEMM is what counts (mode 2 applies the rule there too; tools/gemm_bench + bench.py measure both).
+        static const int env_bm = [] { const char *e = getenv("QVERSE_GEMM_BM"); return e ? atoi(e) : 1; }();
+        const int bmv = g_bm.load(), bm_mode = bmv >= 0 ? bmv : env_bm;
+        if (p.wide && bm_mode > 0) {
+            const long tiles192 = (long)(g.N / 256) * ((g.M + 191) / 192);
+            const long cost256 = ((tiles256 + 255) / 256) * 256, cost192 = ((tiles192 + 255) / 256) * 192;
+            if (bm_mode >= 3 || ((bm_mode == 2 || !busy) && cost192 * 108 <= cost256 * 100)) p.bm = 192;
+        }
     }
     return p;
 }
@@ -1006,8 +1022,8 @@ const char *qv_gemm_kernel_name(int epi, const GemmArgs &g) {
     static const char *EPI[8] = {"f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv", "f32_relu"};
     static thread_local char buf[64];
     const GemmPlan p = gemm_plan(epi, g);
-    if (g.Wi8) snprintf(buf, sizeof buf, p.wide ? "k_gemm256<%s,a8w8>" : "k_gemm<%s,128,a8w8>", EPI[epi]);
-    else if (p.wide) snprintf(buf, sizeof buf, "k_gemm256<%s>", EPI[epi]);
+    if (g.Wi8) snprintf(buf, sizeof buf, p.wide ? (p.bm == 192 ? "k_gemm256<%s,a8w8,192>" : "k_gemm256<%s,a8w8>") : "k_gemm<%s,128,a8w8>", EPI[epi]);
+    else if (p.wide) snprintf(buf, sizeof buf, p.bm == 192 ? "k_gemm256<%s,192>" : "k_gemm256<%s>", EPI[epi]);
     else snprintf(buf, sizeof buf, "k_gemm<%s,%d>", EPI[epi], p.narrow ? 64 : 128);
     return buf;
 }
@@ -1019,7 +1035,7 @@ void launch_gemm(int epi, const GemmArgs &g, hipStream_t s) {
     }
     const GemmPlan p = gemm_plan(epi, g);
     auto go = [&] {
-        if (p.wide && launch_gemm256(epi, g, s)) return;
+        if (p.wide && launch_gemm256(epi, g, s, p.bm)) return;
         launch_gemm_inner(epi, g, s, p.narrow, p.nst);
     };
     if (!g_prof.on) { go(); return; }

@@ -59,10 +59,14 @@ constexpr bool out_is_f32(int epi) { return epi == EPI_RESID || epi == EPI_F32; 
 // WQ: 0 = f16 weights, 4 = W4A16 (block-128 int4), 8 = W8A16 (per-channel int8), 88 = A8W8 (QV_PREC_ORT_MIXED: s8
 // activations x s8 weights on v_mfma_i32_32x32x32_i8 -- K counts byte pairs, so staging, LDS image and fragment reads are
 // the f16 kernel's unchanged; only the accumulator type and the epilogue differ); layouts in qv_kernels.h (GemmArgs)
-template <int EPI, int WQ>
+// MI: 32-row accumulator fragments per wave = tile height / 64: 4 = the 256 x 256 tile, 3 = a 192 x 256 tile (round 6).  The
+// shorter tile exists for the row counts whose 256-row grid leaves a quarter of the chip idle -- M = 24,064 (64 clips of
+// 30 s): 94 x 2 = 188 tiles of 256 rows on 256 CUs for every N = 512 GEMM, 126 x 2 = 252 tiles of 192 rows -- at 17 % more
+// operand bytes per flop.  Products and accumulation order per output element do not depend on MI: the bits are the same.
+template <int EPI, int WQ, int MI>
 __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     constexpr bool W4 = WQ == 4, W8 = WQ == 8, I8 = WQ == 88;
-    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int BM = 64 * MI, BN = 256, BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = W4 ? BN * BK / 2 : W8 ? BN * BK : BN * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int NBP = W4 ? 1 : W8 ? 2 : 4;   // 1 KB pieces of the W tile per wave per K-tile
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     typedef int i32x16 __attribute__((ext_vector_type(16)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef typename std::conditional<I8, i32x16, f32x16>::type acc_t;
-    acc_t acc[4][2];
+    acc_t acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -102,18 +106,22 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     const size_t bbytes = W4 ? (size_t)g.N * g.K / 2 : W8 ? (size_t)g.N * g.K : (size_t)g.N * g.ldw * 2;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, (int)bbytes, 0x00020000);
     constexpr int stepB = W4 ? 2048 : W8 ? 4096 : BK * 2;   // bytes between consecutive K-tiles of a W piece
-    unsigned offA[4], offB[NBP];
-    int dst[4], dstB[NBP];
+    unsigned offA[MI], offB[NBP];
+    int dst[MI], dstB[NBP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = wave * 32 + q * 8 + (lane >> 3), c = lane & 7;
+    for (int q = 0; q < MI; ++q) {
+        const int row = wave * (8 * MI) + q * 8 + (lane >> 3), c = lane & 7;
         int grow = (QW_ABL(64) ? 0 : m0) + row;   // (ablation 64: every block loads tile (0, 0) -- all loads hit L2)
         grow = grow < g.M ? grow : g.M - 1;   // rows past M repeat the last one; their outputs are never stored
         offA[q] = (unsigned)(((size_t)grow * g.lda + c * 8) * 2);
         dst[q] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-        if (!W4 && !W8) {
+    }
+    if (!W4 && !W8) {
+#pragma unroll
+        for (int q = 0; q < (W4 || W8 ? 0 : 4); ++q) {
+            const int row = wave * 32 + q * 8 + (lane >> 3), c = lane & 7;
             offB[q] = (unsigned)(((size_t)((QW_ABL(64) ? 0 : n0) + row) * g.ldw + c * 8) * 2);
-            dstB[q] = A_BYTES + dst[q];
+            dstB[q] = A_BYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
         }
     }
     if (W4) {
@@ -130,12 +138,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
             dstB[q] = A_BYTES + pc * 1024 + lane * 16;
         }
     }
-    u32x4 ra[4], rb[NBP];
+    u32x4 ra[MI], rb[NBP];
     auto fetchA = [&](int kt) {
         if (QW_ABL(8)) return;
         const int so = kt * (BK * 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < MI; ++q)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[q]) : "v"(offA[q]), "s"(rsA), "s"(so) : "memory");
     };
     auto fetchB = [&](int kt) {
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         if (QW_ABL(4)) return;
         unsigned char *st = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4 *)(st + dst[q]) = ra[q];
+        for (int q = 0; q < MI; ++q) *(u32x4 *)(st + dst[q]) = ra[q];
     };
     auto putB = [&](int stage) {
         if (QW_ABL(4)) return;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         unsigned char *st = smem + stage * STAGE_BYTES;
         const int so = kt * (BK * 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < MI; ++q) {
             if (!QW_ABL(4)) *(u32x4 *)(st + dst[q]) = ra[q];
             if (!QW_ABL(8)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[q]) : "v"(offA[q]), "s"(rsA), "s"(so) : "memory");
         }
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    struct Frag { half8 a[4]; half8 b[2]; uint32_t q4[2]; uint2 q8[2]; };
+    struct Frag { half8 a[MI]; half8 b[2]; uint32_t q4[2]; uint2 q8[2]; };
     QW_PHASE(1);
     // All eight waves run the same phase.  Fragment reads are software-pipelined under the wave's own MFMAs (two
     // register sets, pinned with sched_barrier); the A pieces of tile kt + 1 are written (and the A pieces of tile
@@ -225,8 +233,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
                 f.b[j] = *(const half8 *)(sB + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 128 + i * 32 + (lane & 31);
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * (32 * MI) + i * 32 + (lane & 31);
             f.a[i] = *(const half8 *)(sA + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
         }
     };
@@ -238,14 +246,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
         if (QW_ABL(1)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(f.a[i]));
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(f.a[i]));
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[j]));
             return;
         }
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // operands swapped (D^T = W A^T): a lane holds 4 CONSECUTIVE output columns per register quad
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], f.a[i], acc[i][j], 0, 0, 0);
             }
     };
-    // accumulator (i, j), register r: tile row = wm*128 + i*32 + (lane & 31),
+    // accumulator (i, j), register r: tile row = wm*32*MI + i*32 + (lane & 31),
     //   tile column = wn*64 + j*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
     const int l31 = lane & 31, hi = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, g.N * 4, 0x00020000);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 0));
     };
     const int nb = n0 + wn * 64;          // first tile column of this wave
-    const int mb = m0 + wm * 128;         // first row of this wave
+    const int mb = m0 + wm * (32 * MI);   // first row of this wave
     f32x4 bia[2][4], scl[2][4];           // bias (and, W8A16, per-channel weight scales) of the wave's 64 columns
 
     // The last K-tile is written out separately (it stages nothing): +3 % on the long-K residual shapes.  Requesting
@@ -301,8 +309,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         mma(f1);
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
-            // outstanding: W(kt+1) x NBP [, A(kt+2) x4]
-            if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // outstanding: W(kt+1) x NBP [, A(kt+2) x MI]
+            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (has2 && QV_SWAP) swapB(cur ^ 1, kt + 2);
             else { putB(cur ^ 1); if (has2) fetchB(kt + 2); }
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #if defined(QV_GEMM_TRACE) && defined(__HIP_DEVICE_COMPILE__)
     if (QW_ABL(32)) {   // no epilogue at all (accumulators kept live)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         };
         const int nbo = GLU ? n0 / 2 + wn * 32 : nb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             // the tile's rows are rebased per 32-row group: the dense subsampling tensors have millions of 1 KB rows
             const int r0 = mb + i * 32;
             const int rows_here = g.M - r0 < 32 ? g.M - r0 : 32;
@@ -479,18 +487,22 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         half_t *vt = (half_t *)g.out2;
         const int fp = lane & 31, dsub = lane >> 5;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < (MI + 1) / 2; ++hh) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
+                if (hh * 2 + ii < MI) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            sT[(j * 32 + 8 * q + 4 * hi + e) * LDV + ii * 32 + l31] = (half_t)(acc[hh * 2 + ii][j][q * 4 + e] + bia[j][q][e]);
+                            for (int e = 0; e < 4; ++e)
+                                sT[(j * 32 + 8 * q + 4 * hi + e) * LDV + ii * 32 + l31] = (half_t)(acc[hh * 2 + ii][j][q * 4 + e] + bia[j][q][e]);
+                }
+            // (MI = 3: the second 64-frame group holds one 32-row fragment -- frames 32 .. 63 of it belong to the next wave)
+            const bool mine = hh * 64 + 2 * fp + 1 < 32 * MI;
             const int r0 = mb + hh * 64 + 2 * fp, r1 = r0 + 1;
-            const int bt0 = r0 < g.M ? g.row_map[r0] : -1, bt1 = r1 < g.M ? g.row_map[r1] : -1;
+            const int bt0 = (mine && r0 < g.M) ? g.row_map[r0] : -1, bt1 = (mine && r1 < g.M) ? g.row_map[r1] : -1;
             const bool pair = bt0 >= 0 && bt1 == bt0 + 1 && (bt0 & 1) == 0;   // same utterance, even frame: one 4-byte store
             for (int dd = 0; dd < 32; ++dd) {
                 const int d = dd * 2 + dsub;
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 4), 0x00020000);
         const int rr = lane >> 4, cc = (lane & 15) * 4;   // read-back: 4 rows x 256 B per instruction
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             // (requesting row group i + 1's old values before group i is stored -- two register sets -- was measured:
             // no gain, the other waves' epilogues already cover the read latency)
             f32x4 old[8];
@@ -562,7 +574,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         const int rr = lane >> 2, cc = (lane & 3) * 8;    // read-back: 16 rows x 64 B per instruction
         const int nbo = n0 / 2 + wn * 32;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 half4 o;
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.M * g.ldo * 2), 0x00020000);
         const int rr = lane >> 3, cc = (lane & 7) * 8;    // read-back: 8 rows x 128 B per instruction
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -629,11 +641,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(GemmArgs g) {
 #include QV_GEMM_Q_VARIANT
 #endif
 
-template <int EPI, int WQ>
-static void launch256(const GemmArgs &g, hipStream_t s) {
+template <int EPI, int WQ, int MI>
+static void launch256m(const GemmArgs &g, hipStream_t s) {
     constexpr int LDS = 2 * (256 * 64 * 2) * 2;   // two stages of f16 A + W tiles = 128 KB = the eight epilogue slices
 #ifdef QV_GEMM_Q_VARIANT
-    if constexpr (WQ != 88) {
+    if constexpr (WQ != 88 && MI == 4) {
         if (gemm_q()) {
             static bool opted_q = false;
             if (!opted_q) {
@@ -647,15 +659,23 @@ static void launch256(const GemmArgs &g, hipStream_t s) {
 #endif
     static bool opted = false;
     if (!opted) {
-        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)k_gemm256<EPI, WQ, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         opted = true;
     }
-    hipLaunchKernelGGL((k_gemm256<EPI, WQ>), dim3(g.N / 256, (g.M + 255) / 256), dim3(512), LDS, s, g);
+    hipLaunchKernelGGL((k_gemm256<EPI, WQ, MI>), dim3(g.N / 256, (g.M + 64 * MI - 1) / (64 * MI)), dim3(512), LDS, s, g);
+}
+
+static thread_local int t_bm = 256;   // tile height of the launch in progress (launch_gemm256's argument)
+template <int EPI, int WQ>
+static void launch256(const GemmArgs &g, hipStream_t s) {
+    if (t_bm == 192) launch256m<EPI, WQ, 3>(g, s);
+    else launch256m<EPI, WQ, 4>(g, s);
 }
 
 // N % 256 == 0, K % 64 == 0 (int4: K % 128 == 0, K <= 4096 for the scale table in LDS); false = nothing launched
-bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s) {
-    if (g.N % 256 != 0 || g.K % 64 != 0 || !g.bias) return false;
+bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s, int bm) {
+    if (g.N % 256 != 0 || g.K % 64 != 0 || !g.bias || (bm != 256 && bm != 192)) return false;
+    t_bm = bm;
     if (g.Wi8) {
         // int8 activations x int8 weights (QV_PREC_ORT_MIXED): the GEMM-shaped convolutions
         switch (epi) {

@@ -108,9 +108,14 @@ void qv_pack_w8(const float *w, int N, int K, uint8_t *q_out, float *scale_out);
 
 void launch_gemm(int epi, const GemmArgs &g, hipStream_t s);
 // 256 x 256 tiles, one block per CU (qv_gemm256.hip): N % 256 == 0 only; false = nothing launched
-bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s);
+bool launch_gemm256(int epi, const GemmArgs &g, hipStream_t s, int bm = 256);   // bm: tile height, 256 or 192
 // tile policy of launch_gemm: 0 = 128-wide tiles only, 1 = 256 x 256 where the grid has >= 160 tiles (default), 2 = 256 x 256 wherever the shape allows; -1 = back to QVERSE_GEMM_T256 / the default
 void qv_gemm_set_t256(int mode);
+// tile height of the wide kernel: 0 = 256 rows always, 1 = 192 rows where that saves a round of tiles and fewer than three batches
+// are in flight (default), 2 = ... whatever is in flight, 3 = 192 rows always; -1 = back to QVERSE_GEMM_BM / the default
+void qv_gemm_set_bm(int mode);
+// changes whenever a qv_gemm_set_* switch does: part of the forward-graph key (a captured graph holds the old kernel choice)
+int qv_gemm_policy_epoch();
 // tools/gemm_bench only (QV_GEMM_Q_VARIANT builds): 256 x 256 tiles with four waves of 128 x 128 (tools/gemm256q.h)
 void qv_gemm_set_q(int mode);
 // the kernel launch_gemm picks for this call, e.g. "k_gemm256<f16_swish>" / "k_gemm<resid,128>" (thread-local buffer)
@@ -124,7 +129,9 @@ const char *qv_gemm_kernel_name(int epi, const GemmArgs &g);
 //   QV_KV_SPANS   (QVERSE_SPANS)    match_verse's span pass: 1 = prefix-shared walk per start verse (k_spans2, default); 0 = one walk per span
 //   QV_KV_FWD_GRAPH (QVERSE_FWD_GRAPH) multi-context engines: 1 = a forward whose shape repeats on a context is replayed as one hipGraph
 //                                   launch (default); 0 = always the plain launches
-enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_SPANS = 2, QV_KV_FWD_GRAPH = 3, QV_KV_COUNT = 8 };
+//   QV_KV_CTC     (QVERSE_CTC)      the alpha recursion of the CTC rerank: 1 = parity-specialised wave program (ctc_wave2, default);
+//                                   0 = the wave program of rounds 1-5
+enum { QV_KV_LOGMEL = 0, QV_KV_ORT_SUB = 1, QV_KV_SPANS = 2, QV_KV_FWD_GRAPH = 3, QV_KV_CTC = 4, QV_KV_COUNT = 8 };
 int qv_kernel_variant(int which);
 void qv_kernel_variant_set(int which, int mode);   // mode < 0: back to the environment / default
 

@@ -1227,8 +1227,8 @@ void qv_kernel_variant_set(int which, int mode) {
 }
 int qv_kernel_variant(int which) {
     static const struct Env { int v[QV_KV_COUNT]; Env() {
-        const char *names[QV_KV_COUNT] = {"QVERSE_LOGMEL", "QVERSE_ORT_SUB", "QVERSE_SPANS", "QVERSE_FWD_GRAPH", nullptr, nullptr, nullptr, nullptr};
-        const int dflt[QV_KV_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0};
+        const char *names[QV_KV_COUNT] = {"QVERSE_LOGMEL", "QVERSE_ORT_SUB", "QVERSE_SPANS", "QVERSE_FWD_GRAPH", "QVERSE_CTC", nullptr, nullptr, nullptr};
+        const int dflt[QV_KV_COUNT] = {1, 1, 1, 1, 1, 0, 0, 0};
         for (int i = 0; i < QV_KV_COUNT; ++i) {
             const char *e = names[i] ? getenv(names[i]) : nullptr;
             v[i] = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : dflt[i];

@@ -282,13 +282,16 @@ struct QvModel : QvActs {
     // the forward's launches (log-mel .. log-softmax) as ONE hipGraph launch per context, keyed by everything a grid
     // size or kernel argument is computed from on the host; per-utterance lengths are read from lens_dev by the kernels
     struct FwdKey {
-        const float *audio; float *logprobs; const half_t *pos; int64_t n_max; int v[12];
+        const float *audio; float *logprobs; const half_t *pos; int64_t n_max; int v[13];
         bool operator==(const FwdKey &o) const {
             return audio == o.audio && logprobs == o.logprobs && pos == o.pos && n_max == o.n_max && !memcmp(v, o.v, sizeof(v));
         }
     };
-    struct FwdGraph { FwdKey key; hipGraphExec_t exec; } fwd_graph[QV_MAX_CTX][QV_FWD_GRAPHS];
-    int n_fwd_graph[QV_MAX_CTX] = {}, fwd_evict[QV_MAX_CTX] = {};
+    struct FwdGraph { FwdKey key; hipGraphExec_t exec; int64_t last_use; } fwd_graph[QV_MAX_CTX][QV_FWD_GRAPHS];
+    int n_fwd_graph[QV_MAX_CTX] = {};
+    int64_t fwd_tick[QV_MAX_CTX] = {}, fwd_last_capture[QV_MAX_CTX] = {};   // forwards seen by the context / the one that captured last
+    bool fwd_disabled[QV_MAX_CTX] = {};        // a capture or instantiate failed on this context: plain launches from then on
+    int64_t fwd_capture_failures = 0;
     FwdKey fwd_seen[QV_MAX_CTX][QV_FWD_GRAPHS] = {};   // keys of the context's last few uncaptured forwards: a shape is captured when it comes back
     int fwd_seen_at[QV_MAX_CTX] = {};
     int64_t fwd_replays = 0, fwd_captures = 0;   // graph launches / captures since creation (qv_debug_forward_graph_stats)
@@ -1032,10 +1035,13 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
     // (single-context engines), debug taps, stage / GEMM profiling -- takes the plain launches.  QVERSE_FWD_GRAPH=0
     // (or qv_debug_kernel_variant(QV_KV_FWD_GRAPH, 0)) turns it off.
     if (qv_kernel_variant(QV_KV_FWD_GRAPH) == 1 && may_graph && !m->save_taps && !eng->profile_stages && !qv_gemm_prof_on()) {
+        // (the GEMM tile policy is host state that picks kernels: its epoch is part of the key, so a graph captured under
+        // another policy is never replayed after qv_debug_gemm_tiles / QVERSE_GEMM_* changed it)
         QvModel::FwdKey key = {audio, logprobs, posp, n_max,
                                {B, M, T, t3min, tm_max, t1m, t2m, t_max_out, t_min_pad, att_variant,
-                                qv_kernel_variant(QV_KV_LOGMEL), qv_kernel_variant(QV_KV_ORT_SUB)}};
+                                qv_kernel_variant(QV_KV_LOGMEL), qv_kernel_variant(QV_KV_ORT_SUB), qv_gemm_policy_epoch()}};
         const int k = m->cur_ctx;
+        const int64_t tick = ++m->fwd_tick[k];
         QvModel::FwdGraph *hit = nullptr;
         for (int i = 0; i < m->n_fwd_graph[k]; ++i)
             if (m->fwd_graph[k][i].key == key) hit = &m->fwd_graph[k][i];
@@ -1045,31 +1051,52 @@ int qv_model_forward(qv_engine *eng, QvModel *m, const float *audio, const int64
             m->fwd_seen[k][m->fwd_seen_at[k]] = key;
             m->fwd_seen_at[k] = (m->fwd_seen_at[k] + 1) % QV_FWD_GRAPHS;
         }
-        if (!hit && (seen || m->n_fwd_graph[k] < QV_FWD_GRAPHS)) {
+        // a full context replaces its LEAST RECENTLY USED graph, and at most once per 2 * QV_FWD_GRAPHS forwards: a loop
+        // over more recurring shapes than slots must not pay a capture + instantiate + stream synchronise per cycle
+        // (it keeps replaying the shapes it holds and runs the others as plain launches)
+        const bool full = m->n_fwd_graph[k] >= QV_FWD_GRAPHS;
+        const bool may_capture = !m->fwd_disabled[k] && (full ? (seen && tick - m->fwd_last_capture[k] >= 2 * QV_FWD_GRAPHS) : true);
+        bool ran_plain = false;
+        if (!hit && may_capture) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
-            QV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            int rc = launch_all();
-            hipError_t e1 = hipStreamEndCapture(s, &graph);
-            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            QV_HIP(e1);
-            hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            QV_HIP(e2);
-            int slot = m->n_fwd_graph[k];
-            if (slot < QV_FWD_GRAPHS) m->n_fwd_graph[k]++;
-            else {
-                slot = m->fwd_evict[k];
-                m->fwd_evict[k] = (slot + 1) % QV_FWD_GRAPHS;
-                QV_HIP(hipStreamSynchronize(s));   // its last replay may still be queued on this stream (rare: a fifth repeating shape)
-                (void)hipGraphExecDestroy(m->fwd_graph[k][slot].exec);
+            // Any failure of the capture machinery (a capture-unsafe call of the host on this thread invalidated it, a node type
+            // the runtime cannot instantiate) must not fail the batch: the plain launches would have succeeded.  The sticky
+            // error is cleared, graphs are switched off for this context and the launches are issued for real.
+            hipError_t e0 = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            int rc = 0;
+            hipError_t e1 = hipSuccess, e2 = hipSuccess;
+            if (e0 == hipSuccess) {
+                rc = launch_all();
+                e1 = hipStreamEndCapture(s, &graph);
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                if (e1 == hipSuccess) e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
             }
-            m->fwd_graph[k][slot] = {key, exec};
-            m->fwd_captures++;
-            hit = &m->fwd_graph[k][slot];
+            if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || !exec) {
+                (void)hipGetLastError();
+                m->fwd_disabled[k] = true;
+                m->fwd_capture_failures++;
+                TRY(launch_all());
+                ran_plain = true;
+            } else {
+                int slot = m->n_fwd_graph[k];
+                if (!full) m->n_fwd_graph[k]++;
+                else {
+                    slot = 0;
+                    for (int i = 1; i < QV_FWD_GRAPHS; ++i)
+                        if (m->fwd_graph[k][i].last_use < m->fwd_graph[k][slot].last_use) slot = i;
+                    QV_HIP(hipStreamSynchronize(s));   // its last replay may still be queued on this stream (rate-limited above)
+                    (void)hipGraphExecDestroy(m->fwd_graph[k][slot].exec);
+                }
+                m->fwd_graph[k][slot] = {key, exec, tick};
+                m->fwd_last_capture[k] = tick;
+                m->fwd_captures++;
+                hit = &m->fwd_graph[k][slot];
+            }
         }
-        if (hit) { QV_HIP(hipGraphLaunch(hit->exec, s)); m->fwd_replays++; }
-        else TRY(launch_all());
+        if (hit) { QV_HIP(hipGraphLaunch(hit->exec, s)); hit->last_use = tick; m->fwd_replays++; }
+        else if (!ran_plain) TRY(launch_all());
     } else {
         TRY(launch_all());
     }
@@ -1115,6 +1142,7 @@ void qv_model_graph_stats(const QvModel *m, int64_t *replays, int64_t *captures)
     *replays = m->fwd_replays;
     *captures = m->fwd_captures;
 }
+int64_t qv_model_graph_failures(const QvModel *m) { return m->fwd_capture_failures; }
 
 void qv_model_weights_info(const QvModel *m, char *out, int cap) {
     const char *prec = m->ort ? "ort-mixed" : m->w4 ? "mixed-int4-int8" : "fp16";

@@ -1676,6 +1676,85 @@ __device__ void ctc_wave(const float *__restrict__ lp, int T, const uint16_t *__
     for (int k = 0; k < NS; ++k) sa[lane * NS + k] = a[k];
 }
 
+// Single-instruction three-operand forms (the compiler pads fmaxf / fminf chains with canonicalising v_max_f32 x, x
+// because a gathered log-prob could be a signalling NaN; it never is here)
+__device__ __forceinline__ float f_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float f_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float f_med3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float f_max2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float f_min2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// Round 6: the same recursion with fewer instructions per state and frame -- same operands, same operation order, same
+// bits as ctc_wave (tests/test_gpu_postlogits.py compares the two on every instantiation):
+//  * with an even NS the parity of state lane*NS + k is the parity of k, a compile-time constant per register: even
+//    states are blanks, whose third term (the skip transition) does not exist -- ctc_wave adds exp2(NEG - max) = +0 for
+//    it -- so they take a two-term log-sum-exp (2 instead of 3 transcendental issues, 6 instead of ~14 VALU), and
+//    their emission is the one value row[blank] per frame instead of a gather per state;
+//  * max / min / median of three as v_max3 / v_min3 / v_med3 (one instruction each);
+//  * states updated in place from the highest register down (a[k] needs the OLD a[k-1], a[k-2]): no copy pass.
+// The kernel is bound by VALU + transcendental issue (sum over leaders of T x states, ~2.6 G state steps per batch of
+// 64 gated 30 s clips), so this is where its time goes: 116 -> ~72 issue cycles per state and frame.
+template <int NS>
+__device__ void ctc_wave2(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tgt, int L, int lane, float *sa) {
+    const float NEG = -1e30f, LOG2E = 1.44269504088896340736f;
+    constexpr bool PAR = (NS % 2) == 0;
+    int S = 2 * L + 1;
+    int tok[NS];
+    bool skip_ok[NS];
+    float a[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        int s = lane * NS + k;
+        tok[k] = QV_BLANK;
+        skip_ok[k] = false;
+        if (s < S && (s & 1)) {
+            tok[k] = tgt[s >> 1];
+            skip_ok[k] = s > 1 && tgt[s >> 1] != tgt[(s >> 1) - 1];
+        }
+        a[k] = NEG;
+        if (s == 0) a[k] = lp[QV_BLANK] * LOG2E;
+        if (s == 1) a[k] = lp[tok[k]] * LOG2E;
+    }
+    constexpr int TCH = NS <= 2 ? 8 : (NS <= 6 ? 4 : 2);
+    for (int t0 = 1; t0 < T; t0 += TCH) {
+        float lpv[TCH][NS], lpb[TCH];
+#pragma unroll
+        for (int j = 0; j < TCH; ++j) {
+            int t = t0 + j < T ? t0 + j : T - 1;
+            const float *row = lp + (size_t)t * QV_VOCAB;
+            if (PAR) lpb[j] = row[QV_BLANK] * LOG2E;
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (!PAR || (k & 1)) lpv[j][k] = row[tok[k]] * LOG2E;
+        }
+#pragma unroll
+        for (int j = 0; j < TCH; ++j) {
+            if (t0 + j >= T) break;
+            float p1 = __shfl_up(a[NS - 1], 1), p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1) : __shfl_up(a[NS - 1], 2);
+            if (lane == 0) { p1 = NEG; p2 = NEG; }
+            if (NS == 1 && lane == 1) p2 = NEG;
+#pragma unroll
+            for (int k = NS - 1; k >= 0; --k) {
+                const float la1 = a[k];
+                const float la2 = k >= 1 ? a[k - 1] : p1;
+                if (PAR && !(k & 1)) {
+                    const float hi2 = f_max2(la1, la2), lo2 = f_min2(la1, la2);
+                    a[k] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lo2 - hi2)) + hi2 + lpb[j];
+                } else {
+                    float la3 = k >= 2 ? a[k - 2] : (k == 1 ? p1 : p2);
+                    if (NS == 1) la3 = p2;
+                    if (!skip_ok[k]) la3 = NEG;
+                    const float lamax = f_max3(la1, la2, la3), lamin = f_min3(la1, la2, la3), lamed = f_med3(la1, la2, la3);
+                    a[k] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lamed - lamax) + __builtin_amdgcn_exp2f(lamin - lamax)) +
+                           lamax + lpv[j][k];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sa[lane * NS + k] = a[k];
+}
+
 // loss of the target made of the first P tokens, from the alpha_T row a recursion over at least P tokens left
 // in `sa` (log2 units): -ln(alpha_T(2P) + alpha_T(2P - 1)), INFINITY when no alignment exists.
 __device__ __forceinline__ float ctc_readout(const float *sa, int P) {
@@ -1689,23 +1768,32 @@ __device__ __forceinline__ float ctc_readout(const float *sa, int P) {
 
 // LONG = engine capacity above 30 s (more than 384 states per target): only then are the wide
 // instantiations compiled into the kernel, keeping the common kernel's register footprint small
-template <bool LONG>
+template <bool LONG, int VAR>
 __device__ void ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L, int lane, float *sa) {
     int S = 2 * L + 1;
-    if (S <= 64) return ctc_wave<1>(lp, T, tgt, L, lane, sa);
-    if (S <= 128) return ctc_wave<2>(lp, T, tgt, L, lane, sa);
-    if (S <= 192) return ctc_wave<3>(lp, T, tgt, L, lane, sa);
-    if (S <= 256) return ctc_wave<4>(lp, T, tgt, L, lane, sa);
-    if (S <= 384 || !LONG) return ctc_wave<6>(lp, T, tgt, L, lane, sa);
-    if (S <= 512) return ctc_wave<8>(lp, T, tgt, L, lane, sa);
-    return ctc_wave<12>(lp, T, tgt, L, lane, sa);
+    if (VAR == 0) {     // the wave program of rounds 1-5 (QVERSE_CTC=0 / qv_debug_kernel_variant(4, 0)): cross-check only
+        if (S <= 64) return ctc_wave<1>(lp, T, tgt, L, lane, sa);
+        if (S <= 128) return ctc_wave<2>(lp, T, tgt, L, lane, sa);
+        if (S <= 192) return ctc_wave<3>(lp, T, tgt, L, lane, sa);
+        if (S <= 256) return ctc_wave<4>(lp, T, tgt, L, lane, sa);
+        if (S <= 384 || !LONG) return ctc_wave<6>(lp, T, tgt, L, lane, sa);
+        if (S <= 512) return ctc_wave<8>(lp, T, tgt, L, lane, sa);
+        return ctc_wave<12>(lp, T, tgt, L, lane, sa);
+    }
+    if (S <= 64) return ctc_wave2<1>(lp, T, tgt, L, lane, sa);
+    if (S <= 128) return ctc_wave2<2>(lp, T, tgt, L, lane, sa);
+    if (S <= 192) return ctc_wave2<3>(lp, T, tgt, L, lane, sa);
+    if (S <= 256) return ctc_wave2<4>(lp, T, tgt, L, lane, sa);
+    if (S <= 384 || !LONG) return ctc_wave2<6>(lp, T, tgt, L, lane, sa);
+    if (S <= 512) return ctc_wave2<8>(lp, T, tgt, L, lane, sa);
+    return ctc_wave2<12>(lp, T, tgt, L, lane, sa);
 }
 
 // One wave per LEADER candidate (k_candidates' plan): one alpha recursion, then the loss of the leader and of
 // every candidate whose ids are a prefix of its ids.
 // One wave per LEADER candidate (k_candidates' plan): one alpha recursion, then the loss of the leader and of
 // every candidate whose ids are a prefix of its ids.
-template <bool LONG>
+template <bool LONG, int VAR>
 __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn, const float *__restrict__ lp, int t_max) {
     __shared__ float sa_all[4][LONG ? 768 : 384];
     if ((int)blockIdx.y >= *wk.n_fail) return;
@@ -1722,7 +1810,7 @@ __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn
         const int st = wk.cand_start[(size_t)b * QV_CAND_CAP + c], sp = wk.cand_span[(size_t)b * QV_CAND_CAP + c];
         const size_t k0 = (size_t)st * QV_MAX_SPAN;
         const int L = (int)(tab.tok_off[k0 + sp] - tab.tok_off[k0 + sp - 1]);
-        ctc_dispatch<LONG>(lpb, T, tab.tok + tab.tok_off[k0 + sp - 1], L, lane, sa);
+        ctc_dispatch<LONG, VAR>(lpb, T, tab.tok + tab.tok_off[k0 + sp - 1], L, lane, sa);
         // the leader itself (k == sp) and its members
         const int16_t *memb = wk.cand_memb + ((size_t)b * QV_CAND_CAP + c) * QV_MAX_SPAN;
         for (int k = 1; k <= sp; ++k) {
@@ -1743,13 +1831,14 @@ __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn
     }
 }
 
+template <int VAR>
 __global__ __launch_bounds__(64) void k_ctc_debug(const float *__restrict__ lp, int T, const uint16_t *__restrict__ tg,
                                                   const int32_t *__restrict__ off, int n, float *__restrict__ loss) {
     __shared__ float sa[768];
     int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n) return;
     int L = off[c + 1] - off[c];
-    ctc_dispatch<true>(lp, T, tg + off[c], L, lane, sa);
+    ctc_dispatch<true, VAR>(lp, T, tg + off[c], L, lane, sa);
     float l = ctc_readout(sa, L);
     if (lane == 0) loss[c] = l;
 }
@@ -1969,8 +2058,12 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
         // THIS batch has a clip of more than 384 frames -- not whenever the engine COULD hold one: an engine created for
         // 30 s clips used to run every 10 s batch through it (round 4: tools/sweep.py's 10 s row, 4.8 ms, against bench.py's
         // 3.8 ms for the same batch on an engine sized for it).  2L + 1 <= T <= t_max <= 384 holds for every candidate then.
-        else if (t_max > 384) hipLaunchKernelGGL(k_ctc<true>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
-        else hipLaunchKernelGGL(k_ctc<false>, dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        else if (qv_kernel_variant(QV_KV_CTC) == 0) {
+            if (t_max > 384) hipLaunchKernelGGL((k_ctc<true, 0>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+            else hipLaunchKernelGGL((k_ctc<false, 0>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        }
+        else if (t_max > 384) hipLaunchKernelGGL((k_ctc<true, 1>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        else hipLaunchKernelGGL((k_ctc<false, 1>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
         hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
         qv_stage_mark(eng, 4, stream);
         return QV_OK;
@@ -2050,7 +2143,8 @@ int qv_post_debug_ctc(qv_engine *eng, const float *lp, int T, const uint16_t *tg
     QV_HIP(hipMalloc(&d_l, sizeof(float) * std::max(1, n)));
     QV_HIP(hipMemcpyAsync(d_t, tg, sizeof(uint16_t) * off[n], hipMemcpyHostToDevice, stream));
     QV_HIP(hipMemcpyAsync(d_o, off.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_ctc_debug, dim3(n), dim3(64), 0, stream, lp, T, d_t, d_o, n, d_l);
+    if (qv_kernel_variant(QV_KV_CTC) == 0) hipLaunchKernelGGL(k_ctc_debug<0>, dim3(n), dim3(64), 0, stream, lp, T, d_t, d_o, n, d_l);
+    else hipLaunchKernelGGL(k_ctc_debug<1>, dim3(n), dim3(64), 0, stream, lp, T, d_t, d_o, n, d_l);
     QV_HIP(hipMemcpyAsync(loss_host, d_l, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
     QV_HIP(hipStreamSynchronize(stream));
     (void)hipFree(d_t); (void)hipFree(d_o); (void)hipFree(d_l);

@@ -124,6 +124,9 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_profile_replay_gemm.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.qv_profile_replay_kernel.argtypes = [vp, i32, C.c_char_p, i32]
     lib.qv_debug_gemm_tiles.argtypes = [i32]
+    lib.qv_debug_gemm_tile_height.argtypes = [i32]
+    lib.qv_debug_forward_graph_failures.argtypes = [vp]
+    lib.qv_debug_forward_graph_failures.restype = i64
     lib.qv_debug_attention_variant.argtypes = [i32]
     lib.qv_debug_kernel_variant.argtypes = [i32, i32]
     lib.qv_debug_forward_graph_stats.argtypes = [vp, vp, vp]
@@ -371,6 +374,11 @@ class Engine:
         """process-wide GEMM tile policy (qv_debug_gemm_tiles): 0 = 128-wide only, 1 = default, 2 = 256 x 256
         wherever the shape allows, -1 = environment / default."""
         self._check(self.lib.qv_debug_gemm_tiles(int(mode)), "qv_debug_gemm_tiles")
+
+    def gemm_tile_height(self, mode: int):
+        """tile height of the wide GEMM kernel (qv_debug_gemm_tile_height): 0 = 256 rows always, 1 = default (192 rows where
+        they save a round of tiles and < 3 batches are in flight), 2 = that rule always, 3 = 192 rows always, -1 = env / default."""
+        self._check(self.lib.qv_debug_gemm_tile_height(int(mode)), "qv_debug_gemm_tile_height")
 
     def weights_info(self) -> str:
         """precision mode and where the quantisation grids came from (qv_weights_info)"""

@@ -27,13 +27,15 @@ def eng(request):
     e.mixed = bool(request.param)
     yield e
     e.gemm_tiles(-1)
+    e.gemm_tile_height(-1)
     del e
 
 
-def _forward_bits(eng, audio, lens, mode):
+def _forward_bits(eng, audio, lens, mode, height=0):
     import torch
 
     eng.gemm_tiles(mode)
+    eng.gemm_tile_height(height)     # 0 = 256-row tiles, 3 = 192-row tiles wherever the wide kernel runs (round 6)
     lp, T = eng.forward(audio, lens)
     torch.cuda.synchronize()
     return lp.cpu().numpy().view(np.uint32).copy(), list(T)
@@ -51,10 +53,10 @@ def test_tile_shape_does_not_change_a_bit_of_the_logprobs(eng, batch, samples):
         audio[b, lens[b]:] = 0
     ref, T0 = _forward_bits(eng, audio, lens, 0)
     assert np.isfinite(ref.view(np.float32)).all()
-    for mode in (1, 2):
-        got, T = _forward_bits(eng, audio, lens, mode)
+    for mode, height in ((1, 0), (2, 0), (2, 3), (1, 2), (1, -1)):
+        got, T = _forward_bits(eng, audio, lens, mode, height)
         assert T == T0
-        assert np.array_equal(got, ref), f"tile policy {mode}: {np.count_nonzero(got != ref)} words differ"
+        assert np.array_equal(got, ref), f"tile policy {mode}, height {height}: {np.count_nonzero(got != ref)} words differ"
 
 
 def test_replay_reports_the_kernel_the_policy_picks(eng):
@@ -71,8 +73,13 @@ def test_replay_reports_the_kernel_the_policy_picks(eng):
     assert eng.replay_gemm(0, iters=2)["kernel"] == f"k_gemm<f16_swish,{small}>"
     assert eng.replay_gemm(1, iters=2)["kernel"] == f"k_gemm<resid,{small}>"
     eng.gemm_tiles(2)
+    eng.gemm_tile_height(0)
     assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm256<f16_swish>"
     assert eng.replay_gemm(1, iters=2)["kernel"] == "k_gemm256<resid>"
+    eng.gemm_tile_height(3)
+    assert eng.replay_gemm(0, iters=2)["kernel"] == "k_gemm256<f16_swish,192>"
+    assert eng.replay_gemm(1, iters=2)["kernel"] == "k_gemm256<resid,192>"
+    eng.gemm_tile_height(0)
     eng.gemm_tiles(1)   # 24 x 126 rows: 12 x 8 = 96 tiles of 256 x 256 for FFN-up -> below the 160-tile threshold
     assert eng.replay_gemm(0, iters=2)["kernel"] == f"k_gemm<f16_swish,{small}>"
     classes = {}

@@ -82,6 +82,52 @@ def test_ctc_loss_kernel_vs_float64_twin(engine, oracle):
     assert oracle.ctc_score_f64(lp.numpy(), []) == 1e9
 
 
+def test_parity_specialised_ctc_recursion_equals_the_generic_one_bit_for_bit(engine, oracle):
+    """Round 6: ctc_wave2 (two-term log-sum-exp for the blank states of even-NS instantiations, v_max3 / v_min3 / v_med3,
+    in-place update) against the wave program of rounds 1-5 -- same operands in the same order, so every loss must carry
+    the same BITS, on every instantiation (1 ... 12 states per lane: targets of 1 ... 383 tokens), with repeated tokens
+    (no skip transition), targets with no alignment (loss inf) and T = 2L + 1 exactly."""
+    rng = np.random.default_rng(6)
+    for T, noise in ((33, 1.0), (126, 2.5), (376, 1.0), (413, 3.0), (767, 2.0)):
+        ids0 = oracle.token_ids(int(rng.integers(0, 6236)), 1).tolist()
+        lp = torch.log_softmax(torch.from_numpy(synth_logits(ids0, T, seed=T + 11, noise=noise, boost=5.0, rep=2)), -1)
+        targets = [np.asarray(ids0[: max(1, (T - 1) // 2)], np.uint16)]
+        for L in sorted({1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 192, 193, 255, 256, 300, 383}):
+            if 2 * L + 1 > min(T, 768):
+                continue
+            t = rng.integers(0, 1024, size=L)
+            if L > 3:
+                t[2] = t[1]
+                t[L - 1] = t[L - 2]
+            targets.append(t.astype(np.uint16))
+            targets.append(np.full(L, int(rng.integers(0, 1024)), np.uint16))      # one token repeated: needs 2L - 1 + L frames
+        dev = lp.cuda().contiguous()
+        try:
+            engine.kernel_variant(4, 0)
+            old = engine.debug_ctc_loss(dev, targets)
+            engine.kernel_variant(4, 1)
+            new = engine.debug_ctc_loss(dev, targets)
+        finally:
+            engine.kernel_variant(4, -1)
+        assert old.view(np.uint32).tolist() == new.view(np.uint32).tolist(), (T, np.abs(old - new).max())
+    # ... and through the hot path (leaders + the prefix read-outs of their members): corrupted recitations that fail the gate
+    lps = []
+    for i in range(8):
+        ids = oracle.token_ids(int(rng.integers(0, 6236)), 1 + i % 3).tolist()[:60]
+        lps.append(torch.log_softmax(torch.from_numpy(synth_logits(ids, 126, seed=900 + i, noise=3.5, boost=4.0, rep=2)), -1))
+    dev = torch.stack(lps).cuda().contiguous()
+    rows = {}
+    try:
+        for var in (0, 1):
+            engine.kernel_variant(4, var)
+            rows[var] = engine.decode_retrieve_rerank(dev, [126] * 8, want_text=False)
+    finally:
+        engine.kernel_variant(4, -1)
+    assert sum(r["use_ctc"] for r in rows[1]) >= 4
+    for a, b in zip(rows[0], rows[1]):
+        assert a == b, (a, b)
+
+
 def test_retrieval_matches_reference_fixtures(engine, oracle, ret_cases):
     from oracle.oracle import normalize_arabic
 

@@ -287,3 +287,141 @@ def test_tta_rows_all_gather_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the multi-GPU PRODUCT entry: python -m torch.distributed.run ... -m offline_tarteel_amd.benchmark.runner
+_STUB_PLUGIN = r'''
+"""A predict()/predict_batch()/model_size() plugin that needs no GPU: the "prediction" is a function of the file's
+sample count, so a sharded run must reproduce a single-process run row for row."""
+import struct
+from pathlib import Path
+
+
+def _n(path):
+    data = Path(path).read_bytes()
+    return (len(data) - 44) // 2
+
+
+def predict(audio_path):
+    if "bad" in Path(audio_path).name:
+        raise ValueError("undecodable file")
+    n = _n(audio_path)
+    if (n // 100) % 5 == 0:
+        return {"surah": 0, "ayah": 0, "ayah_end": None, "score": 0.0, "transcript": "", "candidates": []}
+    k = n // 100
+    return {"surah": k % 114 + 1, "ayah": k % 7 + 1, "ayah_end": (k % 7 + 1 + k % 3), "score": round((k * 7919 % 10007) / 10007, 4),
+            "transcript": "x", "source": "text"}
+
+
+def predict_batch(paths):
+    if any("bad" in Path(p).name for p in paths):
+        raise ValueError("one undecodable file in the batch")
+    return [predict(p) for p in paths]
+
+
+def model_size():
+    return 1234
+'''
+
+
+def _write_wav(path, n):
+    import struct
+
+    pcm = (np.arange(n) % 251).astype("<i2").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+    path.write_bytes(hdr + b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def _stub_corpus(tmp_path):
+    corpus = tmp_path / "corpus"
+    corpus.mkdir()
+    exps = tmp_path / "exps" / "stub-exp"
+    exps.mkdir(parents=True)
+    (exps / "run.py").write_text(_STUB_PLUGIN)
+    lens = [3100, 900, 12300, 700, 4500, 8100, 2300, 15000, 5200, 6100, 1900]
+    samples = []
+    for i, n in enumerate(lens):
+        name = f"clip_{i:02d}.wav" if i != 4 else "bad_04.wav"
+        _write_wav(corpus / name, n)
+        k = n // 100
+        samples.append({"id": f"s{i}", "file": name, "surah": k % 114 + 1, "ayah": k % 7 + 1, "category": "short" if n < 5000 else "long"})
+    samples.append({"id": "missing", "file": "not_there.wav", "surah": 1, "ayah": 1, "category": "short"})
+    samples[2]["expected_verses"] = [{"surah": samples[2]["surah"], "ayah": samples[2]["ayah"]},
+                                     {"surah": samples[2]["surah"], "ayah": samples[2]["ayah"] + 1}]
+    (corpus / "manifest.json").write_text(json.dumps({"samples": samples}))
+    return corpus, tmp_path / "exps"
+
+
+def _strip(results):
+    out = json.loads(json.dumps(results))
+    for r in out:
+        r.pop("avg_latency", None)
+        r.pop("world_size", None)
+        for row in r["per_sample"]:
+            row.pop("latency", None)
+            row.pop("error", None)
+    return out
+
+
+@pytest.mark.parametrize("deal", ["strided", "contiguous"])
+def test_sharded_runner_entry_gloo_world2_equals_single_process(tmp_path, deal):
+    """The product's multi-GPU entry on two gloo ranks with a stub plugin: rank 0 reads the manifest, shard_plan deals the
+    length-sorted files, both ranks predict (one batch holds an undecodable file: retried file by file, as in the
+    single-process runner), all_gather_results restores the manifest order, rank 0 scores and writes results/*.json --
+    row for row what the single-process runner writes (scores included: 4-decimal values survive the float32 rows)."""
+    corpus, exps = _stub_corpus(tmp_path)
+    base = dict(os.environ, PYTHONPATH=str(ROOT), QVERSE_EXPERIMENTS_DIR=str(exps), MASTER_ADDR="127.0.0.1", QVERSE_DIST_BACKEND="gloo")
+    base.pop("WORLD_SIZE", None)
+    args = ["-m", "offline_tarteel_amd.benchmark.runner", "--experiment", "stub-exp", "--corpus", str(corpus), "--batch", "3"]
+    one = subprocess.run([sys.executable, *args], capture_output=True, text=True, cwd=str(ROOT), timeout=300,
+                         env=dict(base, QVERSE_RESULTS_DIR=str(tmp_path / "res1")))
+    assert one.returncode == 0, one.stdout + one.stderr
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29553" if deal == "strided" else "29555", *args, "--deal", deal],
+                         capture_output=True, text=True, cwd=str(ROOT), timeout=300, env=dict(base, QVERSE_RESULTS_DIR=str(tmp_path / "res2")))
+    assert two.returncode == 0, two.stdout + two.stderr
+
+    def load(d):
+        files = [f for f in sorted(d.glob("*.json")) if f.name != "latest.json"]
+        assert len(files) == 1, files
+        return json.loads(files[0].read_text()), json.loads((d / "latest.json").read_text())
+
+    r1, l1 = load(tmp_path / "res1")
+    r2, l2 = load(tmp_path / "res2")
+    assert r2[0]["world_size"] == 2 and r1[0]["total"] == r2[0]["total"] == 11      # the absent file is not a row
+    assert _strip(r1) == _strip(r2)
+    ids = [row["id"] for row in r2[0]["per_sample"]]
+    assert ids == [f"s{i}" for i in range(11)]                                    # manifest order restored
+    assert sum(1 for row in r2[0]["per_sample"] if row.get("error")) == 1          # the undecodable file, and only it
+    assert [row for row in r2[0]["per_sample"] if row["id"] == "s4"][0]["predicted"] == []
+    assert any(len(row["predicted"]) > 1 for row in r2[0]["per_sample"])           # spans expand to one emission per ayah
+    assert l1[0]["total"] == l2[0]["total"] and l1[0]["recall"] == l2[0]["recall"]
+
+
+def test_shard_plan_deals():
+    from offline_tarteel_amd.dist import shard_plan
+
+    lens = [5, 30, 12, 7, 22, 9, 18]
+    for world in (1, 2, 3, 8):
+        for deal in ("strided", "contiguous"):
+            order, slices = shard_plan(lens, world, deal)
+            assert len(order) % world == 0 and sorted(int(i) for i in order if i >= 0) == list(range(len(lens)))
+            shares = [[int(i) for i in order[s] if i >= 0] for s in slices]
+            for sh in shares:       # every share is sorted longest first
+                assert [lens[i] for i in sh] == sorted((lens[i] for i in sh), reverse=True)
+            if deal == "strided" and world == 2:
+                # balanced: the two shares' total lengths differ by less than the longest clip
+                tot = [sum(lens[i] for i in sh) for sh in shares]
+                assert abs(tot[0] - tot[1]) < max(lens)
+    order, slices = shard_plan([], 4)
+    assert len(order) == 0
+
+
+def test_four_decimal_scores_survive_the_float32_rows():
+    from offline_tarteel_amd.dist import pack_results, unpack_results
+
+    vals = [k / 10000 for k in range(0, 10001)]
+    rows = pack_results([{"surah": 1, "ayah": 1, "ayah_end": None, "score": v} for v in vals])
+    back = unpack_results(rows, round_dp=4)
+    assert [b["score"] for b in back] == vals
