@@ -61,8 +61,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=0,
                     help="utterances per GPU per step (default 64; 256 with --gpus 8 = BASELINE configs[3])")
     ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default 10; 30 for --workload tta30)")
-    ap.add_argument("--workload", choices=("clips", "tta30"), default="clips",
-                    help="clips: the plain hot path; tta30: c2c-direct-mixed-tta on 30 s clips (configs[4])")
+    ap.add_argument("--workload", choices=("clips", "tta30", "strong2048"), default="clips",
+                    help="clips: the plain hot path; tta30: c2c-direct-mixed-tta on 30 s clips (configs[4]); strong2048: ONE ragged "
+                         "global batch of 2,048 clips of 5-30 s dealt to the ranks by dist.shard_plan (strong scaling: a step is the "
+                         "whole global batch, the rows come back through dist.all_gather_results)")
+    ap.add_argument("--deal", choices=("strided", "contiguous"), default="strided", help="strong2048: how shard_plan deals the sorted clips")
     ap.add_argument("--tta-mix", action="store_true",
                     help="tta30 only: the anchor pass's post-logits stages read verse-shaped log-probs at the reference's branch "
                          "ratio (7 of its 53 v1 clips scored < 0.80; qv_profile_inject_logprobs), so that about one clip in eight "
@@ -86,6 +89,8 @@ def parse():
     a = ap.parse_args()
     if a.batch <= 0:
         a.batch = 256 if (a.gpus >= 8 and a.workload == "clips") else 64
+    if a.workload == "strong2048":
+        a.seconds = 30.0
     if a.seconds <= 0:
         a.seconds = 30.0 if a.workload == "tta30" else 10.0
     return a
@@ -244,6 +249,109 @@ def realistic_mix_leg(eng, audio, lengths, B: int, T: int, steps: int, headline:
                     "as the headline line"}
 
 
+def ingest_leg(eng, audio_np, lengths, B: int, T: int, steps: int, headline: float):
+    """The headline loop fed the way a real caller feeds it: every step's batch starts in PINNED HOST memory (8 distinct
+    batches), crosses PCIe on a copy stream into one of a ring of device buffers (one step ahead of the engine), and only then
+    enters qv_predict_batch_async -- so the host-to-device ingest (640 KB per utterance) is inside the timed region and the
+    forward-graph keys rotate with the buffers as they would for a serving loop, instead of one HBM-resident batch replayed
+    through one pointer.  Results are fetched as in the headline loop."""
+    import numpy as np
+    import torch
+
+    n_ctx = eng.contexts
+    n_host, n_dev = 8, n_ctx + 2
+    host = []
+    for k in range(n_host):
+        t = torch.from_numpy(np.roll(audio_np, 997 * k, axis=1).copy() if k else audio_np.copy()).pin_memory()
+        host.append(t)
+    dev = [torch.empty_like(host[0], device=f"cuda:{eng.device}") for _ in range(n_dev)]
+    copy_stream = torch.cuda.Stream(device=eng.device)
+    ready = [torch.cuda.Event() for _ in range(n_dev)]
+    inflight = []
+
+    def upload(i):
+        with torch.cuda.stream(copy_stream):
+            dev[i % n_dev].copy_(host[i % n_host], non_blocking=True)
+            ready[i % n_dev].record(copy_stream)
+
+    def region(k, base):
+        upload(base)
+        for i in range(base, base + k):
+            if i + 1 < base + k:
+                upload(i + 1)                      # one step ahead: the copy of the next batch runs under this batch's forward
+            torch.cuda.current_stream().wait_event(ready[i % n_dev])
+            inflight.append(eng.predict_batch_async(dev[i % n_dev], lengths))
+            if len(inflight) >= n_ctx:
+                # the buffer of the batch joined here is the next one the ring hands out (n_dev = n_ctx + 2 > batches in flight + the one
+                # being uploaded): its audio is never overwritten before its results are on the host
+                eng.fetch_results(inflight.pop(0), B, T)
+        while inflight:
+            eng.fetch_results(inflight.pop(0), B, T)
+        torch.cuda.synchronize()
+
+    region(3 * n_dev, 0)                           # every (context, buffer) pair the timed region will see has been captured
+    g0 = eng.forward_graph_stats()
+    runs = []
+    for r in range(3):
+        t0 = time.perf_counter()
+        region(steps, 1000 * (r + 1))
+        runs.append(time.perf_counter() - t0)
+    g1 = eng.forward_graph_stats()
+    dt = sorted(runs)[1]
+    v = B * steps / dt
+    return {"value": round(v, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "runs_utt_per_s": [round(B * steps / r, 1) for r in runs], "value_is": "median of the three regions",
+            "vs_headline_workload": round(v / headline, 4),
+            "h2d_gb_per_s": round(v * audio_np.shape[1] * 4 / 1e9, 2), "host_batches": n_host, "device_buffers": n_dev,
+            "forward_graph": {"replays": g1["replays"] - g0["replays"], "captures": g1["captures"] - g0["captures"],
+                              "forwards": 3 * steps},
+            "what": f"{n_host} distinct pinned host batches -> H2D on a copy stream one step ahead -> ring of {n_dev} device buffers -> "
+                    "the same engine and batches in flight as the headline line; rows fetched inside the loop"}
+
+
+def strong_plan(world: int, rank: int, deal: str, total: int = 2048, seed: int = 20260630):
+    """the ragged global batch of --workload strong2048: `total` clip lengths drawn uniformly from 5-30 s, dealt by
+    dist.shard_plan; returns (lengths of all clips, order, this rank's original indices longest first)"""
+    import numpy as np
+
+    from offline_tarteel_amd import dist as qdist
+
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(80000, 480001, size=total).astype(np.int64)
+    order, slices = qdist.shard_plan(lengths, world, deal)
+    mine = [int(i) for i in order[slices[rank]]]
+    return lengths, order, mine
+
+
+def strong_pass(eng, base_audio, lengths, mine, per_call: int):
+    """one rank's share of the global batch through the engine, `per_call` clips per engine call (longest first, so a call's
+    clips have similar lengths), batches in flight over the engine's contexts; returns the result rows in the order of `mine`
+    (None for the padding entries).  Clip i is rows i % 64 of the synthetic base batch cut to its length."""
+    import torch
+
+    todo = [i for i in mine if i >= 0]
+    rows_out = {}
+    inflight = []
+
+    def join(t):
+        ctx, idx, buf, t_max = t
+        for i, r in zip(idx, eng.fetch_results(ctx, len(idx), t_max)):
+            rows_out[i] = r
+
+    for s0 in range(0, len(todo), per_call):
+        idx = todo[s0: s0 + per_call]
+        lens = [int(lengths[i]) for i in idx]
+        buf = base_audio[torch.as_tensor([i % base_audio.shape[0] for i in idx], device=base_audio.device), : max(lens)].contiguous()
+        for r, n in enumerate(lens):
+            buf[r, n:] = 0
+        if len(inflight) >= eng.contexts:
+            join(inflight.pop(0))
+        inflight.append((eng.predict_batch_async(buf, lens), idx, buf, eng.frames_for(max(lens))))
+    while inflight:
+        join(inflight.pop(0))
+    return [rows_out.get(i) for i in mine]
+
+
 def cpu_baseline(audio_np, n_clips: int, what: str = "10 s clips"):
     """oracle ("port"): fp32 PyTorch-CPU forward + C post-logits, per-file like the reference."""
     import numpy as np
@@ -353,6 +461,8 @@ def extra_legs():
         # the headline's batch and at the batch that restores its row count (one call holds up to max_batch clips)
         "short_clips_5s_b64": ["--seconds", "5", "--steps", "30", "--warmup", "8"],
         "short_clips_5s_b128": ["--seconds", "5", "--batch", "128", "--steps", "30", "--warmup", "8"],
+        # configs[3]'s global batch as ONE ragged batch of 2,048 clips of 5-30 s through dist.shard_plan (here: one rank takes it all)
+        "configs3_strong_ragged_2048": ["--workload", "strong2048", "--steps", "2", "--warmup", "1"],
     }
     out = {}
     for name, flags in legs.items():
@@ -410,7 +520,8 @@ def main():
     n = int(args.seconds * 16000)
     B = args.batch
     tta = args.workload == "tta30"
-    audio_np = synth_audio(B, n, seed=20260630 + 1000 * rank)
+    strong = args.workload == "strong2048"
+    audio_np = synth_audio(64 if strong else B, n, seed=20260630 + 1000 * rank)
     audio = torch.from_numpy(audio_np).cuda(local_rank).contiguous()
     lengths = [n] * B
     # TTA: the 1.1x-slowed copies are 10 % longer than the clips
@@ -522,7 +633,20 @@ def main():
             ctx = anchor_pass()
             tta_done(tta_start(eng, audio, lengths, want_text=False, anchor_ctx=ctx))
 
-    step = step_tta if tta else step_clips
+    s_lengths = s_order = s_mine = None
+    if strong:
+        from offline_tarteel_amd import dist as qdist
+
+        s_lengths, s_order, s_mine = strong_plan(world, rank, args.deal)
+
+    def step_strong():
+        # the WHOLE global batch: this rank's share through the engine, then the path's one exchange (16 B per utterance)
+        rows = strong_pass(eng, audio, s_lengths, s_mine, B)
+        if use_dist:
+            full = qdist.all_gather_results(torch.from_numpy(qdist.pack_results(rows)).cuda(local_rank), s_order, len(s_lengths))
+            assert full.shape == (len(s_lengths), 4)
+
+    step = step_tta if tta else step_strong if strong else step_clips
 
     def sync_all():
         while tta_prev:
@@ -559,15 +683,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
-    if not tta and not use_dist:
+    value = (len(s_lengths) if strong else world * B) * args.steps / dt
+    if not tta and not strong and not use_dist:
         assert fetched["batches"] == args.steps and fetched["rows"] == B * args.steps, fetched   # every timed batch came back
 
     # The driver's timed region is K = 20 steps (~73 ms): the same loop over a region two orders of magnitude longer, in
     # the same process on the same engine, so that the short region's number is corroborated in the same output line
     # (default line only: one GPU, configs[1]).
     long_region = None
-    if (world == 1 and not tta and not use_dist and args.precision == "fp16" and B == 64 and args.seconds == 10.0
+    if (world == 1 and not tta and not strong and not use_dist and args.precision == "fp16" and B == 64 and args.seconds == 10.0
             and not args.no_extra):
         n_long = 2000
         fetched["batches"] = fetched["rows"] = 0
@@ -582,6 +706,9 @@ def main():
                        "unit": "utterances/s", "note": "same step() as the timed region, run after it"}
 
     # sanity: results come back and look like predictions
+    if strong:
+        audio, lengths = audio[: min(B, 64)].contiguous(), [n] * min(B, 64)
+        B = len(lengths)
     res = eng.predict_batch(audio, lengths, want_text=False)
     if not os.environ.get("QVERSE_SKIP"):   # (timing experiments drop kernels: results are meaningless then)
         assert len(res) == B and all(r["t_frames"] == eng.frames_for(n) for r in res)
@@ -681,12 +808,18 @@ def main():
 
     post = None
     mix = None
+    ingest = None
+    if rank == 0 and not args.no_post_logits and not tta and not strong and world == 1:
+        try:
+            ingest = ingest_leg(eng, audio_np, lengths, B, eng.frames_for(n), max(10, min(args.steps, 30)), value)
+        except Exception as e:
+            ingest = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_post_logits:
         try:
             post = post_logits_legs(eng, min(B, 64), min(126, eng.frames_for(cap)))
         except Exception as e:
             post = {"error": f"{type(e).__name__}: {e}"}
-        if not tta and world == 1:
+        if not tta and not strong and world == 1:
             try:
                 mix = realistic_mix_leg(eng, audio, lengths, B, eng.frames_for(n), max(10, min(args.steps, 30)), value)
             except Exception as e:
@@ -702,7 +835,7 @@ def main():
                    "sample": f"failed: {type(e).__name__}: {e}"}
 
     extra = None
-    default_line = (world == 1 and not tta and args.precision == "fp16" and B == 64 and args.seconds == 10.0)
+    default_line = (world == 1 and not tta and not strong and args.precision == "fp16" and B == 64 and args.seconds == 10.0)
     if rank == 0 and default_line and not args.no_extra:
         eng.close()   # the legs create engines of their own on this GPU
         extra = extra_legs()
@@ -715,7 +848,12 @@ def main():
                  "the reference's onnxruntime arithmetic: int4 (block-128) Linear weights on f16 activations; every Conv as "
                  "DynamicQuantizeLinear (per-utterance uint8 activations) -> ConvInteger (per-tensor int8 weights, int32 "
                  "accumulation: i8 MFMA / exact integer stencils) -> float32 rescale")
-        if tta:
+        if strong:
+            secs = float(s_lengths.sum()) / 16000.0
+            workload = (f"c2c-direct-mixed hot path, ONE ragged global batch of {len(s_lengths)} synthetic clips of 5-30 s ({secs:.0f} audio-seconds) per "
+                        f"step, dealt to {world} rank(s) by dist.shard_plan ({args.deal}), {B} clips per engine call, rows back through "
+                        f"dist.all_gather_results, {wdesc} (BASELINE.json configs[3]'s global batch as a STRONG-scaling workload); seeded random weights")
+        elif tta:
             cfg_name = "BASELINE.json configs[4]" + ("" if world == 8 else f" workload on {world} GPU(s)")
             workload = (f"c2c-direct-mixed-tta hot path, batch={B}/GPU synthetic {args.seconds:g} s/16 kHz clips: anchor pass, "
                         "0.5 confidence gate, GPU 0.9x/1.1x speed-perturbed copies of the gated clips, majority / best-score "
@@ -735,20 +873,25 @@ def main():
                         f"FastConformer-CTC forward ({wdesc}) + greedy decode + verse retrieval + CTC rerank "
                         f"({cfg_name}); seeded random weights (real ONNX absent)")
         out = {
-            "metric": f"utterances/sec ({args.seconds:g} s @16 kHz{', TTA 0.9x/1.0x/1.1x' if tta else ''})",
+            "metric": ("utterances/sec (5-30 s @16 kHz, ragged global batch of 2048)" if strong else
+                       f"utterances/sec ({args.seconds:g} s @16 kHz{', TTA 0.9x/1.0x/1.1x' if tta else ''})"),
             "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f16" if not mixed else "f16 (int4/int8 weights)" if args.precision == "mixed" else "f16 Linear (int4 weights) + u8 x i8 -> i32 Conv",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "global_batch": world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
+                       "global_batch": len(s_lengths) if strong else world * B, "seconds": args.seconds, "parallelism": f"dp{world}",
                        "gate_failed_utterances_per_batch": used_ctc,
                        "skip_unused_passes": not args.literal, "weights": args.precision, "weights_effective": weights_info,
                        "batches_in_flight": n_ctx, "forward_graph": forward_graph, "engine_capacity_seconds": round(cap / 16000.0, 2),
                        "concurrent_streams_probe": int(eng.lib.qv_probe_concurrent_streams())},
-            "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "realistic_mix": mix, "long_region": long_region, "extra": extra,
+            "roofline": roof, "cpu_baseline": cpu, "post_logits": post, "realistic_mix": mix, "ingest": ingest, "long_region": long_region, "extra": extra,
         }
+        if strong:
+            out["audio_seconds_per_s"] = round(float(s_lengths.sum()) / 16000.0 * args.steps / dt, 1)
+            out["config"]["deal"] = args.deal
+            out["config"]["rank0_share_audio_seconds"] = round(float(sum(s_lengths[i] for i in s_mine if i >= 0)) / 16000.0, 1)
         if tta:
             out["config"]["tta_gated_fraction"] = round(tta_stats["gated"] / max(1, tta_stats["clips"]), 3)
         sys.stdout.flush()

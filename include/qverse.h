@@ -176,6 +176,21 @@ int qv_predict_batch_async_ctx(qv_engine *e, const float *audio_dev, const int64
 int qv_upfirdn(qv_engine *e, const float *x_dev, int64_t n_in, const float *taps_host, int32_t n_taps,
                int32_t up, int32_t down, int64_t m0, int64_t n_out, float *y_dev, void *stream);
 
+/* The same FIR over a BATCH of rows in one launch: output row r = resample of source row src_rows_host[r] (NULL: row r) of
+ * x_dev [.., x_pitch], n_in_host[r] samples long; y_dev row r [y_pitch] receives ceil(n_in * up / down) samples followed by
+ * zeros up to y_pitch -- the engine's zero-padded [B, N] input layout, so the result can go straight into qv_predict_batch.
+ * Used by the TTA wrapper (all 0.9x or all 1.1x copies of a batch's gated clips: one launch instead of one per clip) and by
+ * the device ingest of non-16 kHz files (160/441, 1/3: offline-tarteel_amd/audio.py load_audio_device; reference
+ * shared/audio.py:8-18).  Per sample the arithmetic is qv_upfirdn's, term for term.  rows <= 1024.  Asynchronous on
+ * `stream`; the host arrays may be released on return. */
+int qv_upfirdn_batch(qv_engine *e, const float *x_dev, int64_t x_pitch, const int32_t *src_rows_host, const int64_t *n_in_host,
+                     int32_t rows, const float *taps_host, int32_t n_taps, int32_t up, int32_t down, int64_t m0,
+                     float *y_dev, int64_t y_pitch, void *stream);
+/* Interleaved multi-channel rows [frames][channels] (float32) -> mono rows: the float32 mean over the channel axis (sequential
+ * sum, one division), i.e. numpy's x.reshape(-1, ch).mean(axis=1) -- the reference's mix-down (shared/audio.py:13-15). */
+int qv_mixdown_batch(qv_engine *e, const float *x_dev, int64_t x_pitch, const int64_t *n_frames_host, int32_t rows,
+                     int32_t channels, float *y_dev, int64_t y_pitch, void *stream);
+
 /* ---- batches in flight (n_contexts > 1) -------------------------------------------------
  * qv_predict_batch_async() then only ORDERS ITS INPUTS on `stream` (the audio must stay unchanged
  * until the call's results have been joined) and runs on the context's internal stream; a call

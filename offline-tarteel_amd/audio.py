@@ -8,6 +8,9 @@ standard library (PCM 8/16/24/32-bit and IEEE float) and resampled with
 for non-16 kHz sources the samples agree to resampler-design tolerance, not bit-for-bit
 (documented in DESIGN.md); 16 kHz sources (the 29 RetaSy files of the v1 corpus) are exact.
 Compressed formats (mp3/m4a) raise: there is no decoder in this environment.
+
+``load_audio_device(paths, eng)`` (round 6) is the same computation with the mix-down and the polyphase FIR on the GPU
+(qv_mixdown_batch / qv_upfirdn_batch); the plugin's batched entry uses it (QVERSE_INGEST=host switches back).
 """
 
 from __future__ import annotations
@@ -21,7 +24,8 @@ import numpy as np
 TARGET_SR = 16000
 
 
-def _read_wav(path: Path):
+def _decode_wav(path: Path):
+    """-> (interleaved float32 samples, channels, sample rate): the container's PCM as it is, no mix-down, no resampling"""
     data = path.read_bytes()
     if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
         raise ValueError(f"{path}: not a RIFF/WAVE file (no decoder for compressed audio in this environment)")
@@ -57,8 +61,14 @@ def _read_wav(path: Path):
         x = v.astype(np.float32) / 8388608.0
     else:
         raise ValueError(f"{path}: unsupported WAV encoding tag={tag} bits={bits}")
+    ch = max(1, int(ch))
+    return np.ascontiguousarray(x[: len(x) // ch * ch], dtype=np.float32), ch, sr
+
+
+def _read_wav(path: Path):
+    x, ch, sr = _decode_wav(path)
     if ch > 1:
-        x = x[: len(x) // ch * ch].reshape(-1, ch).mean(axis=1)
+        x = x.reshape(-1, ch).mean(axis=1)
     return x.astype(np.float32), sr
 
 
@@ -103,6 +113,48 @@ def resample(audio: np.ndarray, orig_sr: int, target_sr: int) -> np.ndarray:
 def load_audio(path: str, sr: int = TARGET_SR) -> np.ndarray:
     audio, native = _read_wav(Path(path))
     return resample(audio, native, sr)
+
+
+def load_audio_device(paths, eng, sr: int = TARGET_SR):
+    """load_audio for a list of files with the mix-down and the resampling ON THE GPU (reference: shared/audio.py:8-18).
+
+    The host only parses the containers (PCM -> float32, interleaved).  Files that are already mono at ``sr`` are
+    uploaded as they are; every other (sample rate, channel count) group is uploaded interleaved, mixed down by
+    qv_mixdown_batch (numpy's float32 mean over the channels) and resampled by qv_upfirdn_batch with the rational
+    factor sr / native (160/441 for 44.1 kHz, 1/3 for 48 kHz, ...): the float32 polyphase FIR of
+    scipy.signal.resample_poly, bit for bit -- i.e. exactly what load_audio() computes on the host, which differs
+    from the reference's librosa default (soxr_hq, another FIR design) by resampler-design tolerance only
+    (tools/resample_delta.py).  Returns (float32 cuda tensor [len(paths), max length] zero-padded, list of lengths)."""
+    import torch
+
+    dev = torch.device(f"cuda:{eng.device}")
+    decoded = [_decode_wav(Path(p)) for p in paths]
+    groups: dict = {}
+    for i, (x, ch, native) in enumerate(decoded):
+        groups.setdefault((native, ch), []).append(i)
+    rows_of: dict = {}
+    for (native, ch), idx in groups.items():
+        frames = [len(decoded[i][0]) // ch for i in idx]
+        if min(frames) < 1:
+            raise ValueError(f"{paths[idx[frames.index(min(frames))]]}: empty audio")
+        host = np.zeros((len(idx), max(frames) * ch), dtype=np.float32)
+        for r, i in enumerate(idx):
+            host[r, : frames[r] * ch] = decoded[i][0]
+        x = torch.from_numpy(host).to(dev, non_blocking=False)
+        if ch > 1:
+            x = eng.mixdown_rows(x, frames, ch)
+        lens = frames
+        if native != sr:
+            fr = Fraction(sr, native)
+            x, lens = eng.resample_rows(x, frames, fr.numerator, fr.denominator)
+        for r, i in enumerate(idx):
+            rows_of[i] = (x, r, int(lens[r]))
+    lens_out = [rows_of[i][2] for i in range(len(paths))]
+    out = torch.zeros((len(paths), max(lens_out)), dtype=torch.float32, device=dev)
+    for i in range(len(paths)):
+        x, r, n = rows_of[i]
+        out[i, :n] = x[r, :n]
+    return out, lens_out
 
 
 _PLAN_CACHE: dict = {}

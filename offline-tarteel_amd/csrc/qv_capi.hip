@@ -780,30 +780,85 @@ extern "C" int qv_predict_batch(qv_engine *eng, const float *audio_dev, const in
     return qv_fetch_results(eng, batch, eng->last_tmax, res, greedy_host, stream);
 }
 
+static int fir_for(qv_engine *eng, const float *taps, int32_t n_taps, int32_t up, const qv_engine::Fir **out);
+
 extern "C" int qv_upfirdn(qv_engine *eng, const float *x_dev, int64_t n_in, const float *taps, int32_t n_taps, int32_t up,
                           int32_t down, int64_t m0, int64_t n_out, float *y_dev, void *stream) {
     QV_SERIALISE(eng);
     QV_ORDERED(eng, stream);
     if (!eng || !x_dev || !taps || !y_dev || n_in < 1 || n_taps < 1 || up < 1 || down < 1 || m0 < 0 || n_out < 0) return QV_ERR_ARG;
     const qv_engine::Fir *fir = nullptr;
-    for (const auto &f : eng->firs)
-        if (f.up == up && (int)f.taps.size() == n_taps && memcmp(f.taps.data(), taps, sizeof(float) * n_taps) == 0) fir = &f;
-    if (!fir) {
-        // first use of this filter: per-phase, time-reversed rows (what upfirdn builds as h_trans_flip)
-        int P = (n_taps + up - 1) / up;
-        std::vector<float> hf((size_t)up * P, 0.f);
-        for (int t = 0; t < up; ++t)
-            for (int j = 0; j < P; ++j) {
-                int k = t + up * (P - 1 - j);
-                if (k < n_taps) hf[(size_t)t * P + j] = taps[k];
-            }
-        float *d = nullptr;
-        QV_TRY(dalloc(eng, hf.size(), &d));
-        QV_HIP(hipMemcpy(d, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
-        eng->firs.push_back({up, std::vector<float>(taps, taps + n_taps), d, P});
-        fir = &eng->firs.back();
-    }
+    QV_TRY(fir_for(eng, taps, n_taps, up, &fir));
     launch_upfirdn(x_dev, n_in, fir->hflip_dev, fir->P, up, down, m0, n_out, y_dev, (hipStream_t)stream);
+    QV_HIP(hipGetLastError());
+    return QV_OK;
+}
+
+// the per-phase, time-reversed filter rows of (taps, up), uploaded once per distinct filter
+static int fir_for(qv_engine *eng, const float *taps, int32_t n_taps, int32_t up, const qv_engine::Fir **out) {
+    for (const auto &f : eng->firs)
+        if (f.up == up && (int)f.taps.size() == n_taps && memcmp(f.taps.data(), taps, sizeof(float) * n_taps) == 0) { *out = &f; return QV_OK; }
+    int P = (n_taps + up - 1) / up;
+    std::vector<float> hf((size_t)up * P, 0.f);
+    for (int t = 0; t < up; ++t)
+        for (int j = 0; j < P; ++j) {
+            int k = t + up * (P - 1 - j);
+            if (k < n_taps) hf[(size_t)t * P + j] = taps[k];
+        }
+    float *d = nullptr;
+    QV_TRY(dalloc(eng, hf.size(), &d));
+    QV_HIP(hipMemcpy(d, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+    eng->firs.push_back({up, std::vector<float>(taps, taps + n_taps), d, P});
+    *out = &eng->firs.back();
+    return QV_OK;
+}
+
+extern "C" int qv_upfirdn_batch(qv_engine *eng, const float *x_dev, int64_t x_pitch, const int32_t *src_rows_host,
+                                const int64_t *n_in_host, int32_t rows, const float *taps, int32_t n_taps, int32_t up, int32_t down,
+                                int64_t m0, float *y_dev, int64_t y_pitch, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
+    if (!eng || !x_dev || !n_in_host || !taps || !y_dev || rows < 1 || rows > QV_RESAMPLE_ROWS || n_taps < 1 || up < 1 || down < 1 || m0 < 0 ||
+        x_pitch < 1 || y_pitch < 1)
+        return QV_ERR_ARG;
+    for (int r = 0; r < rows; ++r) {
+        if (n_in_host[r] < 1 || n_in_host[r] > x_pitch) { qv_set_error(eng, "qv_upfirdn_batch: a row's length is outside [1, x_pitch]"); return QV_ERR_ARG; }
+        if ((n_in_host[r] * up + down - 1) / down > y_pitch) { qv_set_error(eng, "qv_upfirdn_batch: y_pitch is shorter than a row's output"); return QV_ERR_ARG; }
+        if (src_rows_host && src_rows_host[r] < 0) return QV_ERR_ARG;
+    }
+    const qv_engine::Fir *fir = nullptr;
+    QV_TRY(fir_for(eng, taps, n_taps, up, &fir));
+    // row table: [QV_RESAMPLE_ROWS] int64 lengths + int32 source rows, one slot of a small ring per call (the copy is issued
+    // from pageable memory: the runtime stages it before this function returns, so the host vectors may go away)
+    if (!eng->resample_tab) QV_TRY(dalloc(eng, (size_t)QV_RESAMPLE_SLOTS * QV_RESAMPLE_ROWS * 12, &eng->resample_tab));
+    unsigned char *slot = eng->resample_tab + (size_t)(eng->resample_at++ % QV_RESAMPLE_SLOTS) * QV_RESAMPLE_ROWS * 12;
+    hipStream_t s = (hipStream_t)stream;
+    QV_HIP(hipMemcpyAsync(slot, n_in_host, sizeof(int64_t) * rows, hipMemcpyHostToDevice, s));
+    int32_t *src_dev = nullptr;
+    if (src_rows_host) {
+        src_dev = (int32_t *)(slot + (size_t)QV_RESAMPLE_ROWS * 8);
+        QV_HIP(hipMemcpyAsync(src_dev, src_rows_host, sizeof(int32_t) * rows, hipMemcpyHostToDevice, s));
+    }
+    launch_upfirdn_rows(x_dev, x_pitch, src_dev, (const int64_t *)slot, rows, fir->hflip_dev, fir->P, up, down, m0, y_dev, y_pitch, s);
+    QV_HIP(hipGetLastError());
+    return QV_OK;
+}
+
+extern "C" int qv_mixdown_batch(qv_engine *eng, const float *x_dev, int64_t x_pitch, const int64_t *n_frames_host, int32_t rows,
+                                int32_t channels, float *y_dev, int64_t y_pitch, void *stream) {
+    QV_SERIALISE(eng);
+    QV_ORDERED(eng, stream);
+    if (!eng || !x_dev || !n_frames_host || !y_dev || rows < 1 || rows > QV_RESAMPLE_ROWS || channels < 1 || channels > 64) return QV_ERR_ARG;
+    int64_t mx = 0;
+    for (int r = 0; r < rows; ++r) {
+        if (n_frames_host[r] < 0 || n_frames_host[r] * channels > x_pitch || n_frames_host[r] > y_pitch) return QV_ERR_ARG;
+        mx = n_frames_host[r] > mx ? n_frames_host[r] : mx;
+    }
+    if (!eng->resample_tab) QV_TRY(dalloc(eng, (size_t)QV_RESAMPLE_SLOTS * QV_RESAMPLE_ROWS * 12, &eng->resample_tab));
+    unsigned char *slot = eng->resample_tab + (size_t)(eng->resample_at++ % QV_RESAMPLE_SLOTS) * QV_RESAMPLE_ROWS * 12;
+    hipStream_t s = (hipStream_t)stream;
+    QV_HIP(hipMemcpyAsync(slot, n_frames_host, sizeof(int64_t) * rows, hipMemcpyHostToDevice, s));
+    launch_mixdown(x_dev, x_pitch, (const int64_t *)slot, rows, channels, y_dev, y_pitch, mx, s);
     QV_HIP(hipGetLastError());
     return QV_OK;
 }

@@ -169,6 +169,8 @@ struct QvKnobs {
 // verse tracker workspace (qv_tracker_match): QV_TRACK_CAP texts per launch
 #define QV_TRACK_CAP 256
 #define QV_TRACK_BLOCKS 32   // >= ceil(n_verses / 256) partial maxima per text
+#define QV_RESAMPLE_ROWS 1024   // rows per qv_upfirdn_batch / qv_mixdown_batch call
+#define QV_RESAMPLE_SLOTS 16    // calls whose row tables may be in flight on a stream at once
 struct QvTrack {
     uint8_t *q;          // [CAP * QV_MAXQ] codes of the slice's texts, back to back
     int32_t *meta;       // [CAP][4] q_len, n_words, bonus verse, offset in q
@@ -266,6 +268,8 @@ struct qv_engine {
     // resampler filters already arranged per phase and resident in HBM (qv_upfirdn)
     struct Fir { int up; std::vector<float> taps; float *hflip_dev; int P; };
     std::vector<Fir> firs;
+    unsigned char *resample_tab = nullptr;   // ring of row tables for qv_upfirdn_batch / qv_mixdown_batch
+    unsigned resample_at = 0;
     QvTrack track;
     bool profile_stages;
     // measurement hook (qv_profile_inject_logprobs): caller-owned log-probs the post-logits stages of

@@ -42,5 +42,9 @@ void launch_dwconv1d(const half_t *x, const float *w, const float *bias, const i
 void launch_logsoftmax(const float *logits, int ld, float *out, int M, const int32_t *row_map, int t_out, hipStream_t s);
 // zeros rows [len[b], t_out) of every utterance of a dense [B][t_out][1025] tensor; t_min = the shortest utterance's frames
 void launch_zero_pad_rows(float *out, const int32_t *len, int t_out, int t_min, int batch, hipStream_t s);
+void launch_upfirdn_rows(const float *x, int64_t x_pitch, const int32_t *src, const int64_t *n_in_rows, int rows, const float *hflip,
+                         int P, int up, int down, int64_t m0, float *y, int64_t y_pitch, hipStream_t s);
+void launch_mixdown(const float *x, int64_t x_pitch, const int64_t *n_frames, int rows, int channels, float *y, int64_t y_pitch,
+                    int64_t max_frames, hipStream_t s);
 void launch_upfirdn(const float *x, int64_t n_in, const float *hflip, int P, int up, int down, int64_t m0, int64_t n_out,
                     float *y, hipStream_t s);

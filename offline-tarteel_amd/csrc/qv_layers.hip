@@ -1382,7 +1382,63 @@ __global__ __launch_bounds__(256) void k_upfirdn(const float *__restrict__ x, in
     for (int64_t i = first + j0; i <= last; ++i) acc = __fadd_rn(acc, __fmul_rn(x[i], h[i - first]));
     y[m] = acc;
 }
+// The same FIR for a BATCH of rows in one launch (round 6: the TTA wrapper's 0.9x / 1.1x copies of every gated clip, the
+// 44.1 / 48 kHz -> 16 kHz ingest of audio.load_audio_device): output row r reads source row src[r] (or r) of x, n_in[r]
+// samples long, writes ceil(n_in[r] * up / down) samples and zeroes the rest of its pitch -- the engine's [B, N]
+// zero-padded input layout.  Per output sample the arithmetic is k_upfirdn's, term for term.
+__global__ __launch_bounds__(256) void k_upfirdn_rows(const float *__restrict__ x, int64_t x_pitch, const int32_t *__restrict__ src,
+                                                      const int64_t *__restrict__ n_in_rows, const float *__restrict__ hflip,
+                                                      int P, int up, int down, int64_t m0, float *__restrict__ y, int64_t y_pitch) {
+    const int r = blockIdx.y;
+    const int64_t n_in = n_in_rows[r];
+    const int64_t n_out = (n_in * up + down - 1) / down;
+    const float *xr = x + (size_t)(src ? src[r] : r) * x_pitch;
+    float *yr = y + (size_t)r * y_pitch;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < y_pitch; m += (int64_t)gridDim.x * 256) {
+        if (m >= n_out) { yr[m] = 0.f; continue; }
+        int64_t pos = (m0 + m) * down;
+        int64_t xi = pos / up;
+        int t = (int)(pos - xi * up);
+        const float *h = hflip + (size_t)t * P;
+        int64_t first = xi - (P - 1);
+        int j0 = first < 0 ? (int)(-first) : 0;
+        int64_t last = xi < n_in - 1 ? xi : n_in - 1;
+        float acc = 0.f;
+        for (int64_t i = first + j0; i <= last; ++i) acc = __fadd_rn(acc, __fmul_rn(xr[i], h[i - first]));
+        yr[m] = acc;
+    }
+}
+
+// interleaved [frames][channels] float32 -> mono: numpy's float32 mean over the channel axis (sequential sum, one
+// division by the channel count), what audio._read_wav / the reference's soundfile fallback do (shared/audio.py:13-15)
+__global__ __launch_bounds__(256) void k_mixdown(const float *__restrict__ x, int64_t x_pitch, const int64_t *__restrict__ n_frames,
+                                                 int channels, float *__restrict__ y, int64_t y_pitch) {
+    const int r = blockIdx.y;
+    const int64_t n = n_frames[r];
+    const float *xr = x + (size_t)r * x_pitch;
+    float *yr = y + (size_t)r * y_pitch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float acc = xr[i * channels];
+        for (int c = 1; c < channels; ++c) acc = __fadd_rn(acc, xr[i * channels + c]);
+        yr[i] = __fdiv_rn(acc, (float)channels);
+    }
+}
 }  // namespace
+
+void launch_upfirdn_rows(const float *x, int64_t x_pitch, const int32_t *src, const int64_t *n_in_rows, int rows, const float *hflip,
+                         int P, int up, int down, int64_t m0, float *y, int64_t y_pitch, hipStream_t s) {
+    if (rows <= 0 || y_pitch <= 0) return;
+    const int64_t bx = (y_pitch + 255) / 256;
+    hipLaunchKernelGGL(k_upfirdn_rows, dim3((unsigned)(bx < 4096 ? bx : 4096), rows), dim3(256), 0, s, x, x_pitch, src, n_in_rows, hflip, P, up,
+                       down, m0, y, y_pitch);
+}
+
+void launch_mixdown(const float *x, int64_t x_pitch, const int64_t *n_frames, int rows, int channels, float *y, int64_t y_pitch,
+                    int64_t max_frames, hipStream_t s) {
+    if (rows <= 0 || max_frames <= 0) return;
+    const int64_t bx = (max_frames + 255) / 256;
+    hipLaunchKernelGGL(k_mixdown, dim3((unsigned)(bx < 4096 ? bx : 4096), rows), dim3(256), 0, s, x, x_pitch, n_frames, channels, y, y_pitch);
+}
 
 void launch_upfirdn(const float *x, int64_t n_in, const float *hflip, int P, int up, int down, int64_t m0, int64_t n_out,
                     float *y, hipStream_t s) {

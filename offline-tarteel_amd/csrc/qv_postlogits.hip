@@ -183,13 +183,31 @@ __device__ int block_topk_select(const double *sc, int n, int K, uint32_t *scrat
     return K;
 }
 
+#ifndef QV_LCS_ADDC
+#define QV_LCS_ADDC 1   // 0: the compiler's own carry chain (cross-check builds)
+#endif
 // ------------------------------------------------------------------ bit-parallel LCS ---
 // Hyyro/Crochemore: V all ones; per text char U = V & M; V = (V + U) | (V & ~M).
 // pm: match masks [sym][stride] (u64), W words used; text codes >= QV_NSYM match nothing.
 // lcs_chunk advances the recurrence over the first cnt (<= 8) codes packed in `chunk`; lcs_feed continues it over n
 // more text codes (V carries the state); lcs_count reads the LCS length of everything fed so far: LCS(pattern, text[:j]) is
 // available at every j of one walk over the text.
-template <int W>
+// 64-bit a + b + carry-in -> sum, carry-out, with the carry held as a LANE MASK in an SGPR pair (v_addc_co_u32's VOP3 form takes any
+// pair as carry source and destination): two instructions per word.  The generic lowering of __builtin_addcll costs two 64-bit
+// adds, two 64-bit compares and the selects that turn them into a carry value -- the window scans, the full-string pass and the
+// span pass are bound by VALU issue (profiles/r06_c_pmc_post.txt: 202 M / 82 M / 118 M VALU instructions per launch), and the carry
+// was half of a word-step's instructions.
+__device__ __forceinline__ uint64_t addc64(uint64_t a, uint64_t b, unsigned long long &carry) {
+    uint32_t lo, hi;
+    asm("v_addc_co_u32 %0, %2, %3, %4, %2\n\tv_addc_co_u32 %1, %2, %5, %6, %2"
+        : "=&v"(lo), "=&v"(hi), "+s"(carry)
+        : "v"((uint32_t)a), "v"((uint32_t)b), "v"((uint32_t)(a >> 32)), "v"((uint32_t)(b >> 32)));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ZROW: the mask table has an all-zero row at index QV_NSYM (the LDS copies: load_pm_lds, k_frag's slice): codes past cnt
+// and codes outside the alphabet select THAT row, instead of a select per mask word (2 of a word-step's ~10 instructions).
+template <int W, bool ZROW = false>
 __device__ __forceinline__ void lcs_chunk(uint64_t (&V)[W], const uint64_t *__restrict__ pm, int stride, uint64_t chunk, int cnt) {
     // The match masks of CH consecutive codes are requested TOGETHER, before the dependent add chain
     // of those steps: the recurrence is one serial chain per lane, and a mask load inside every step
@@ -204,21 +222,21 @@ __device__ __forceinline__ void lcs_chunk(uint64_t (&V)[W], const uint64_t *__re
         for (int e = 0; e < CH; ++e) {
             int c = (int)((chunk >> (8 * (g0 + e))) & 0xFF);
             const bool valid = g0 + e < cnt && c < QV_NSYM;
-            const uint64_t *M = pm + (size_t)(valid ? c : 0) * stride;
+            const uint64_t *M = pm + (size_t)(valid ? c : (ZROW ? QV_NSYM : 0)) * stride;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 uint64_t x = M[w];
-                mk[e][w] = valid ? x : 0ull;
+                mk[e][w] = (ZROW || valid) ? x : 0ull;
             }
         }
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
-            unsigned long long carry = 0;
+            unsigned long long carry = 0;   // lane mask of the carries (addc64)
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 uint64_t v = V[w], mm = mk[e][w];
-                // v + (v & mm) + carry with the carry chained through the words (add / addc)
-                uint64_t s2 = __builtin_addcll(v, v & mm, carry, &carry);
+                // v + (v & mm) + carry with the carry chained through the words
+                uint64_t s2 = QV_LCS_ADDC ? addc64(v, v & mm, carry) : __builtin_addcll(v, v & mm, carry, &carry);
                 V[w] = s2 | (v & ~mm);
             }
         }
@@ -227,7 +245,7 @@ __device__ __forceinline__ void lcs_chunk(uint64_t (&V)[W], const uint64_t *__re
 
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
-template <int W>
+template <int W, bool ZROW = false>
 __device__ __forceinline__ void lcs_feed(uint64_t (&V)[W], const uint64_t *__restrict__ pm, int stride,
                                          const uint8_t *__restrict__ text, int n) {
     // the text is fetched 8 codes per (possibly unaligned) load: one memory access per 8 steps
@@ -238,7 +256,7 @@ __device__ __forceinline__ void lcs_feed(uint64_t (&V)[W], const uint64_t *__res
     for (int j0 = 0; j0 < n; j0 += 8) {
         const uint64_t chunk = next;
         if (j0 + 8 < n) next = *(const u64_unaligned *)(text + j0 + 8);
-        lcs_chunk<W>(V, pm, stride, chunk, n - j0 < 8 ? n - j0 : 8);
+        lcs_chunk<W, ZROW>(V, pm, stride, chunk, n - j0 < 8 ? n - j0 : 8);
     }
 }
 
@@ -255,26 +273,27 @@ __device__ __forceinline__ int lcs_count(const uint64_t (&V)[W], int m) {
     return zeros;
 }
 
-template <int W>
+template <int W, bool ZROW = false>
 __device__ __forceinline__ int lcs_core(const uint64_t *__restrict__ pm, int stride, const uint8_t *__restrict__ text,
                                         int n, int m) {
     uint64_t V[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
-    lcs_feed<W>(V, pm, stride, text, n);
+    lcs_feed<W, ZROW>(V, pm, stride, text, n);
     return lcs_count<W>(V, m);
 }
 
+template <bool ZROW = false>
 __device__ __forceinline__ int lcs_dispatch(int W, const uint64_t *pm, int stride, const uint8_t *text, int n, int m) {
     if (n <= 0 || m <= 0) return 0;
-    if (W <= 1) return lcs_core<1>(pm, stride, text, n, m);
-    if (W <= 2) return lcs_core<2>(pm, stride, text, n, m);
-    if (W <= 3) return lcs_core<3>(pm, stride, text, n, m);
-    if (W <= 4) return lcs_core<4>(pm, stride, text, n, m);
-    if (W <= 6) return lcs_core<6>(pm, stride, text, n, m);
-    if (W <= 8) return lcs_core<8>(pm, stride, text, n, m);
-    if (W <= 11) return lcs_core<11>(pm, stride, text, n, m);
-    return lcs_core<16>(pm, stride, text, n, m);
+    if (W <= 1) return lcs_core<1, ZROW>(pm, stride, text, n, m);
+    if (W <= 2) return lcs_core<2, ZROW>(pm, stride, text, n, m);
+    if (W <= 3) return lcs_core<3, ZROW>(pm, stride, text, n, m);
+    if (W <= 4) return lcs_core<4, ZROW>(pm, stride, text, n, m);
+    if (W <= 6) return lcs_core<6, ZROW>(pm, stride, text, n, m);
+    if (W <= 8) return lcs_core<8, ZROW>(pm, stride, text, n, m);
+    if (W <= 11) return lcs_core<11, ZROW>(pm, stride, text, n, m);
+    return lcs_core<16, ZROW>(pm, stride, text, n, m);
 }
 
 // ---- the same recurrence with the pattern's words spread over G neighbouring lanes (G = 4, 8, 16; lane w of the group
@@ -328,9 +347,13 @@ __device__ __forceinline__ int lcs_systolic(const uint64_t *__restrict__ pm, int
 #ifndef QV_PMS
 #define QV_PMS (QV_MAXW + 2)   // 144 B rows: 16-byte aligned for ds_read_b128, 16 distinct bank offsets
 #endif
+#define QV_PM_ROWS (QV_NSYM + 1)   // rows per pattern of an LDS copy: the alphabet + one all-zero row (lcs_chunk<W, true>)
 __device__ __forceinline__ void load_pm_lds(uint64_t *spm, const uint64_t *gpm) {
-    for (int i = threadIdx.x; i < 2 * QV_NSYM * QV_MAXW; i += blockDim.x)
-        spm[(i / QV_MAXW) * QV_PMS + (i % QV_MAXW)] = gpm[i];
+    for (int i = threadIdx.x; i < 2 * QV_NSYM * QV_MAXW; i += blockDim.x) {
+        const int row = i / QV_MAXW, p = row / QV_NSYM;
+        spm[(p * QV_PM_ROWS + row - p * QV_NSYM) * QV_PMS + (i % QV_MAXW)] = gpm[i];
+    }
+    for (int i = threadIdx.x; i < 2 * QV_PMS; i += blockDim.x) spm[((i / QV_PMS) * QV_PM_ROWS + QV_NSYM) * QV_PMS + (i % QV_PMS)] = 0ull;
     __syncthreads();
 }
 
@@ -710,7 +733,8 @@ __device__ __forceinline__ TextRef text_of(const QvTables &tab, int v, int varia
 #endif
 #define FRAG_SCRATCH 2112      // int16 per wave: anchors [QV_MAXQ / 4 + 2] + refine list [QV_MAXQ]
 #define FRAG_GRID 1024         // blocks of k_frag (4 waves each): four per CU, the list is consumed by whoever is free
-__device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane, int16_t *scratch) {
+#define FRAG_PM_STRIDE (QV_MAXW + 1)   // u64 per symbol row of the wave's LDS copy of the pattern masks (odd: rows spread over the banks)
+__device__ __forceinline__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane, int16_t *scratch, uint64_t *lpm) {
     const QvUtt &u = wk.utt[b];
     double *out = wk.fs + ((size_t)b * tab.n_verses + v) * 3 + variant;
     if (variant == 2 && tab.nobsm_len[v] == 0) { if (lane == 0) *out = -1.0; return; }
@@ -772,13 +796,25 @@ __device__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, in
         }
     }
     int16_t *cv = scratch, *list = scratch + FRAG_SCRATCH / 2;
+    if (nwin > 0) {
+        // Round 6: the pattern's match masks (40 symbols x W words) move into the wave's own LDS slice for the scan (row
+        // QV_NSYM of the slice stays all zero: lcs_chunk<W, true>).  Every step of every window reads W mask words of ITS code:
+        // ds_read instead of flat gathers over up to 40 global rows, and no select per mask word; the copy costs ~5 loads per
+        // lane per item.
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < QV_NSYM * W; i += 64) {
+            const int c = i / W, w = i - c * W;
+            lpm[c * FRAG_PM_STRIDE + w] = pm[(size_t)c * stride + w];
+        }
+        QV_WSYNC();
+    }
     const bool direct = nwin <= FRAG_DIRECT_MAX;
     const int nco = (nwin + FRAG_STEP - 1) / FRAG_STEP;       // anchors k * FRAG_STEP, k < nco; cv[nco] = last window
     int nlist = direct ? nwin : nco + 1;
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = lane; i < nlist; i += 64) {
             int w = pass ? (int)list[i] : (direct ? i : (i < nco ? FRAG_STEP * i : nwin - 1));
-            int r = lcs_dispatch(W, pm, stride, lt + w, s, s);
+            int r = lcs_dispatch<true>(W, lpm, FRAG_PM_STRIDE, lt + w, s, s);
             if (!pass && !direct) cv[i] = (int16_t)r;
             best = max(best, r);
         }
@@ -832,7 +868,7 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
     const QvUtt &u = wk.utt[b];
     if (u.q_len == 0) return;
     const int m = u.q_len, ms = u.qs_len, W = (m + 63) >> 6, N = tab.n_verses, qw = u.q_words;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
+    __shared__ uint64_t spm[2 * QV_PM_ROWS * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     const uint64_t *pm = spm;
     const int32_t *cand1 = wk.cand1 + (size_t)b * N;
@@ -849,7 +885,7 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
             variant = j % 3;
             if (variant == 2) {         // pass 3
                 wk.lcs_p3[(size_t)b * N + v] =
-                    (int16_t)lcs_dispatch((ms + 63) >> 6, spm + QV_NSYM * QV_PMS, QV_PMS, tab.clean + tab.clean_off[v], tab.clean_len[v], ms);
+                    (int16_t)lcs_dispatch<true>((ms + 63) >> 6, spm + QV_PM_ROWS * QV_PMS, QV_PMS, tab.clean + tab.clean_off[v], tab.clean_len[v], ms);
                 continue;
             }
             if (u.full_scan) continue;  // search(): pass 1 already scored every verse
@@ -857,7 +893,7 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
         double *fs = wk.fs + ((size_t)b * N + v) * 3 + variant;
         if (variant == 2 && tab.nobsm_len[v] == 0) { *fs = -1.0; continue; }
         TextRef t = text_of(tab, v, variant);
-        const int l = lcs_dispatch(W, pm, QV_PMS, t.p, t.n, m);
+        const int l = lcs_dispatch<true>(W, pm, QV_PMS, t.p, t.n, m);
         out[v * 3 + variant] = (int16_t)l;
         const int n = t.n, vw = t.nw;
         const double fr = ratio_from(l, m, n);
@@ -907,14 +943,17 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
 // long text (hundreds of windows of a 16-word pattern) does not hold a fixed share of the list hostage.
 __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk) {
     __shared__ int16_t frag_scratch[4][FRAG_SCRATCH];
+    __shared__ uint64_t frag_pm[4][QV_PM_ROWS * FRAG_PM_STRIDE];
     int16_t *scratch = frag_scratch[threadIdx.x >> 6];
+    uint64_t *lpm = frag_pm[threadIdx.x >> 6];
+    for (int i = threadIdx.x & 63; i < FRAG_PM_STRIDE; i += 64) lpm[QV_NSYM * FRAG_PM_STRIDE + i] = 0ull;   // the all-zero row
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
     const int n_items = wk.frag_ctr[0];
     int idx = wave;
     while (idx < n_items) {
         const uint32_t it = wk.frag_list[idx];
-        frag_job(tab, wk, (int)(it >> 15), (int)((it >> 2) & 0x1FFFu), (int)(it & 3u), lane, scratch);
+        frag_job(tab, wk, (int)(it >> 15), (int)((it >> 2) & 0x1FFFu), (int)(it & 3u), lane, scratch, lpm);
         int nx = 0;
         if (lane == 0) nx = atomicAdd(&wk.frag_ctr[1], 1);
         idx = nwave + __shfl(nx, 0);
@@ -1049,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
+    __shared__ uint64_t spm[2 * QV_PM_ROWS * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     if (u.q_len > 0) {
         int m = u.q_len, W = (m + 63) >> 6;
@@ -1175,8 +1214,9 @@ __device__ __forceinline__ uint64_t lcs_systolic_chunks(const uint64_t *__restri
         for (int k = 0; k < 8; ++k) {
             const int code = (int)((chunk >> (8 * k)) & 0xFF);
             const bool valid = act && code < QV_NSYM;
-            const uint64_t x = pm[(size_t)(valid ? code : 0) * stride + (act ? w : 0)];
-            mk[k] = valid ? x : 0ull;           // a zero mask leaves V alone and produces no carry
+            // (pm is always load_pm_lds's copy here: invalid codes and idle lanes read its all-zero row -- a zero mask leaves V
+            // alone and produces no carry)
+            mk[k] = pm[(size_t)(valid ? code : QV_NSYM) * stride + (act ? w : 0)];
         }
         cout8 = 0;
 #pragma unroll
@@ -1206,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_spans2(QvTables tab, QvWork wk, QvKnobs
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
-    __shared__ uint64_t spm[2 * QV_NSYM * QV_PMS];
+    __shared__ uint64_t spm[2 * QV_PM_ROWS * QV_PMS];
     load_pm_lds(spm, wk.pm + (size_t)b * 2 * QV_NSYM * QV_MAXW);
     if (u.q_len > 0) {
         const int m = u.q_len, W = (m + 63) >> 6;
@@ -1275,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_spans2(QvTables tab, QvWork wk, QvKnobs
                         for (; pos < end; pos += 8) {
                             const uint64_t chunk = next;
                             next = *(const uint64_t *)(tab.clean8 + pos + 8);       // (the array is padded by 64 filler codes)
-                            lcs_chunk<WW>(V, pm, QV_PMS, chunk, 8);
+                            lcs_chunk<WW, true>(V, pm, QV_PMS, chunk, 8);
                         }
                         if (j.surv >> e & 1u) score(lcs_count<WW>(V, m), j, e);
                     }

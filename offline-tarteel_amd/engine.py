@@ -107,6 +107,8 @@ def load_library(path: Path | str | None = None) -> C.CDLL:
     lib.qv_packed_results_dev.argtypes = [vp]
     lib.qv_packed_results_dev.restype = vp
     lib.qv_upfirdn.argtypes = [vp, vp, i64, vp, i32, i32, i32, i64, i64, vp, vp]
+    lib.qv_upfirdn_batch.argtypes = [vp, vp, i64, vp, vp, i32, vp, i32, i32, i32, i64, vp, i64, vp]
+    lib.qv_mixdown_batch.argtypes = [vp, vp, i64, vp, i32, i32, vp, i64, vp]
     lib.qv_context_count.argtypes = [vp]
     lib.qv_probe_concurrent_streams.argtypes = []
     lib.qv_last_context.argtypes = [vp]
@@ -362,6 +364,50 @@ class Engine:
                                  up, down, m0, n_out, C.c_void_p(y.data_ptr()), self._stream())
         self._check(rc, "qv_upfirdn")
         return y
+
+    def resample_rows(self, x, lengths, up: int, down: int, src_rows=None, out_pitch: int | None = None):
+        """scipy.signal.resample_poly(row, up, down) for every row of a float32 cuda matrix in ONE launch (qv_upfirdn_batch):
+        x [R0, pitch] holds the clips zero-padded, ``lengths`` their sample counts; ``src_rows`` (optional) picks which rows
+        of x are resampled (output row r <- x[src_rows[r]], lengths[r] = that clip's length).  Returns (y [R, out_pitch]
+        zero-padded like x, list of output lengths).  Every output sample is bit-identical to resample_poly's float32 one."""
+        from .audio import resample_plan
+
+        torch = self.torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        lens = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        rows = len(lens)
+        plan = [resample_plan(up, down, int(n)) for n in sorted(set(lens.tolist()))]
+        up_r, down_r, m0 = plan[0][0], plan[0][1], plan[0][3]
+        if up_r == down_r == 1:
+            y = x if src_rows is None else x[torch.as_tensor(list(src_rows), device=x.device)]
+            return y.clone(), lens.tolist()
+        # one filter for the whole batch: the longest zero padding any row's length asks for (padding taps add exact zeros)
+        taps = max((p[2] for p in plan), key=len)
+        n_out = [int((int(n) * up_r + down_r - 1) // down_r) for n in lens]
+        pitch = int(out_pitch or max(n_out))
+        assert pitch >= max(n_out)
+        y = torch.empty((rows, pitch), dtype=torch.float32, device=x.device)
+        src = None if src_rows is None else np.ascontiguousarray(np.asarray(list(src_rows), dtype=np.int32))
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+        rc = self.lib.qv_upfirdn_batch(self.h, C.c_void_p(x.data_ptr()), int(x.stride(0)), p(src), p(lens), rows, p(taps), len(taps),
+                                       up_r, down_r, m0, C.c_void_p(y.data_ptr()), pitch, self._stream())
+        self._check(rc, "qv_upfirdn_batch")
+        return y, n_out
+
+    def mixdown_rows(self, x, n_frames, channels: int):
+        """interleaved [R, frames * channels] float32 cuda rows -> mono [R, max frames] (numpy's float32 mean over channels)"""
+        torch = self.torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        nf = np.ascontiguousarray(np.asarray(n_frames, dtype=np.int64))
+        y = torch.zeros((len(nf), int(nf.max())), dtype=torch.float32, device=x.device)
+        rc = self.lib.qv_mixdown_batch(self.h, C.c_void_p(x.data_ptr()), int(x.stride(0)), nf.ctypes.data_as(C.c_void_p), len(nf), int(channels),
+                                       C.c_void_p(y.data_ptr()), int(y.stride(0)), self._stream())
+        self._check(rc, "qv_mixdown_batch")
+        return y
+
+    def speed_perturb_rows(self, x, lengths, factor: float, src_rows=None):
+        """the TTA wrapper's speed perturbation (tta/run.py:60-71: up = int(factor * 10), down = 10) of many clips at once"""
+        return self.resample_rows(x, lengths, int(factor * 10), 10, src_rows=src_rows)
 
     def speed_perturb(self, x, factor: float):
         """0.9 = 10 % slower, 1.1 = 10 % faster (tta/run.py:60-71: up = int(factor * 10), down = 10)."""

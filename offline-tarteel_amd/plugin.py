@@ -102,8 +102,27 @@ def predict_arrays(arrays, round_score: bool = True) -> list[dict]:
     return out
 
 
+def predict_device(dev, lens, round_score: bool = True) -> list[dict]:
+    """a zero-padded float32 cuda matrix of 16 kHz clips -> predict()-shaped dicts, one engine call per <= MAX_BATCH rows"""
+    eng = _ensure_engine()
+    out = []
+    for s in range(0, len(lens), eng.max_batch):
+        chunk = lens[s: s + eng.max_batch]
+        raw = eng.predict_batch(dev[s: s + len(chunk), : max(chunk)].contiguous(), chunk)
+        _last_raw[:] = raw
+        out.extend(_to_dict(r, round_score) for r in raw)
+    return out
+
+
 def predict_batch(audio_paths) -> list[dict]:
-    return predict_arrays([load_audio(p) for p in audio_paths])
+    """files -> dicts.  The ingest (mix-down, resampling to 16 kHz) runs on the GPU (audio.load_audio_device: the same float32
+    arithmetic as the host load_audio, bit for bit); QVERSE_INGEST=host keeps it on the host."""
+    if os.getenv("QVERSE_INGEST", "device") == "host":
+        return predict_arrays([load_audio(p) for p in audio_paths])
+    from .audio import load_audio_device
+
+    dev, lens = load_audio_device(list(audio_paths), _ensure_engine())
+    return predict_device(dev, lens)
 
 
 def predict(audio_path: str) -> dict:
@@ -178,44 +197,50 @@ def tta_start(eng, audio, lengths, want_text: bool = True, anchor_ctx: int | Non
     """First half of tta_device_batch: the anchor results (run here, or fetched from context `anchor_ctx` when the
     caller already launched the anchor pass with predict_batch_async), the 0.5 gate, and the 0.9x / 1.1x copies
     of the gated clips launched as further batches.  With one context those batches are finished here; with more
-    they stay in flight until tta_finish() -- a serving loop can launch the next batch's anchor pass in between."""
-    torch = eng.torch
+    they stay in flight until tta_finish() -- a serving loop can launch the next batch's anchor pass in between.
+
+    Round 6: the copies of ALL gated clips of one speed are made by ONE launch (Engine.speed_perturb_rows ->
+    qv_upfirdn_batch, straight into the engine's zero-padded input layout) and travel as one batch per speed -- rows of
+    similar length, and only the slowed copies can exceed 384 frames -- instead of one launch + one row copy per clip and
+    batches that interleave the two speeds."""
     if anchor_ctx is None:
         raw = eng.predict_batch(audio, lengths, want_text=want_text)
     else:
         raw = eng.fetch_results(anchor_ctx, len(lengths), eng.frames_for(max(lengths)), want_text=want_text)
     anchors = [_to_dict(r, False) for r in raw]
     hard = [i for i, a in enumerate(anchors) if a["score"] < CONFIDENCE_SKIP_THRESHOLD]
-    st = {"anchors": anchors, "out": list(anchors), "tickets": [], "want_text": want_text}
-    per_call = max(1, eng.max_batch // 2)
-    for s0 in range(0, len(hard), per_call):
-        idx = hard[s0: s0 + per_call]
-        variants = []
-        for i in idx:
-            clip = audio[i, : lengths[i]].contiguous()
-            variants += [eng.speed_perturb(clip, 0.9), eng.speed_perturb(clip, 1.1)]
-        lens = [int(v.numel()) for v in variants]
-        rows = torch.zeros((len(variants), max(lens)), dtype=torch.float32, device=audio.device)
-        for r, v in enumerate(variants):
-            rows[r, : v.numel()] = v
-        if eng.contexts > 1:
-            # the perturbed batches do not depend on one another: keep them in flight (one context stays free for
-            # the caller's next anchor pass when there are more than two)
-            if len(st["tickets"]) >= max(1, eng.contexts - (1 if eng.contexts > 2 else 0)):
-                _tta_join(eng, st, st["tickets"].pop(0))
-            st["tickets"].append((eng.predict_batch_async(rows, lens), idx, rows, eng.frames_for(max(lens))))
-            continue
-        res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens, want_text=want_text)]
-        for k, i in enumerate(idx):
-            st["out"][i] = _tta_combine(res[2 * k], anchors[i], res[2 * k + 1])
+    st = {"anchors": anchors, "out": list(anchors), "tickets": [], "want_text": want_text, "parts": {}}
+    for s0 in range(0, len(hard), eng.max_batch):
+        idx = hard[s0: s0 + eng.max_batch]
+        lens_in = [lengths[i] for i in idx]
+        for factor in (0.9, 1.1):
+            rows, lens = eng.speed_perturb_rows(audio, lens_in, factor, src_rows=idx)
+            if eng.contexts > 1:
+                # the perturbed batches do not depend on one another: keep them in flight (one context stays free for
+                # the caller's next anchor pass when there are more than two)
+                if len(st["tickets"]) >= max(1, eng.contexts - (1 if eng.contexts > 2 else 0)):
+                    _tta_join(eng, st, st["tickets"].pop(0))
+                st["tickets"].append((eng.predict_batch_async(rows, lens), idx, rows, eng.frames_for(max(lens)), factor))
+                continue
+            res = [_to_dict(r, False) for r in eng.predict_batch(rows, lens, want_text=want_text)]
+            _tta_part(st, idx, factor, res)
     return st
 
 
-def _tta_join(eng, st: dict, ticket):
-    ctx, idx, rows, t_max = ticket   # (rows: the batch's input, kept alive until it has run)
-    res = [_to_dict(r, False) for r in eng.fetch_results(ctx, rows.shape[0], t_max, want_text=st["want_text"])]
+def _tta_part(st: dict, idx, factor: float, res: list[dict]):
+    """one speed's results of the clips `idx`; a clip is decided once both of its copies are in"""
     for k, i in enumerate(idx):
-        st["out"][i] = _tta_combine(res[2 * k], st["anchors"][i], res[2 * k + 1])
+        part = st["parts"].setdefault(i, {})
+        part[factor] = res[k]
+        if len(part) == 2:
+            st["out"][i] = _tta_combine(part[0.9], st["anchors"][i], part[1.1])
+            del st["parts"][i]
+
+
+def _tta_join(eng, st: dict, ticket):
+    ctx, idx, rows, t_max, factor = ticket   # (rows: the batch's input, kept alive until it has run)
+    res = [_to_dict(r, False) for r in eng.fetch_results(ctx, rows.shape[0], t_max, want_text=st["want_text"])]
+    _tta_part(st, idx, factor, res)
 
 
 def tta_finish(eng, st: dict) -> list[dict]:

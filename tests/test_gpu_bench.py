@@ -153,3 +153,33 @@ def test_engine_created_before_any_other_device_work_runs_at_full_speed():
     a, b = run("engine_first"), run("torch_first")
     assert a["contexts"] == b["contexts"] == 4
     assert a["ms_per_batch"] < 1.12 * b["ms_per_batch"], (a, b)
+
+
+def test_bench_strong2048_under_torchrun_with_the_sharded_gather():
+    """--workload strong2048 with the collective path forced on for one rank: dist.shard_plan deals the ragged global batch
+    of 2,048 clips (5-30 s), the rank's share runs in engine calls of 64 with batches in flight, dist.all_gather_results
+    un-permutes the rows over RCCL -- the functions the sharded runner entry ships, at the size of BASELINE configs[3]."""
+    env = dict(os.environ, QVERSE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29563", str(ROOT / "bench.py"), "--gpus", "1",
+                        "--workload", "strong2048", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-post-logits"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 2048 and d["value"] > 0
+    assert d["config"]["deal"] == "strided" and d["audio_seconds_per_s"] > 0
+    assert "shard_plan" in d["config"]["workload"]
+
+
+def test_bench_ingest_leg_small():
+    """the `ingest` leg of the default line at a reduced size: distinct pinned host batches cross PCIe on a copy stream into a ring
+    of device buffers one step ahead of the engine; every timed forward is accounted for (graph replays + plain launches)."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "10", "--warmup", "2", "--batch", "8",
+                        "--seconds", "5", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    ing = d["ingest"]
+    assert "error" not in ing, ing
+    assert ing["value"] > 0 and ing["host_batches"] == 8 and ing["device_buffers"] == d["config"]["batches_in_flight"] + 2
+    assert ing["forward_graph"]["forwards"] == 30 and ing["forward_graph"]["replays"] >= 20
+    assert ing["h2d_gb_per_s"] > 0
