@@ -181,6 +181,25 @@ def structured_weights(seed: int = 20260630, rank: int = 16, mix: float = 0.15, 
     return out
 
 
+def damped_weights(seed: int = 20260630, branch: float = 0.25, head: float = 0.1, n_layers: int = N_LAYERS) -> dict[str, torch.Tensor]:
+    """random_weights() with every residual branch's OUTPUT matrix (feed_forward*.linear2, self_attn.linear_out,
+    conv.pointwise_conv2) scaled by `branch` and the CTC head by `head`: every quantiser of the ORT-mixed arithmetic still
+    sees full-range activations, but a rounding-boundary flip inside a branch moves the residual stream -- and the log-probs --
+    by correspondingly less.  The weight set on which the oracle's own reproducibility floor falls BELOW north_star's 1e-2, so
+    that the device can be held to the absolute number there (tests/test_gpu_ort_mixed.py, tools/ort_floor_table.py)."""
+    w = random_weights(seed, n_layers)
+    out = {}
+    for name, t in w.items():
+        scale = 1.0
+        if name.endswith(("feed_forward1.linear2.weight", "feed_forward2.linear2.weight", "self_attn.linear_out.weight",
+                          "conv.pointwise_conv2.weight")):
+            scale = branch
+        elif name == "ctc_decoder.decoder_layers.0.weight":
+            scale = head
+        out[name] = (t * np.float32(scale)).contiguous() if scale != 1.0 else t
+    return out
+
+
 # ------------------------------------------------------------------- int4 weights -----
 # The reference's "mixed" model file stores the Linear-layer MatMuls as 4-bit MatMulNBits
 # ("MatMulNBitsQuantizer int4", experiments/c2c-direct-mixed/run.py:1-9; the script it names,
