@@ -325,7 +325,7 @@ def model_size():
 '''
 
 
-def _write_wav(path, n):
+def _write_wav_n(path, n):
     import struct
 
     pcm = (np.arange(n) % 251).astype("<i2").tobytes()
@@ -343,7 +343,7 @@ def _stub_corpus(tmp_path):
     samples = []
     for i, n in enumerate(lens):
         name = f"clip_{i:02d}.wav" if i != 4 else "bad_04.wav"
-        _write_wav(corpus / name, n)
+        _write_wav_n(corpus / name, n)
         k = n // 100
         samples.append({"id": f"s{i}", "file": name, "surah": k % 114 + 1, "ayah": k % 7 + 1, "category": "short" if n < 5000 else "long"})
     samples.append({"id": "missing", "file": "not_there.wav", "surah": 1, "ayah": 1, "category": "short"})
