@@ -7,6 +7,7 @@
 // transposed by the QKV GEMM epilogue so that PV's B operand is K-contiguous too).
 
 #include "qv_layers.h"
+#include <type_traits>
 
 #include <atomic>
 #include "qv_dev_util.h"
@@ -909,6 +910,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // when tile kt's barrier frees the other buffer) and a 192-row position ring (160-row window + the 32 rows of the next
 // tile).  The arithmetic of a (head, query tile) is the same wave program in both shapes: outputs are bit-identical.
 
+#ifdef QV_ATT_STAMPS   // tools/att_bench.hip: per key tile, clock stamps of every wave of ONE block of the key-tiled kernel
+__device__ long long g_ws_stamp[12][16][6];
+#define WS_STAMP(kt, i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 17 && lane == 0 && (kt) < 16) g_ws_stamp[wave][kt][i] = clock64(); } while (0)
+#else
+#define WS_STAMP(kt, i) do { } while (0)
+#endif
 template <int HPB, int NST, int RING>
 __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
                                                                   const half_t *__restrict__ pos, int pos_ld,
@@ -972,16 +979,20 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
             pos_rows(32 + 128, 4);
         }
         for (int kt = 0; kt < n_kt; ++kt) {
+            WS_STAMP(kt, 0);
             // unit(kt) has landed once only the units requested after it may still be in flight
             if (NST == 3 && kt + 1 < n_kt) {
                 if (HPB == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WS_STAMP(kt, 1);
             __builtin_amdgcn_s_barrier();           // tile kt visible; the buffers of tile kt - 1 are free
+            WS_STAMP(kt, 2);
             if (kt + NST - 1 < n_kt) {
                 stage(kt + NST - 1);
                 pos_rows(32 * (kt + NST - 1) + 128, 4);   // the 32 new rows of that tile
             }
+            WS_STAMP(kt, 3);
         }
         return;
     }
@@ -1012,71 +1023,96 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -1e30f, l_run = 0.f;
-    f32x16 rprev;
+    // Round 6.  The loop below is bound by the instructions the two consumer waves of a SIMD issue per key tile (stamps in
+    // tools/att_bench: 4.4 k cycles per tile, the loaders land a tile ahead and wait), so the same arithmetic is issued
+    // with fewer of them -- the output bits do not change (tests compare variants 0 .. 2):
+    //  * scores stay in RAW units (8 x the scaled score) up to the exponential: exp((p - m) / 8) = exp2((p - m) * (log2 e / 8)),
+    //    and scaling by a power of two commutes with every rounding on the way -- 16 multiplies per tile gone;
+    //  * the key mask (j0 + jj < T) only exists in an utterance's LAST key tile: the other tiles run an unmasked copy of
+    //    the body (16 compares + 32 selects gone);
+    //  * the skew slab keeps alternating halves (tile kt sits where tile kt - 1 wrote it as ITS second tile), but the column
+    //    of a value is no longer computed with a wrap: an even key tile reads lane constant + immediate (31 - ii + jj <= 62
+    //    never wraps), an odd one reads the same column XOR 32, i.e. one of two lane-constant bases chosen by a compare of two
+    //    constants per value -- ~5 integer instructions per value read become 0 / 2;
+    //  * fragment addresses: lane constants computed once, XORed with the K-step.
+    constexpr float NEG = -1e30f * 8.0f, L2E8 = 0x1.715476p+0f * 0.125f;   // (__expf(x) is v_exp_f32(x * 0x1.715476p+0))
+    float m_run = NEG, l_run = 0.f;
+    const int swz = (l31 >> 1) & 7;
+    const int kf0 = l31 * 64 + ((hi ^ swz) << 3);                  // K / position fragment of K-step ks: kf0 ^ (ks << 4) (halves)
+    float *const slw = sl + l31 * ATT_LDS_LD + 4 * hi;            // slab stores: + 32 * tile + (r & 3) + 8 * (r >> 2)
+    const float *const slr = sl + l31 * ATT_LDS_LD + (31 - l31 + 4 * hi);   // slab loads: + (r & 3) + 8 * (r >> 2), never past column 62
+    // odd tiles: slab column = window column ^ 32, i.e. + 32 where the window column 31 - ii + jj is below 32 and - 32 elsewhere;
+    // bit r of `hiw` says "elsewhere" for register r, so the address is one shift-add away from a lane constant
+    unsigned hiw = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rprev[r] = 0.f;
-    for (int kt = 0; kt < n_kt; ++kt) {
-        __builtin_amdgcn_s_barrier();
-        if (!active) continue;
+    for (int r = 0; r < 16; ++r) hiw |= (unsigned)((r & 3) + 8 * (r >> 2) >= 1 + l31 - 4 * hi) << r;
+    const int vda = l31 * 32 + 4 * hi, vdc = (32 + l31) * 32 + 4 * hi, vsw = (l31 >> 2) & 3;   // V^T rows d = l31 and 32 + l31 share (d >> 2) & 3
+    int ring1 = (128 - 32 * w4) % RING;                          // position tile kt + 1 of this wave starts at ring row 32 kt + 128 - 32 w4
+    auto tile = [&](int kt, auto masked_c, auto odd_c) {
+        constexpr bool MASKED = decltype(masked_c)::value, ODD = decltype(odd_c)::value;   // ODD: kt & 1 (never kt == 0)
         const int j0 = kt * 32, buf = kt % NST;
+        // (the per-K-step fragment offsets are re-derived from three lane constants in every tile -- one XOR / shift each: hoisted
+        // out of the loop they are 14 more live registers, and the two-heads-per-block shape has 168 per wave)
+        int kfl = kf0, val = vda, vcl = vdc;
+        asm volatile("" : "+v"(kfl), "+v"(val), "+v"(vcl));
         const half_t *sKb = sK[hh][buf], *sVb = sV[hh][buf];
-        // window-relative position rows of this wave: 32 kt + 96 - 32 w4 + c, c in [0, 64)
-        const int wr0 = 32 * kt + 96 - 32 * w4 + l31;
-        const int ring0 = wr0 % RING, ring1 = (wr0 + 32) % RING;
         // position tile pt = rows 32 pt .. of the wave's window: key tile kt needs tiles kt and kt + 1, and tile kt is what
         // key tile kt - 1 computed as ITS second tile -- same operands, same products, so it is carried over instead of
-        // being computed (and pushed through the slab) twice
-        f32x16 st, r0, r1;
+        // being computed twice
+        f32x16 st, r1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; r1[r] = 0.f; }
-        if (kt == 0) {
+        if (!ODD && kt == 0) {
+            const int ring0 = (96 - 32 * w4) % RING;
+            f32x16 r0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) r0[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int c = ks * 2 + hi;
-                half8 p0 = *(const half8 *)(sPh + ring0 * 64 + ((c ^ ((ring0 >> 1) & 7)) << 3));
+                half8 p0 = *(const half8 *)(sPh + ring0 * 64 + (kfl ^ (ks << 4)));
                 r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);
             }
-        } else r0 = rprev;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slw[(r & 3) + 8 * (r >> 2)] = r0[r];
+        }
+        const half_t *sP1 = sPh + ring1 * 64;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int c = ks * 2 + hi;
-            half8 kf = *(const half8 *)(sKb + l31 * 64 + ((c ^ ((l31 >> 1) & 7)) << 3));
-            half8 p1 = *(const half8 *)(sPh + ring1 * 64 + ((c ^ ((ring1 >> 1) & 7)) << 3));
+            half8 kf = *(const half8 *)(sKb + (kfl ^ (ks << 4)));
+            half8 p1 = *(const half8 *)(sP1 + (kfl ^ (ks << 4)));
             st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);
             r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);
         }
-        rprev = r1;
-        // skew: tile pt lives in slab columns 32 (pt & 1) .., so tile kt is already there (written as tile (kt - 1) + 1) and
-        // only tile kt + 1 replaces tile kt - 1; BD^T[jj][ii] = slab[ii][(32 (kt & 1) + 31 - ii + jj) mod 64]
+        ring1 += 32;
+        if (ring1 >= RING) ring1 -= RING;
+        // skew: BD^T[jj][ii] = window[ii][31 - ii + jj], window = [tile kt | tile kt + 1]; tile pt lives in slab columns
+        // 32 (pt & 1) .., so tile kt is already there and tile kt + 1 replaces tile kt - 1
         __builtin_amdgcn_wave_barrier();
-        if (kt == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sl[l31 * ATT_LDS_LD + (r & 3) + 8 * (r >> 2) + 4 * hi] = r0[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sl[l31 * ATT_LDS_LD + 32 * ((kt + 1) & 1) + (r & 3) + 8 * (r >> 2) + 4 * hi] = r1[r];
+        for (int r = 0; r < 16; ++r) slw[(ODD ? 0 : 32) + (r & 3) + 8 * (r >> 2)] = r1[r];
         __builtin_amdgcn_wave_barrier();
+        WS_STAMP(kt, 2);
         float p[16];
-        float mx = -1e30f;
+        float mx = NEG;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float bd = sl[l31 * ATT_LDS_LD + ((32 * (kt & 1) + 31 - l31 + jj) & 63)];
-            float sc = (st[r] + bd) * 0.125f;
-            p[r] = (j0 + jj < T) ? sc : -1e30f;
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int e = (r & 3) + 8 * (r >> 2);
+            // even tile: window column = slab column; odd tile: slab column = window column ^ 32
+            const float bd = !ODD ? slr[e] : *(const float *)((const char *)(slr + 32 + e) - (((hiw >> r) & 1u) << 8));
+            const float sc = st[r] + bd;
+            p[r] = (!MASKED || j0 + jj < T) ? sc : NEG;
             mx = fmaxf(mx, p[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float m_new = fmaxf(m_run, mx);
-        float corr = __expf(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * L2E8);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float e = (j0 + jj < T) ? __expf(p[r] - m_new) : 0.f;
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float e = (!MASKED || j0 + jj < T) ? __builtin_amdgcn_exp2f((p[r] - m_new) * L2E8) : 0.f;
             p[r] = e;
             sum += e;
         }
@@ -1085,22 +1121,31 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
         m_run = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+        WS_STAMP(kt, 3);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 pbf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pbf[e] = (half_t)p[8 * ks + e];
             // V^T pieces: keys 16 ks + 4 hi + {0..3} and + 8 -> 16-B chunks 2 ks and 2 ks + 1, 8-byte half `hi`
-            const int da = l31, dc = 32 + l31;
-            half4 a0 = *(const half4 *)(sVb + da * 32 + (((2 * ks) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
-            half4 a1 = *(const half4 *)(sVb + da * 32 + (((2 * ks + 1) ^ ((da >> 2) & 3)) << 3) + 4 * hi);
-            half4 c0 = *(const half4 *)(sVb + dc * 32 + (((2 * ks) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
-            half4 c1 = *(const half4 *)(sVb + dc * 32 + (((2 * ks + 1) ^ ((dc >> 2) & 3)) << 3) + 4 * hi);
+            half4 a0 = *(const half4 *)(sVb + val + (((2 * ks) ^ vsw) << 3));
+            half4 a1 = *(const half4 *)(sVb + val + (((2 * ks + 1) ^ vsw) << 3));
+            half4 c0 = *(const half4 *)(sVb + vcl + (((2 * ks) ^ vsw) << 3));
+            half4 c1 = *(const half4 *)(sVb + vcl + (((2 * ks + 1) ^ vsw) << 3));
             half8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             half8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pbf, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pbf, o1, 0, 0, 0);
         }
+        WS_STAMP(kt, 4);
+    };
+    for (int kt = 0; kt < n_kt; ++kt) {
+        WS_STAMP(kt, 0);
+        __builtin_amdgcn_s_barrier();
+        WS_STAMP(kt, 1);
+        if (!active) continue;
+        if (kt + 1 < n_kt) { if (kt & 1) tile(kt, std::false_type{}, std::true_type{}); else tile(kt, std::false_type{}, std::false_type{}); }
+        else { if (kt & 1) tile(kt, std::true_type{}, std::true_type{}); else tile(kt, std::true_type{}, std::false_type{}); }
     }
     if (active && i0 + l31 < T) {
         float inv = 1.f / l_run;

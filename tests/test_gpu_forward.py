@@ -650,8 +650,11 @@ def test_forward_graph_replay_equals_the_plain_launches():
         for i, name in enumerate(order):
             assert run(name) == ref[name], (i, name)
         st = eng.forward_graph_stats()
-        # 7 distinct keys ("a" and "p" share one), 4 graphs kept per context: captures beyond 2 x 7 are re-captures after eviction
-        assert st["captures"] >= 14 and st["replays"] >= len(order) // 2, st
+        # 7 distinct keys ("a" and "p" share one), 4 graphs kept per context: the first 2 x 4 shapes are captured as they arrive; once a
+        # context is full it replaces its least recently used graph, and at most once per 8 forwards (round 6: a loop over more
+        # shapes than slots must not pay a capture + instantiate + stream synchronise per cycle) -- so a few more, not 2 x 7
+        assert 8 < st["captures"] <= 14 and st["replays"] >= len(order) // 2, st
+        assert eng.lib.qv_debug_forward_graph_failures(eng.h) == 0
     finally:
         eng.kernel_variant(3, -1)
         eng.close()

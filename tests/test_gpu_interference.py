@@ -69,14 +69,17 @@ def test_shipped_logmel_is_undisturbed_by_the_shipped_precision2_front_end(probe
     assert diff == 0 and groups == 0, (diff, groups)
 
 
-@pytest.mark.parametrize("victim", [20, 21, 22, 23])
-def test_gemm_kernels_with_their_packed_fp32_epilogues_are_undisturbed(probes, victim):
-    """The two GEMM translation units keep packed-FP32 instructions (offline-tarteel_amd/build.py says why).  Victims 20-23 are
-    the FFN-up and the long-K GEMM on 256 x 256 and on 128-wide tiles, compiled as shipped (the `_pk` flavour), next to
-    the withdrawn aggressor: every output word must stay identical over 400 launches."""
-    for aggr in (1, 3):
-        diff, groups, _ = _run(probes["withdrawn_pk"], 400, aggr, victim)
-        assert diff == 0 and groups == 0, (victim, aggr, diff, groups)
+@pytest.mark.parametrize("victim", [20, 21, 22, 23, 24, 25])
+def test_gemm_kernels_are_undisturbed(probes, victim):
+    """Round 6: the GEMM translation units are built without packed-FP32 instructions like the rest of the library; the two
+    instantiations that keep them (k_gemm_pk: W8A16 on 128-wide tiles with the GLU / residual epilogue -- they spill without
+    the packed forms, csrc/qv_gemm.hip) are victims 24 / 25.  Victims 20-23 are the FFN-up and the long-K GEMM on 256 x 256
+    and on 128-wide tiles.  Next to the withdrawn aggressor every output word must stay identical over 400 launches, in the
+    product's flavour AND with packed FP32 left on everywhere (`_pk`, how rounds 1-5 compiled the GEMM units)."""
+    for flavour in ("withdrawn", "withdrawn_pk"):
+        for aggr in (1, 3):
+            diff, groups, _ = _run(probes[flavour], 400, aggr, victim)
+            assert diff == 0 and groups == 0, (flavour, victim, aggr, diff, groups)
 
 
 @pytest.mark.parametrize("victim", [6, 7, 10, 11])

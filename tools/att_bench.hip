@@ -56,6 +56,26 @@ int main(int argc, char **argv) {
         if (variant) for (size_t i = 0; i < ref.size(); ++i) md = std::max(md, (double)fabsf((float)ref[i] - (float)got[i]));
         printf("variant %d: %.2f us per launch (back to back), max |diff| to variant 0 = %.3g\n", variant, ms * 1000 / iters, md);
     }
+    if (T > 128) {
+        // variant 0 (two heads per block) ran first and variant 1, 2 overwrote nothing of it: re-run variant 0 once for the stamps
+        qv_attention_set_variant(0);
+        launch_attention(qk, vt, pos, pos_ld, bu, bv, len, off, out, T, T, t_pad, B, s);
+        CK(hipStreamSynchronize(s));
+        static long long st[12][16][6];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ws_stamp), sizeof(st)));
+        const int n_kt = (T + 31) / 32 < 16 ? (T + 31) / 32 : 16;
+        const long long t0 = st[0][0][0];
+        printf("k_attention_ws<2,2,192> block (head pair 1, query group 1, utterance 17): clocks since consumer wave 0 reached its first barrier\n");
+        for (int w : {0, 1, 4, 8, 9}) {
+            printf("  %s wave %2d:", w < 8 ? "consumer" : "loader  ", w);
+            for (int kt = 0; kt < n_kt; ++kt) {
+                if (w < 8) printf(" | kt%d at-barrier %lld released %lld skewed %lld softmax %lld pv %lld", kt, st[w][kt][0] - t0, st[w][kt][1] - t0, st[w][kt][2] - t0, st[w][kt][3] - t0, st[w][kt][4] - t0);
+                else printf(" | kt%d wait %lld landed %lld released %lld issued %lld", kt, st[w][kt][0] - t0, st[w][kt][1] - t0, st[w][kt][2] - t0, st[w][kt][3] - t0);
+                if (kt == 3) { printf(" ..."); kt = n_kt - 3; }
+            }
+            printf("\n");
+        }
+    }
     if (T <= 128) {
         long long st[4][8];
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_att_stamp), sizeof(st)));

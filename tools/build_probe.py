@@ -17,7 +17,8 @@ ROOT = Path(__file__).resolve().parent.parent
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SRC = ROOT / "tools" / "interference_probe.hip"
 DEPS = [Path(__file__).resolve(), ROOT / "offline-tarteel_amd" / "build.py", SRC, ROOT / "tools" / "logmel_variants.h", ROOT / "tools" / "withdrawn" / "qv_ort_conv0_mfma.hip",
-        *sorted((ROOT / "offline-tarteel_amd" / "csrc").glob("*.h")),
+        *sorted((ROOT / "offline-tarteel_amd" / "csrc").glob("*.h")), *sorted((ROOT / "offline-tarteel_amd" / "csrc").glob("*.inc")),
+        ROOT / "offline-tarteel_amd" / "csrc" / "qv_gemm.hip", ROOT / "offline-tarteel_amd" / "csrc" / "qv_gemm256.hip",
         ROOT / "offline-tarteel_amd" / "csrc" / "qv_layers.hip", ROOT / "offline-tarteel_amd" / "csrc" / "qv_ort.hip"]
 
 

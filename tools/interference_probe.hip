@@ -167,6 +167,10 @@ __global__ void k_lane_primitives(int *out) {
     out[10 * 64 + lane] = __builtin_amdgcn_mov_dpp(lane, 0x128, 0xf, 0xf, true);  // row_ror:8
 }
 
+__global__ void k_copy_f4(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
 template <class T> static T *dev(const std::vector<T> &h) {
     T *p = nullptr;
     if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return nullptr;
@@ -285,7 +289,9 @@ int main(int argc, char **argv) {
     // GEMM victims: operands of gemm_bench's kind, outputs into the feature buffers (13.9 M words >= 8064 x 2048 halves)
     half_t *g_A = nullptr, *g_W = nullptr;
     float *g_bias = nullptr;
-    if (victim >= 20 && victim <= 23) {
+    uint8_t *g_W8 = nullptr;
+    float *g_w8s = nullptr, *g_res0 = nullptr;
+    if (victim >= 20 && victim <= 25) {
         const int GM = 8064;
         std::vector<half_t> hA((size_t)GM * 2048), hW((size_t)2048 * 2048);
         uint32_t gs = 99;
@@ -294,9 +300,27 @@ int main(int argc, char **argv) {
         std::vector<float> hb(4096);
         for (auto &x : hb) { gs = gs * 1664525u + 1013904223u; x = ((int)(gs >> 9) % 2001 - 1000) * 1e-4f; }
         g_A = dev(hA); g_W = dev(hW); g_bias = dev(hb);
+        if (victim >= 24) {   // the two instantiations that KEEP packed FP32 in the product (k_gemm_pk: W8A16 on 128-wide tiles, GLU / residual epilogue)
+            std::vector<uint8_t> h8((size_t)1024 * 512);
+            for (auto &x : h8) { gs = gs * 1664525u + 1013904223u; x = (uint8_t)(1 + (gs >> 9) % 255); }
+            std::vector<float> hs(1024), hr((size_t)GM * 512);
+            for (auto &x : hs) { gs = gs * 1664525u + 1013904223u; x = (1 + (int)(gs >> 9) % 1000) * 1e-5f; }
+            for (auto &x : hr) { gs = gs * 1664525u + 1013904223u; x = ((int)(gs >> 9) % 2001 - 1000) * 1e-3f; }
+            g_W8 = dev(h8); g_w8s = dev(hs); g_res0 = dev(hr);
+        }
     }
     auto run_gemm_victim = [&](float *out) {
         GemmArgs g = {};
+        if (victim >= 24) {
+            const bool glu = victim == 24;
+            g.A = g_A; g.W8 = g_W8; g.w8scale = g_w8s; g.bias = g_bias; g.out = out;
+            g.M = 8064; g.N = glu ? 1024 : 512; g.K = 512; g.lda = 512; g.ldw = 512; g.ldo = 512; g.alpha = glu ? 1.f : 0.5f;
+            // the residual epilogue reads and rewrites its output: start every launch from the same residual stream
+            if (!glu) hipLaunchKernelGGL(k_copy_f4, dim3(2048), dim3(256), 0, sv, (const float4 *)g_res0, (float4 *)out, (size_t)8064 * 512 / 4);
+            qv_gemm_set_t256(0);
+            launch_gemm(glu ? EPI_GLU : EPI_RESID, g, sv);
+            return;
+        }
         const bool up = victim <= 21;
         g.A = g_A; g.W = g_W; g.bias = g_bias; g.out = out;
         g.M = 8064; g.N = up ? 2048 : 512; g.K = up ? 512 : 2048; g.lda = g.K; g.ldw = g.K; g.ldo = g.N; g.alpha = 1.f;
@@ -305,7 +329,7 @@ int main(int argc, char **argv) {
     };
     auto run_victim = [&](float *out) {
         const dim3 g4((tm_max + 3) / 4, B);
-        if (victim >= 20 && victim <= 23) { run_gemm_victim(out); return; }
+        if (victim >= 20 && victim <= 25) { run_gemm_victim(out); return; }
         if (victim == 0) launch_logmel(d_audio, n_max, d_n, ft, out, tm_max, stats_v, B, sv);
         else if (victim == 7) hipLaunchKernelGGL(lmv::k_logmel_reg<0>, g4, dim3(256), 0, sv, d_audio, n_max, d_n, ft, out, tm_max);
         else if (victim == 10) hipLaunchKernelGGL((lmv::k_logmel_lds<true, false, false>), dim3(tm_max, B), dim3(64), 0, sv, d_audio, n_max, d_n, ft, out, tm_max, (float2 *)nullptr, (float *)nullptr);
