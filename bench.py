@@ -760,6 +760,17 @@ def main():
 
         traffic, traffic_source = quoted("r*_pmc_traffic.json", "hbm_bytes_per_launch", r_dn["kernel"])
         mfma_util, mfma_source = quoted("r*_mfma_busy.json", "mfma_util", r_dn["kernel"])
+        insitu, insitu_source = None, None
+        try:
+            for f in sorted((ROOT / "profiles").glob("r*_mfma_in_situ*.json"), reverse=True):
+                doc = json.loads(f.read_text())
+                if int(doc.get("rows", 0)) == rows_per_launch and doc.get("weights") == args.precision:
+                    insitu = doc["all_gemm"]["mfma_util"]
+                    insitu_source = (f"profiles/{f.name} (rocprofv3 --pmc over THIS command with --contexts 1, weighted over all "
+                                     f"{doc['all_gemm']['launches']} GEMM launches; not collected in this run)")
+                    break
+        except Exception:
+            pass
         up_traffic, _ = quoted("r*_pmc_traffic.json", "hbm_bytes_per_launch", rep["kernel"])
         up_util, _ = quoted("r*_mfma_busy.json", "mfma_util", rep["kernel"])
         eng.profile_gemm(True)
@@ -777,6 +788,7 @@ def main():
                      "attention-out / pointwise-conv-2 [M,512]x[512,512] per step",
             "achieved": round(ach_cls, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_cls / PEAK_F16_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source, "mfma_util_pmc": mfma_util, "mfma_util_source": mfma_source,
+            "mfma_util_in_situ": insitu, "mfma_util_in_situ_source": insitu_source,
             "flops_per_launch": cls_flops / 68, "avg_launch_us": round(cls_us / 68, 2), "launches": 120,
             "members": {"ffn_down": {"kernel": r_dn["kernel"], "tflops": tf(r_dn), "avg_launch_us": round(r_dn["avg_us"], 2),
                                      "blocks": tiles_of(r_dn, 512), "cus_occupied": cus_dn,

@@ -15,4 +15,7 @@ cp_ $F/profpost/p_kernel_stats.csv postlogits_verse_shaped_kernel_stats.csv; cp_
 cp_ $F/prof_b64_ort/p_kernel_stats.csv b64_ort_contexts1_kernel_stats.csv
 for p in fp16 mixed ort; do cp_ $F/prof_b256_$p/p_kernel_stats.csv b256_${p}_contexts1_kernel_stats.csv; done
 cp_ $R/gpurun_out/pmc_$T/traffic.json pmc_traffic.json; cp_ $R/gpurun_out/pmc_$T/mfma.json mfma_busy.json
+cp_ $F/mfma_in_situ_b64.json mfma_in_situ_b64.json; cp_ $F/mfma_in_situ_b256.json mfma_in_situ_b256.json
+cp_ $F/post_bench_376.jsonl post_bench_376.jsonl; cp_ $F/bench_strong2048.json bench_strong2048.json; cp_ $F/bench_strong2048_contiguous.json bench_strong2048_contiguous.json
+cp_ $F/ort_floor_table.json ort_floor_table.json
 ls $P | grep "^${T}_" | wc -l

@@ -21,6 +21,10 @@ timeout 300 python bench.py --workload tta30 --precision ort --steps 4 --warmup 
 timeout 300 python bench.py --capacity-seconds 30 --steps 40 --no-cpu-baseline --no-extra --no-post-logits > "$O/bench_capacity30s.json" 2>/dev/null; cut -c1-170 "$O/bench_capacity30s.json"
 timeout 300 python tools/sweep.py --out "$O/sweep.json" > "$O/sweep.log" 2>&1; tail -n 3 "$O/sweep.log" | cut -c1-200
 timeout 200 python tools/post_bench.py > "$O/post_bench.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench.jsonl"
+timeout 200 python tools/post_bench.py --frames 376 > "$O/post_bench_376.jsonl" 2>/dev/null; cut -c1-110 "$O/post_bench_376.jsonl"
+timeout 600 python bench.py --workload strong2048 --steps 3 --warmup 1 --no-cpu-baseline --no-post-logits --no-extra > "$O/bench_strong2048.json" 2>/dev/null; cut -c1-170 "$O/bench_strong2048.json"
+timeout 600 python bench.py --workload strong2048 --deal contiguous --steps 3 --warmup 1 --no-cpu-baseline --no-post-logits --no-extra > "$O/bench_strong2048_contiguous.json" 2>/dev/null; cut -c1-170 "$O/bench_strong2048_contiguous.json"
+timeout 900 python tools/ort_floor_table.py --out "$O/ort_floor_table.json" > "$O/ort_floor_table.log" 2>&1; tail -n 3 "$O/ort_floor_table.log" | cut -c1-200
 timeout 200 python tools/tracker_bench.py --cpu-texts 4 > "$O/tracker_bench.jsonl" 2>/dev/null; tail -n 2 "$O/tracker_bench.jsonl"
 timeout 300 python tools/ort_delta.py --seconds 10 --out "$O/ort_semantics_delta.json" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -31,6 +35,13 @@ for prec in fp16 mixed ort; do   # B = 256 (configs[2] / the per-rank slice of c
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b256_$prec" -o p -- python "$R/bench.py" --precision $prec --batch 256 --steps 8 --warmup 2 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_tta30" -o p -- python "$R/bench.py" --workload tta30 --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+# in-situ matrix-pipe utilisation over ALL GEMM launches of the bench command itself (one batch at a time; B = 64 and B = 256)
+for bb in 64 256; do
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/pmc_insitu_$bb" -o p -- python "$R/bench.py" --batch $bb --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
+  f=$(find "$O/pmc_insitu_$bb" -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python "$R/tools/pmc_insitu.py" "$f" "$O/mfma_in_situ_b$bb.json" $((bb * 126)) fp16 | cut -c1-300
+  rm -rf "$O/pmc_insitu_$bb"
+done
 timeout 120 "$R/tools/att_bench" 64 126 200 > "$O/att_bench.log" 2>&1; timeout 120 "$R/tools/att_bench" 256 126 100 >> "$O/att_bench.log" 2>&1; timeout 120 "$R/tools/att_bench" 64 376 50 >> "$O/att_bench.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b64_ort" -o p -- python "$R/bench.py" --precision ort --steps 16 --contexts 1 --no-cpu-baseline --no-post-logits --no-extra > /dev/null 2>&1
 # the rejected fused feed-forward prototype next to the two GEMM kernels it would replace ("commit it with its rocprof table")

@@ -51,20 +51,9 @@ interference)
     echo "== the other kernels that share the chip with it: k_sub01 (4), k_attention_short (8), k_attention_ws (16)"
     for a in 4 8 16; do QVERSE_LOGMEL=1 ${P}_current 300 $a 0 2>&1 | filt; done
   } > "${L}_probe_matrix.log" 2>&1
-  {
-    echo "== shader clock capped (rocm-smi --setperfdeterminism 1300)"
-    rocm-smi --setperfdeterminism 1300 2>&1 | grep -v "^$" | head -8
-    rocm-smi --showclocks 2>&1 | grep -i "sclk\|mclk" | head -4
-    QVERSE_LOGMEL=0 ${P}_withdrawn 600 1 0 2>&1 | filt
-    QVERSE_LOGMEL=0 ${P}_withdrawn 600 1 12 2>&1 | filt
-    echo "== and capped at 900"
-    rocm-smi --setperfdeterminism 900 2>&1 | grep -v "^$" | head -8
-    QVERSE_LOGMEL=0 ${P}_withdrawn 600 1 0 2>&1 | filt
-    rocm-smi --resetperfdeterminism 2>&1 | grep -v "^$" | head -8
-    echo "== back at the default clocks"
-    QVERSE_LOGMEL=0 ${P}_withdrawn 600 1 0 2>&1 | filt
-  } > "${L}_clock_cap.log" 2>&1
-  cat "${L}_device.log" | head -30; cat "${L}_probe_matrix.log" "${L}_clock_cap.log"
+  # (round 5 also tried a shader-clock cap here; the pool no longer allows changing machine settings, and the attempt was inconclusive:
+  # profiles/archive/r05_a_interference_clock_cap.log)
+  cat "${L}_device.log" | head -30; cat "${L}_probe_matrix.log"
   ;;
 interference2)
   P=tools/interference_probe

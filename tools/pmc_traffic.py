@@ -22,12 +22,12 @@ EPI = ["f16", "f16_swish", "f16_relu", "glu", "resid", "f32", "qkv"]
 def short_name(kernel: str):
     """'void k_gemm<1, 128, 0, 2, 1>(GemmArgs)' -> 'k_gemm<f16_swish,128>' (+ loader / stage variant);
     'void k_gemm256<1, 0>(GemmArgs)' -> 'k_gemm256<f16_swish>'."""
-    w = re.search(r"k_gemm256<(\d+)(?:, (\d+))?>", kernel)
+    w = re.search(r"k_gemm256<(\d+)(?:, (\d+))?(?:, (\d+))?>", kernel)
     if w:
-        wq = int(w.group(2) or 0)
-        return (f"k_gemm256<{EPI[int(w.group(1))]}>",
-                "256 x 256 tiles, one block per CU, every wave stages and computes" + (f", int{wq} weights" if wq else ""))
-    m = re.search(r"k_gemm<(\d+), (\d+), (\w+), (\d+)(?:, (\d+))?>", kernel)
+        wq, mi = int(w.group(2) or 0), int(w.group(3) or 4)
+        return (f"k_gemm256<{EPI[int(w.group(1))]}{',192' if mi == 3 else ''}>",
+                f"{64 * mi} x 256 tiles, one block per CU, every wave stages and computes" + (f", int{wq} weights" if wq else ""))
+    m = re.search(r"k_gemm(?:_pk)?<(\d+), (\d+), (\w+), (\d+)(?:, (\d+))?>", kernel)
     if not m:
         return None, None
     epi, bn, wq, nst, ld = int(m.group(1)), int(m.group(2)), m.group(3), int(m.group(4)), int(m.group(5) or 0)
