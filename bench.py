@@ -806,7 +806,7 @@ def main():
                             + ("" if n_ctx >= 4 else
                                " and >= 128 such tiles, or K >= 2048" if n_ctx >= 3 else " and >= 160 such tiles")
                             + " (with several batches in flight the small-grid GEMMs run on 64-128 CUs: fewer CU-microseconds per GEMM, the "
-                              "other batches' kernels take the idle CUs; profiles/r02_f_tile_policy_sweep.txt), 128-wide tiles otherwise; "
+                              "other batches' kernels take the idle CUs; profiles/archive/r02_f_tile_policy_sweep.txt), 128-wide tiles otherwise; "
                               "other_gemms are stand-alone replays under that policy"),
             "other_gemms": {eng.REPLAY_SHAPES[w]: tf(eng.replay_gemm(w, 50)) for w in (2, 4)},
             "all_gemm_in_situ_tflops": round(sum(c["flops"] for c in classes) / (gemm_ms * 1e-3) / 1e12, 2),

@@ -23,7 +23,7 @@ static std::string g_create_error;
 // four fresh streams -- what an engine with four contexts is about to create; the caller's stream and RCCL's already
 // exist and hold their queues -- each run a one-wave kernel that spins for a fixed
 // wall-clock time; the elapsed time over the spin time is how many of them shared a queue.  Measured
-// (tools/hwq_probe.py, profiles/r03_c_hwq_probe.txt): with GPU_MAX_HW_QUEUES=8 in place 7 fresh streams run side by side in
+// (tools/hwq_probe.py, profiles/archive/r03_c_hwq_probe.txt): with GPU_MAX_HW_QUEUES=8 in place 7 fresh streams run side by side in
 // a plain process and 4 after RCCL has created its own; on the default 4 queues only 3 do.
 namespace {
 __global__ void k_spin(long long ticks) {   // wall_clock64: 100 MHz
@@ -564,7 +564,7 @@ extern "C" int qv_create(const qv_config *cfg, qv_engine **out) {
     // an event there per batch; in a process whose first device work is this function, the runtime used to hand the
     // default stream -- first used later, by the table upload below -- a queue one of the context streams ends up on as
     // well, so that event sat behind ~300 queued kernels of an older batch and every new batch waited for it:
-    // 4.7-4.8 ms per batch of 64 x 10 s instead of 3.5 (profiles/r05_r_init_order.log; tools/sweep.py, which creates
+    // 4.7-4.8 ms per batch of 64 x 10 s instead of 3.5 (profiles/archive/r05_r_init_order.log; tools/sweep.py, which creates
     // its engine first, under-reported every row since round 2).  One kernel on the default stream, before the probe
     // below creates the process's first other streams, is what a process that touched the device earlier had anyway.
     // (A host thread that is inside a stream capture must not touch the legacy stream -- it would invalidate the capture or

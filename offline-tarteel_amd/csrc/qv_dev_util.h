@@ -26,7 +26,7 @@ static __device__ __forceinline__ float wave_min(float v) {
 // over all eight L2s and finds nothing the GEMM before it wrote.  xcd_order maps a workgroup id to a position in the
 // row-ordered work list such that XCD k gets the k-th contiguous chunk (bijective for any count, the GEMMs' formula):
 // k_layernorm2 (reads and rewrites the residual stream the FFN-down GEMM just wrote) 14.5 -> 9.2 us per launch, k_dwconv1d
-// 10.55 -> 9.72, k_layernorm 5.64 -> 5.4-5.6 (profiles/r05_o_xcd_order_kernel_averages.log); the attention kernels did not gain.
+// 10.55 -> 9.72, k_layernorm 5.64 -> 5.4-5.6 (profiles/archive/r05_o_xcd_order_kernel_averages.log); the attention kernels did not gain.
 static __device__ __forceinline__ int xcd_order(int wg, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;

@@ -9,7 +9,7 @@ Two kinds of checks:
     wrong LSB is 4e-3 of the tensor's range; the bounds below are 1e-5 of it (Swish / sigmoid differ by an ulp or two
     between expf implementations, everything else is expected to be bit-identical and the match rate is printed).
   * END-TO-END: log-probs against the oracle.  The oracle differs from ITSELF by ~0.05 max / ~0.012 rms when only the
-    float32 summation order changes (1 vs 16 threads; profiles/r03_a_ort_noise_floor.json), because every
+    float32 summation order changes (1 vs 16 threads; profiles/archive/r03_a_ort_noise_floor.json), because every
     DynamicQuantizeLinear is a rounding discontinuity; the bound here is that floor with head room, and the f16-weight
     path (QV_PREC_MIXED_INT4_INT8) must be several times further away.
 """
@@ -462,7 +462,7 @@ def test_edge_shapes_one_frame_thirty_seconds_and_silence():
             assert int(tr[0]) == T[b]
             # a clip of ONE frame has a handful of values per quantiser: sub-ulp noise rarely flips any of them (the floor
             # reads ~3e-3 or exactly 0), while the f16 rounding of the Linear inputs -- the device's design point, equal
-            # to the other perturbations on ordinary clips (profiles/r03_a_ort_noise_floor.json) -- does.  The edge
+            # to the other perturbations on ordinary clips (profiles/archive/r03_a_ort_noise_floor.json) -- does.  The edge
             # shapes are therefore judged against the envelope that includes that row.
             floor = oracle_floor(R, w, one, [lens[b]], ref, [T[b]], one_thread=False, seeds=(1, 2, 3), f16_inputs=True)
             _assert_on_the_floor(f"edge utt {b} (T = {T[b]})", delta(lp[b: b + 1], ref, [T[b]]), floor)

@@ -389,7 +389,7 @@ def test_prefix_shared_span_pass_under_match_verse_with_spans_of_eight(engine, g
 
 
 def test_span_pass_differential_fuzz_small():
-    """tools/fuzz_spans.py at a size that runs in seconds (the full runs: profiles/r05_l_fuzz_spans.log, 33,000 texts, 0
+    """tools/fuzz_spans.py at a size that runs in seconds (the full runs: profiles/archive/r05_l_fuzz_spans.log, 33,000 texts, 0
     mismatches): k_spans2 against k_spans through the hot path's retrieval and through qv_match_verse (max_span 8, hints)."""
     import subprocess
     import sys

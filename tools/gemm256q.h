@@ -1,6 +1,6 @@
 // gemm256q.h -- k_gemm256q: the 256 x 256 x 64 GEMM tile with FOUR waves of 128 x 128 (one per SIMD, accumulators in the
 // AGPR half) instead of k_gemm256's eight of 128 x 64.  Built in round 5, bit-identical to k_gemm256 / k_gemm in every
-// epilogue, MEASURED SLOWER (profiles/r05_e_gemm256q.log: FFN-up 26.5 against 23.8 us, FFN-down 52.6 against 47.4 us at
+// epilogue, MEASURED SLOWER (profiles/archive/r05_e_gemm256q.log: FFN-up 26.5 against 23.8 us, FFN-down 52.6 against 47.4 us at
 // M = 8064; 15-25 % at M = 32,256) and therefore not part of the library: it is compiled only into tools/gemm_bench
 // (mode 3), which defines QV_GEMM_Q_VARIANT to this file before including csrc/qv_gemm256.hip.
 // What the ablations say (QV_Q_ABL, same log): without its buffer loads the kernel is no faster, without loads, stage stores

@@ -6,7 +6,7 @@
 Prints one JSON line: ms per batch of 64 x 10 s clips, `contexts` batches in flight, no results fetched (tools/sweep.py's
 loop).  Until round 5 `engine_first` read 4.7-4.8 ms against 3.5 for the other two: the legacy default stream -- the
 stream the batches are ordered behind -- got its hardware queue only after the engine's streams and shared one with a
-context stream (qv_create now runs one kernel on it first; profiles/r05_r_init_order.log,
+context stream (qv_create now runs one kernel on it first; profiles/archive/r05_r_init_order.log,
 tests/test_gpu_bench.py::test_engine_created_before_any_other_device_work_runs_at_full_speed)."""
 import argparse
 import ctypes as C

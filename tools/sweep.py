@@ -88,7 +88,7 @@ def main():
     rows.append({"case": "tta_30s_all_gated", "batch": B, "audio_seconds_per_batch": 1920.0,
                  "ms_per_batch": round(dt / nst * 1e3, 3), "utterances_per_s": round(B * nst / dt, 1),
                  "audio_seconds_per_s": round(1920.0 * nst / dt, 1),
-                 "note": "anchor + 0.9x + 1.1x passes of all 64 clips, 128 resampler launches per batch"})
+                 "note": "anchor + 0.9x + 1.1x passes of all 64 clips, two batched resampler launches per batch (qv_upfirdn_batch)"})
     print(json.dumps(rows[-1]), flush=True)
     doc = {"what": "c2c-direct-mixed hot path, one MI355X, synthetic clips resident in HBM, whole path per batch",
            "batches_in_flight": eng.contexts, "weights": args.precision, "steps": args.steps, "rows": rows}
