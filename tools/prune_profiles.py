@@ -48,7 +48,9 @@ def main():
     pat = re.compile(r"profiles/(" + "|".join(re.escape(n) for n in names) + r")(?![A-Za-z0-9_.\-])")
     changed = 0
     for t in tracked:
-        if not t or t.startswith("profiles/") and not t.endswith(".md") or t.startswith("tests/golden/"):
+        # (driver-written records at the repo root -- BENCH_r*.json, GPUTEST_r*.json, VERDICT.md, ... -- are never touched)
+        if not t or t.startswith("profiles/") and not t.endswith(".md") or t.startswith("tests/golden/") or (
+                "/" not in t and (t.endswith(".json") or t.endswith(".jsonl") or t in ("VERDICT.md", "ADVICE.md", "SURVEY.md", "BASELINE.md"))):
             continue
         p = ROOT / t
         if not p.is_file() or p.suffix in (".gz", ".bin", ".npz", ".so", ".png"):
