@@ -238,6 +238,9 @@ def run_experiment_sharded(exp: dict, samples: list[dict] | None, corpus_dir: Pa
         box = [(present, order.tolist())]
     dist.broadcast_object_list(box, src=0, group=group)
     present, order = box[0]
+    if not present:      # nothing to predict (no audio under the corpus directory): no collective with empty rows
+        return None if rank != 0 else {"name": exp["name"], "recall": 0, "precision": 0, "sequence_accuracy": 0, "total": 0,
+                                       "avg_latency": 0, "model_size": 0, "per_sample": [], "world_size": world}
     order = np.asarray(order, dtype=np.int64)
     per = len(order) // world
     mine = [int(i) for i in order[rank * per: (rank + 1) * per]]

@@ -425,3 +425,24 @@ def test_four_decimal_scores_survive_the_float32_rows():
     rows = pack_results([{"surah": 1, "ayah": 1, "ayah_end": None, "score": v} for v in vals])
     back = unpack_results(rows, round_dp=4)
     assert [b["score"] for b in back] == vals
+
+
+def test_sharded_runner_with_fewer_files_than_ranks_and_with_none(tmp_path):
+    """edge cases of the sharded entry on two gloo ranks: ONE present file (rank 1's share is all padding) and NO present file
+    (no collective is attempted: both ranks leave through the same door)."""
+    corpus, exps = _stub_corpus(tmp_path)
+    m = json.loads((corpus / "manifest.json").read_text())
+    base = dict(os.environ, PYTHONPATH=str(ROOT), QVERSE_EXPERIMENTS_DIR=str(exps), MASTER_ADDR="127.0.0.1", QVERSE_DIST_BACKEND="gloo")
+    for tag, keep, port in (("one", [m["samples"][0]], "29557"), ("none", [m["samples"][-1]], "29559")):     # the last row's file is absent
+        (corpus / "manifest.json").write_text(json.dumps({"samples": keep}))
+        out = tmp_path / f"res_{tag}"
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", port, "-m", "offline_tarteel_amd.benchmark.runner", "--experiment", "stub-exp",
+                            "--corpus", str(corpus), "--batch", "3"],
+                           capture_output=True, text=True, cwd=str(ROOT), timeout=300, env=dict(base, QVERSE_RESULTS_DIR=str(out)))
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = [f for f in sorted(out.glob("*.json")) if f.name != "latest.json"]
+        doc = json.loads(files[0].read_text())
+        assert doc[0]["total"] == (1 if tag == "one" else 0) and doc[0]["world_size"] == 2
+        if tag == "one":
+            assert doc[0]["per_sample"][0]["id"] == "s0"
