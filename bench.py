@@ -546,7 +546,8 @@ def main():
     if args.capacity_seconds > 0:
         cap = max(cap, int(args.capacity_seconds * 16000))
     # TTA: anchor pass of the next step + the two perturbed batches of this one: three batches in flight at most
-    n_ctx = min(args.contexts, 3) if tta else args.contexts
+    # TTA: two anchor passes ahead + the two perturbed batches of the step being decided: four batches in flight at most
+    n_ctx = min(args.contexts, 4) if tta else args.contexts
     eng = Engine(device=local_rank, with_model=True, seed=20260630, max_batch=B, max_samples=cap,
                  precision={"fp16": 0, "mixed": 1, "ort": 2}[args.precision], skip_unused_passes=not args.literal,
                  contexts=n_ctx)
@@ -601,6 +602,7 @@ def main():
             (gather if use_dist else fetch)(pending.pop(0))
 
     tta_prev = []   # the previous step's TTA state while its perturbed batches are still in flight
+    tta_anchors = []   # contexts of anchor passes launched ahead (four contexts: two ahead)
     tta_lp = None
     if tta and args.tta_mix:
         # anchor passes read verse-shaped log-probs: clean ones (text match >= 0.80, far above the 0.5 gate) and corrupted
@@ -641,7 +643,16 @@ def main():
         # previous step's perturbed batches are joined, so the two run side by side.
         from offline_tarteel_amd.plugin import tta_start
 
-        if n_ctx >= 3:
+        if n_ctx >= 4:
+            # Round 6: TWO anchor passes ahead.  With one (below) the host joins step k - 1's perturbed batches and then waits
+            # for anchor k with nothing else on the chip; here anchor k + 1 is already running beside it, and the perturbed
+            # batches of step k run beside anchors k + 1 and k + 2 -- what a serving loop with a queue of batches does.
+            tta_anchors.append(anchor_pass())
+            if len(tta_anchors) >= 2:
+                while tta_prev:
+                    tta_done(tta_prev.pop(0))
+                tta_prev.append(tta_start(eng, audio, lengths, want_text=False, anchor_ctx=tta_anchors.pop(0)))
+        elif n_ctx >= 3:
             ctx = anchor_pass()
             if tta_prev:
                 tta_done(tta_prev.pop())
@@ -666,6 +677,12 @@ def main():
     step = step_tta if tta else step_strong if strong else step_clips
 
     def sync_all():
+        while tta_anchors:       # the anchors launched ahead are decided too: every timed step's clips come back inside the region
+            from offline_tarteel_amd.plugin import tta_start
+
+            while tta_prev:
+                tta_done(tta_prev.pop(0))
+            tta_prev.append(tta_start(eng, audio, lengths, want_text=False, anchor_ctx=tta_anchors.pop(0)))
         while tta_prev:
             tta_done(tta_prev.pop())
         while pending:

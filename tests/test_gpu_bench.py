@@ -50,7 +50,7 @@ def test_bench_tta30_workload_small():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _line(p.stdout)
     assert "TTA" in d["metric"] and d["config"]["tta_gated_fraction"] == 1.0 and d["value"] > 0
-    assert "configs[4]" in d["config"]["workload"] and d["config"]["batches_in_flight"] == 3
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["batches_in_flight"] == 4
 
 
 def test_bench_tta30_with_the_reference_gate_ratio_small():
@@ -89,7 +89,7 @@ def test_bench_tta30_under_torchrun_with_collective_path():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = _line(p.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and "TTA" in d["metric"]
-    assert d["config"]["tta_gated_fraction"] == 1.0 and d["config"]["batches_in_flight"] == 3
+    assert d["config"]["tta_gated_fraction"] == 1.0 and d["config"]["batches_in_flight"] == 4
 
 
 _CTX_PROG = r"""
