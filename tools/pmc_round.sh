@@ -8,6 +8,9 @@ TAG=${1:-x}; ROWS=${2:-8064}
 O=$R/gpurun_out/pmc_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+# tile height fixed to 256 rows: what the engine runs with three or more batches in flight (the bench line the numbers are quoted in);
+# left to the policy, a lone gemm_bench launch at M = 8,064 picks 192-row tiles for the N = 512 shapes and the kernel names no longer match
+export QVERSE_GEMM_BM=0
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch" -o p -- "$R/tools/gemm_bench" 10 $ROWS > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/write" -o p -- "$R/tools/gemm_bench" 10 $ROWS > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/sq" -o p -- "$R/tools/gemm_bench" 10 $ROWS > "$O/sq.log" 2>&1
