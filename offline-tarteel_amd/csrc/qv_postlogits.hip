@@ -1755,7 +1755,9 @@ __device__ void ctc_wave2(const float *__restrict__ lp, int T, const uint16_t *_
         if (s == 0) a[k] = lp[QV_BLANK] * LOG2E;
         if (s == 1) a[k] = lp[tok[k]] * LOG2E;
     }
-    constexpr int TCH = NS <= 2 ? 8 : (NS <= 6 ? 4 : 2);
+    // (a parity-specialised lane gathers only its NS / 2 token states + the one blank value per frame: four frames ahead fit
+    // the registers up to NS = 8, where the generic program stopped at NS = 6)
+    constexpr int TCH = NS <= 2 ? 8 : (NS <= (PAR ? 8 : 6) ? 4 : 2);
     for (int t0 = 1; t0 < T; t0 += TCH) {
         float lpv[TCH][NS], lpb[TCH];
 #pragma unroll
