@@ -1633,7 +1633,41 @@ __device__ void candidates_block(const QvTables &tab, const QvWork &wk, const Qv
         else memb[(size_t)leader * QV_MAX_SPAN + sp - 1] = (int16_t)c;
     }
     __syncthreads();
-    if (tid == 0) u.n_lead = *nlead;
+    // Round 6: the leaders in order of DECREASING state count (64-state buckets).  k_ctc hands leader i to wave i mod 256 of the
+    // utterance: with ~400 leaders of 64 ... 448 states in arbitrary order, a wave could draw two long recursions and another two
+    // short ones; sorted, the waves that take a second leader take the SHORTEST ones.  The order changes no loss.
+    {
+        const int nl = *nlead;
+        int32_t *bcnt = (int32_t *)pscore;                 // [16] bucket counts, then [16] bucket offsets (pscore is dead by now)
+        int16_t *tmp = (int16_t *)(bcnt + 32);             // [QV_CAND_CAP]
+        if (tid < 32) bcnt[tid] = 0;
+        __syncthreads();
+        int bk[QV_CAND_CAP / 256], ps[QV_CAND_CAP / 256];
+#pragma unroll
+        for (int j = 0; j < QV_CAND_CAP / 256; ++j) {
+            const int i = tid + j * 256;
+            bk[j] = -1;
+            if (i < nl) {
+                const int c = lead[i], st = cs[c], sp = cp[c];
+                const size_t k0 = (size_t)st * QV_MAX_SPAN;
+                const int L = (int)(tab.tok_off[k0 + sp] - tab.tok_off[k0 + sp - 1]);
+                bk[j] = 15 - min(15, L >> 5);             // bucket 0 = the longest targets
+                ps[j] = atomicAdd(&bcnt[bk[j]], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int k = 0; k < 16; ++k) { bcnt[16 + k] = run; run += bcnt[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < QV_CAND_CAP / 256; ++j)
+            if (bk[j] >= 0) tmp[bcnt[16 + bk[j]] + ps[j]] = lead[tid + j * 256];
+        __syncthreads();
+        for (int i = tid; i < nl; i += 256) lead[i] = tmp[i];
+        if (tid == 0) u.n_lead = nl;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_candidates(QvTables tab, QvWork wk, QvKnobs kn) {
@@ -1838,11 +1872,14 @@ __device__ void ctc_dispatch(const float *lp, int T, const uint16_t *tgt, int L,
 template <bool LONG, int VAR>
 __global__ __launch_bounds__(256) void k_ctc(QvTables tab, QvWork wk, QvKnobs kn, const float *__restrict__ lp, int t_max) {
     __shared__ float sa_all[4][LONG ? 768 : 384];
-    if ((int)blockIdx.y >= *wk.n_fail) return;
-    int b = wk.fail_list[blockIdx.y];
+    // grid = (utterance, block of four leader slots): the hardware dispatches workgroups x-fastest, and k_candidates sorted the
+    // leaders by decreasing state count -- so EVERY utterance's longest recursions start first and the shortest ones fill the tail
+    // (with the utterance on y, the last utterances' long leaders started when everything else was done)
+    if ((int)blockIdx.x >= *wk.n_fail) return;
+    int b = wk.fail_list[blockIdx.x];
     const QvUtt &u = wk.utt[b];
     if (!u.use_ctc) return;
-    int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    int lane = threadIdx.x & 63, wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwave = gridDim.y * 4;
     float *sa = sa_all[threadIdx.x >> 6];
     int T = u.t_frames;
     const float *lpb = lp + (size_t)b * t_max * QV_VOCAB;
@@ -2101,11 +2138,11 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
         // 30 s clips used to run every 10 s batch through it (round 4: tools/sweep.py's 10 s row, 4.8 ms, against bench.py's
         // 3.8 ms for the same batch on an engine sized for it).  2L + 1 <= T <= t_max <= 384 holds for every candidate then.
         else if (qv_kernel_variant(QV_KV_CTC) == 0) {
-            if (t_max > 384) hipLaunchKernelGGL((k_ctc<true, 0>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
-            else hipLaunchKernelGGL((k_ctc<false, 0>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+            if (t_max > 384) hipLaunchKernelGGL((k_ctc<true, 0>), dim3(batch, 64), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+            else hipLaunchKernelGGL((k_ctc<false, 0>), dim3(batch, 64), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
         }
-        else if (t_max > 384) hipLaunchKernelGGL((k_ctc<true, 1>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
-        else hipLaunchKernelGGL((k_ctc<false, 1>), dim3(64, batch), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        else if (t_max > 384) hipLaunchKernelGGL((k_ctc<true, 1>), dim3(batch, 64), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
+        else hipLaunchKernelGGL((k_ctc<false, 1>), dim3(batch, 64), dim3(256), 0, stream, tab, wk, eng->knobs, lp, t_max);
         hipLaunchKernelGGL(k_result, dim3(batch), dim3(256), 0, stream, tab, wk, batch);
         qv_stage_mark(eng, 4, stream);
         return QV_OK;
