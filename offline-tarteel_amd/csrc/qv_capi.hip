@@ -446,7 +446,8 @@ static int alloc_work(qv_engine *eng, int k) {
     QV_TRY(dalloc(eng, Bz * N * 3, &w.fs));
     QV_TRY(dalloc(eng, Bz * N, &w.lcs_p3));
     QV_TRY(dalloc(eng, Bz * N * 3, &w.frag_list));
-    QV_TRY(dalloc(eng, (size_t)2, &w.frag_ctr));
+    QV_TRY(dalloc(eng, (size_t)4, &w.frag_ctr));
+    w.frag_cap = (int)(Bz * N * 3);
     w.search_sc = nullptr;
     QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.runner_idx));
     QV_TRY(dalloc(eng, Bz * QV_RUNNER_CAP, &w.runner_score));

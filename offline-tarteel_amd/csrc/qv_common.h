@@ -135,7 +135,8 @@ struct QvWork {
     double *fs;              // [B][N][3] fragment scores (clean, alt, nobsm)
     int16_t *lcs_p3;         // [B][N]   pass 3: LCS(spaceless transcript, clean text) (k_lcs_full mode 1)
     uint32_t *frag_list;     // [B * N * 3] texts whose fragment score needs the window scan: utterance << 15 | verse << 2 | variant
-    int32_t *frag_ctr;       // [2] entries in frag_list; work-stealing cursor of k_frag
+    int32_t *frag_ctr;       // [4]: expensive entries (front of frag_list), work-stealing cursor of k_frag, cheap entries (back of the list)
+    int frag_cap;            // entries frag_list holds
     double *search_sc;       // [B][N]   search score (max over clean/alt)
     int32_t *runner_idx;     // [B][QV_RUNNER_CAP]
     double *runner_score;    // [B][QV_RUNNER_CAP]

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(QvTables tab, QvWork 
     __shared__ int16_t s_fid[QV_TCAP];
     __shared__ int32_t s_tok[QV_TCAP];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (b == 0 && tid == 0) { *wk.n_fail = 0; wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
+    if (b == 0 && tid == 0) { *wk.n_fail = 0; wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; wk.frag_ctr[2] = 0; }
     QvUtt &u = wk.utt[b];
     const int T = t_dev[b];
     // a wave takes every 16th frame; the 17 loads of a row are all requested before the first comparison (a frame's
@@ -732,6 +732,7 @@ __device__ __forceinline__ TextRef text_of(const QvTables &tab, int v, int varia
 #define FRAG_STEP 4          // anchor spacing of the coarse pass (power of two, >= 4)
 #endif
 #define FRAG_SCRATCH 2112      // int16 per wave: anchors [QV_MAXQ / 4 + 2] + refine list [QV_MAXQ]
+#define FRAG_HEAVY 1200       // word-steps per lane above which a window scan counts as expensive (k_lcs_full's two-ended list)
 #define FRAG_GRID 1024         // blocks of k_frag (4 waves each): four per CU, the list is consumed by whoever is free
 #define FRAG_PM_STRIDE (QV_MAXW + 1)   // u64 per symbol row of the wave's LDS copy of the pattern masks (odd: rows spread over the banks)
 __device__ __forceinline__ void frag_job(const QvTables &tab, const QvWork &wk, int b, int v, int variant, int lane, int16_t *scratch, uint64_t *lpm) {
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
                 sub = ok;
             }
         }
-        bool need = false;
+        bool need = false, heavy = false;
         if (sub) *fs = fr > 0.98 ? fr : 0.98;
         else if (short_q || vw < 2) *fs = fr;                 // no windows below 4 query words / 2 verse words
         else {
@@ -924,16 +925,25 @@ __global__ __launch_bounds__(256) void k_lcs_full(QvTables tab, QvWork wk, int m
                 bl = fr > blended ? fr : blended;
             }
             if (bl == fr) *fs = fr;
-            else need = true;
+            else {
+                need = true;
+                // Round 6: what the scan will cost (rounds of 64 windows x pattern length x words), so that k_frag can start the
+                // expensive items first: they go to the FRONT of the list, the cheap ones fill it from the BACK, and the queue is
+                // consumed front to back -- the longest scans no longer start when everything else is done
+                const int nwin = (m <= n ? n : m) - s + 1, nev = nwin <= FRAG_DIRECT_MAX ? nwin : (nwin + FRAG_STEP - 1) / FRAG_STEP + 1;
+                heavy = ((nev + 63) >> 6) * s * ((s + 63) >> 6) >= FRAG_HEAVY;
+            }
         }
-        // wave-aggregated append to the work list
-        const unsigned long long mask = __ballot(need);
+        // wave-aggregated append to the work list (two ends)
+        const unsigned long long mh = __ballot(need && heavy), ml = __ballot(need && !heavy);
         if (need) {
+            const unsigned long long mask = heavy ? mh : ml;
             const int leader = __ffsll((long long)mask) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&wk.frag_ctr[0], __popcll(mask));
+            if (lane == leader) base = atomicAdd(&wk.frag_ctr[heavy ? 0 : 2], __popcll(mask));
             base = __shfl(base, leader);
-            wk.frag_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)b << 15) | ((uint32_t)v << 2) | (uint32_t)variant;
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            wk.frag_list[heavy ? pos : wk.frag_cap - 1 - pos] = ((uint32_t)b << 15) | ((uint32_t)v << 2) | (uint32_t)variant;
         }
     }
 }
@@ -949,10 +959,10 @@ __global__ __launch_bounds__(256) void k_frag(QvTables tab, QvWork wk) {
     for (int i = threadIdx.x & 63; i < FRAG_PM_STRIDE; i += 64) lpm[QV_NSYM * FRAG_PM_STRIDE + i] = 0ull;   // the all-zero row
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
-    const int n_items = wk.frag_ctr[0];
+    const int n_heavy = wk.frag_ctr[0], n_items = n_heavy + wk.frag_ctr[2];
     int idx = wave;
     while (idx < n_items) {
-        const uint32_t it = wk.frag_list[idx];
+        const uint32_t it = wk.frag_list[idx < n_heavy ? idx : wk.frag_cap - 1 - (idx - n_heavy)];
         frag_job(tab, wk, (int)(it >> 15), (int)((it >> 2) & 0x1FFFu), (int)(it & 3u), lane, scratch, lpm);
         int nx = 0;
         if (lane == 0) nx = atomicAdd(&wk.frag_ctr[1], 1);
@@ -1084,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_spans(QvTables tab, QvWork wk, QvKnobs 
     // tables in L2.)
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
     // pass 1's window scans are done, search()'s have not started: empty the fragment work list
-    if (blk == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
+    if (blk == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; wk.frag_ctr[2] = 0; }
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
@@ -1242,7 +1252,7 @@ __global__ __launch_bounds__(256) void k_spans2(QvTables tab, QvWork wk, QvKnobs
     __shared__ unsigned long long sh_k[8];
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
     // pass 1's window scans are done, search()'s have not started: empty the fragment work list
-    if (blk == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
+    if (blk == 0 && b == 0 && tid == 0) { wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; wk.frag_ctr[2] = 0; }
     const QvUtt &u = wk.utt[b];
     double best = -1.0;
     unsigned long long bkey = ~0ull;
@@ -1982,7 +1992,7 @@ __global__ __launch_bounds__(256) void k_result(QvTables tab, QvWork wk, int bat
 
 __global__ void k_init_utts(QvWork wk, const int32_t *__restrict__ t_dev, int batch) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) { *wk.n_fail = 0; wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; }
+    if (b == 0) { *wk.n_fail = 0; wk.frag_ctr[0] = 0; wk.frag_ctr[1] = 0; wk.frag_ctr[2] = 0; }
     if (b < batch) wk.utt[b].t_frames = t_dev[b];
 }
 
