@@ -319,10 +319,11 @@ int qv_debug_gemm_tile_height(int32_t mode);
 /* Process-wide attention kernel variant, for the tests: 3 = the default: an utterance of at most 128 encoder frames
  * (10.2 s) is served by the single-pass short-utterance kernel, a longer one by the key-tiled kernel -- by its OWN length,
  * so the bits of an utterance never depend on the batch it travels in; 0 = the key-tiled kernel (two heads per block)
- * for every utterance, 1 = one head per block, 2 = one wave per query tile; -1 = back to the environment
- * (QVERSE_ATT_TILED=1 / QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1, read once per process) / default.  Variants 0..2 give
- * identical bits; 3 differs from them for short utterances by the softmax's summation order only (one pass over the row
- * instead of a running maximum). */
+ * for every utterance, 1 = one head per block, 2 = one wave per query tile, 4 = k_attention_x (key-tiled, four self-staging
+ * waves per (head, 128-query group), two blocks per CU) for every utterance, 5 = the short-utterance kernel + k_attention_x;
+ * -1 = back to the environment (QVERSE_ATT_X=1 / QVERSE_ATT_TILED=1 / QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1, read once per
+ * process) / default.  Variants 0, 1, 2, 4 give identical bits, so do 3 and 5; 3 / 5 differ from the others for short
+ * utterances by the softmax's summation order only (one pass over the row instead of a running maximum). */
 int qv_debug_attention_variant(int32_t mode);
 
 /* Process-wide variant of a single kernel, for the tests that compare two implementations of one stage bit for bit

@@ -1035,7 +1035,7 @@ extern "C" int qv_weights_info(qv_engine *eng, char *out, int32_t cap) {
 }
 
 extern "C" int qv_debug_attention_variant(int32_t mode) {
-    if (mode < -1 || mode > 3) return QV_ERR_ARG;
+    if (mode < -1 || mode > 5) return QV_ERR_ARG;
     qv_attention_set_variant(mode);
     return QV_OK;
 }

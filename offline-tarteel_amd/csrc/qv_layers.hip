@@ -1162,6 +1162,201 @@ __global__ __launch_bounds__(256 * HPB + 256) void k_attention_ws(const half_t *
     }
 }
 
+// Round 6, variant 4: the key-tiled computation WITHOUT loader waves and with TWO independent blocks per CU.
+// k_attention_ws<2, 2, 192> is bound by the instruction issue of the two consumer waves of a SIMD, and those two run in lock
+// step: both heads of a block leave the same barrier, so both are in their MFMA phase, then both in their softmax phase
+// (stamps: tools/att_bench).  Here a block is ONE (head, 128-query group, utterance) with four waves that stage their own
+// tiles -- each wave issues its quarter of the K, V^T and position loads of key tile kt + 1 (three 1 KB direct-to-LDS loads)
+// right after the barrier that released tile kt -- in 74 KB of LDS and, without loader waves, 256 threads: two blocks per
+// CU, 256 registers per wave.  The two consumer waves of a SIMD then belong to DIFFERENT blocks, whose barriers are
+// independent: one wave's matrix products run under the other's softmax.  Same wave program per (head, query tile) as the
+// other key-tiled shapes => the same bits (tests/test_gpu_forward.py compares variants 0, 1, 2 and 4).
+template <int RING>
+__global__ __launch_bounds__(256, 2) void k_attention_x(const half_t *__restrict__ qk, const half_t *__restrict__ vt,
+                                                         const half_t *__restrict__ pos, int pos_ld,
+                                                         const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                         const int32_t *__restrict__ len, const int32_t *__restrict__ row_off,
+                                                         half_t *__restrict__ out, int t_max, int t_pad, int t_short) {
+    static_assert(RING % 32 == 0 && RING >= 160 + 32, "position ring: window + the rows of the next tile");
+    __shared__ __attribute__((aligned(16))) half_t sK[2][32 * 64];      // [key][d], 16-B chunks swizzled by (key >> 1) & 7
+    __shared__ __attribute__((aligned(16))) half_t sV[2][64 * 32];      // [d][key], 16-B chunks swizzled by (d >> 2) & 3
+    __shared__ __attribute__((aligned(16))) half_t sP[RING * 64];       // ring of position rows, swizzled like sK
+    __shared__ float slab[4][32 * ATT_LDS_LD];
+    const int b = blockIdx.z, qg = blockIdx.y, h = blockIdx.x;
+    const int T = len[b];
+    if (qg * 128 >= T || T <= t_short) return;
+    const int w4 = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const size_t row0 = (size_t)row_off[b];
+    const int n_kt = (T + 31) >> 5;
+    const int Rb = t_max - 128 * qg - 128;           // first position row of key tile 0's window
+    const half_t *kb = qk + row0 * (2 * QV_D) + QV_D + h * QV_DK;
+    const half_t *vb = vt + ((size_t)b * QV_D + h * QV_DK) * t_pad;
+    const half_t *pb = pos + h * QV_DK;
+    auto stage = [&](int kt) {                        // this wave's quarter of key tile kt: 8 keys of K, 16 d rows of V^T
+        const int j0 = kt * 32, buf = kt & 1;
+        {
+            int r = w4 * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            int kj = j0 + r;
+            kj = kj < T ? kj : T - 1;
+            att_glds16(kb + (size_t)kj * (2 * QV_D) + c * 8, sK[buf] + w4 * 512);
+        }
+        {
+            int r = w4 * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+            att_glds16(vb + (size_t)r * t_pad + j0 + c * 8, sV[buf] + w4 * 512);
+        }
+    };
+    auto pos_rows = [&](int first, int n8) {          // n8 chunks of 8 rows starting at window row `first`, this wave's share
+        for (int q = w4; q < n8; q += 4) {
+            int wr = first + q * 8 + (lane >> 3);
+            int ring = wr % RING;
+            int c = (lane & 7) ^ ((ring >> 1) & 7);
+            int rr = Rb + wr;
+            rr = rr < 0 ? 0 : (rr > 2 * t_max - 2 ? 2 * t_max - 2 : rr);
+            att_glds16(pb + (size_t)rr * pos_ld + c * 8, sP + (size_t)((first + q * 8) % RING) * 64);
+        }
+    };
+    pos_rows(0, 20);                                  // rows 0 .. 159: the window of tile 0
+    stage(0);
+
+    const int i0 = qg * 128 + w4 * 32;
+    const bool active = i0 < T;
+    const half_t *qb = qk + row0 * (2 * QV_D) + h * QV_DK;
+    float *sl = slab[w4];
+    half8 qu[4], qv[4];
+    {
+        int qi = i0 + l31;
+        qi = qi < T ? qi : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            int d = ks * 16 + hi * 8;
+            half8 q8 = *(const half8 *)(qb + (size_t)qi * (2 * QV_D) + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float qf = (float)q8[e];
+                qu[ks][e] = (half_t)(qf + bias_u[h * QV_DK + d + e]);
+                qv[ks][e] = (half_t)(qf + bias_v[h * QV_DK + d + e]);
+            }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    // (the wave program below is k_attention_ws's, statement for statement: raw-unit softmax, mask in the last tile only,
+    // alternating slab halves with wrap-free addressing)
+    constexpr float NEG = -1e30f * 8.0f, L2E8 = 0x1.715476p+0f * 0.125f;
+    float m_run = NEG, l_run = 0.f;
+    const int swz = (l31 >> 1) & 7;
+    const int kf0 = l31 * 64 + ((hi ^ swz) << 3);
+    float *const slw = sl + l31 * ATT_LDS_LD + 4 * hi;
+    const float *const slr = sl + l31 * ATT_LDS_LD + (31 - l31 + 4 * hi);
+    unsigned hiw = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hiw |= (unsigned)((r & 3) + 8 * (r >> 2) >= 1 + l31 - 4 * hi) << r;
+    const int vda = l31 * 32 + 4 * hi, vdc = (32 + l31) * 32 + 4 * hi, vsw = (l31 >> 2) & 3;
+    int ring1 = (128 - 32 * w4) % RING;
+    auto tile = [&](int kt, auto masked_c, auto odd_c) {
+        constexpr bool MASKED = decltype(masked_c)::value, ODD = decltype(odd_c)::value;
+        const int j0 = kt * 32, buf = kt & 1;
+        const half_t *sKb = sK[buf], *sVb = sV[buf];
+        f32x16 st, r1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; r1[r] = 0.f; }
+        if (!ODD && kt == 0) {
+            const int ring0 = (96 - 32 * w4) % RING;
+            f32x16 r0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r0[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                half8 p0 = *(const half8 *)(sP + ring0 * 64 + (kf0 ^ (ks << 4)));
+                r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, qv[ks], r0, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slw[(r & 3) + 8 * (r >> 2)] = r0[r];
+        }
+        const half_t *sP1 = sP + ring1 * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 kf = *(const half8 *)(sKb + (kf0 ^ (ks << 4)));
+            half8 p1 = *(const half8 *)(sP1 + (kf0 ^ (ks << 4)));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], st, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, qv[ks], r1, 0, 0, 0);
+        }
+        ring1 += 32;
+        if (ring1 >= RING) ring1 -= RING;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slw[(ODD ? 0 : 32) + (r & 3) + 8 * (r >> 2)] = r1[r];
+        __builtin_amdgcn_wave_barrier();
+        float p[16];
+        float mx = NEG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int e = (r & 3) + 8 * (r >> 2);
+            const float bd = !ODD ? slr[e] : *(const float *)((const char *)(slr + 32 + e) - (((hiw >> r) & 1u) << 8));
+            const float sc = st[r] + bd;
+            p[r] = (!MASKED || j0 + jj < T) ? sc : NEG;
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * L2E8);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float e = (!MASKED || j0 + jj < T) ? __builtin_amdgcn_exp2f((p[r] - m_new) * L2E8) : 0.f;
+            p[r] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * corr + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 pbf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pbf[e] = (half_t)p[8 * ks + e];
+            half4 a0 = *(const half4 *)(sVb + vda + (((2 * ks) ^ vsw) << 3));
+            half4 a1 = *(const half4 *)(sVb + vda + (((2 * ks + 1) ^ vsw) << 3));
+            half4 c0 = *(const half4 *)(sVb + vdc + (((2 * ks) ^ vsw) << 3));
+            half4 c1 = *(const half4 *)(sVb + vdc + (((2 * ks + 1) ^ vsw) << 3));
+            half8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            half8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pbf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pbf, o1, 0, 0, 0);
+        }
+    };
+    for (int kt = 0; kt < n_kt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarter of tile kt (and of its position rows) has landed ...
+        __builtin_amdgcn_s_barrier();                        // ... and everybody's; everybody has left tile kt - 1's buffers
+        if (kt + 1 < n_kt) {
+            stage(kt + 1);
+            pos_rows(32 * (kt + 1) + 128, 4);               // the 32 new rows of that tile
+        }
+        if (!active) continue;
+        if (kt + 1 < n_kt) { if (kt & 1) tile(kt, std::false_type{}, std::true_type{}); else tile(kt, std::false_type{}, std::false_type{}); }
+        else { if (kt & 1) tile(kt, std::true_type{}, std::true_type{}); else tile(kt, std::true_type{}, std::false_type{}); }
+    }
+    if (active && i0 + l31 < T) {
+        float inv = 1.f / l_run;
+        half_t *o = out + (row0 + i0 + l31) * QV_D + h * QV_DK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int d = 8 * q + 4 * hi;
+            half4 h0, h1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h0[e] = (half_t)(o0[4 * q + e] * inv); h1[e] = (half_t)(o1[4 * q + e] * inv); }
+            *(half4 *)(o + d) = h0;
+            *(half4 *)(o + 32 + d) = h1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ conv module --------
 // depthwise Conv1d(512, k=9, pad 4) + folded BatchNorm + Swish on f16 [M][512]; input frames
 // t >= len[b] read as zero (the reference zeroes padded frames after GLU).  A lane owns 8
@@ -1341,10 +1536,14 @@ void launch_to_float(const half_t *x, float *y, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
 }
 
-// Cross-check variants of the attention kernel (tests/test_gpu_forward.py): 3 = the default (an utterance of at most
-// ATT_SHORT_T frames on k_attention_short, a longer one key-tiled), 0 = key-tiled with two heads per block for every
-// utterance, 1 = one head per block (3 K/V stages, 256-row ring), 2 = the one-wave-per-query-tile kernel the specialised
-// one replaced; 0..2 are bit-identical.  The environment (QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1) is read ONCE per process; tests switch with
+// Variants of the attention kernel (tests/test_gpu_forward.py): 3 = the default (an utterance of at most ATT_SHORT_T
+// frames on k_attention_short, a longer one on k_attention_ws with two heads per block), 0 = k_attention_ws with two heads per
+// block for every utterance, 1 = one head per block (3 K/V stages, 256-row ring), 2 = the one-wave-per-query-tile kernel the
+// specialised ones replaced, 4 = k_attention_x (round 6: four self-staging waves per (head, query group), two blocks per CU)
+// for every utterance, 5 = k_attention_short + k_attention_x; 0, 1, 2 and 4 are bit-identical, so are 3 and 5.
+// k_attention_x is 4-10 % faster than k_attention_ws launched back to back (tools/att_bench) and level with it inside the
+// forward with batches in flight (profiles/r06_p_attention_x_same_box.log), so it stays a variant.  The environment
+// (QVERSE_ATT_X=1 / QVERSE_ATT_HPB=1 / QVERSE_ATT_OLD=1 / QVERSE_ATT_TILED=1) is read ONCE per process; tests switch with
 // qv_debug_attention_variant() instead of setenv, which is not safe against launches from another thread.
 static std::atomic<int> g_att_variant{-1};
 void qv_attention_set_variant(int mode) { g_att_variant.store(mode); }
@@ -1352,8 +1551,9 @@ static int attention_variant() {
     static const int env = [] {
         // QVERSE_ATT_OLD=1: one wave per query tile; QVERSE_ATT_HPB=1: one head per block; QVERSE_ATT_TILED=1: the
         // two-heads-per-block kernel for every utterance (no k_attention_short)
-        const char *o = getenv("QVERSE_ATT_OLD"), *h = getenv("QVERSE_ATT_HPB"), *t = getenv("QVERSE_ATT_TILED");
-        return (o && o[0] == '1') ? 2 : (h && h[0] == '1') ? 1 : (t && t[0] == '1') ? 0 : 3;
+        // ... QVERSE_ATT_X=1: k_attention_x instead of k_attention_ws for the long utterances (variant 5)
+        const char *o = getenv("QVERSE_ATT_OLD"), *h = getenv("QVERSE_ATT_HPB"), *t = getenv("QVERSE_ATT_TILED"), *x = getenv("QVERSE_ATT_X");
+        return (o && o[0] == '1') ? 2 : (h && h[0] == '1') ? 1 : (t && t[0] == '1') ? 0 : (x && x[0] == '1') ? 5 : 3;
     }();
     const int v = g_att_variant.load();
     return v < 0 ? env : v;
@@ -1376,14 +1576,17 @@ void launch_attention(const half_t *qk, const half_t *vt, const half_t *pos, int
     // wave-specialised kernel -- by its OWN length, so that its bits do not depend on the batch it travels in; a launch
     // none of whose utterances qualify is skipped (t_min / t_max are the batch's shortest / longest utterance)
     int t_short = 0;
-    if (variant == 3) {
+    if (variant == 3 || variant == 5) {      // 5: k_attention_short for short utterances, k_attention_x for the longer ones
         t_short = ATT_SHORT_T;
         if (t_min <= ATT_SHORT_T)
             hipLaunchKernelGGL(k_attention_short, dim3(QV_H, batch), dim3(256), 0, s, qk, vt, pos, pos_ld, bu, bv, len, row_off,
                                out, t_max, t_pad);
         if (t_max <= ATT_SHORT_T) return;
     }
-    if (variant == 1)
+    if (variant == 4 || variant == 5)
+        hipLaunchKernelGGL((k_attention_x<192>), dim3(QV_H, (t_max + 127) / 128, batch), dim3(256), 0, s, qk, vt, pos,
+                           pos_ld, bu, bv, len, row_off, out, t_max, t_pad, t_short);
+    else if (variant == 1)
         hipLaunchKernelGGL((k_attention_ws<1, 3, 256>), dim3(QV_H, (t_max + 127) / 128, batch), dim3(512), 0, s, qk, vt, pos,
                            pos_ld, bu, bv, len, row_off, out, t_max, t_pad, t_short);
     else

@@ -434,8 +434,9 @@ class Engine:
 
     def attention_variant(self, mode: int):
         """process-wide attention kernel variant (qv_debug_attention_variant): 3 = default (utterances of <= 128 frames on
-        the single-pass kernel, longer ones key-tiled), 0 = key-tiled with two heads per block for every utterance,
-        1 = one head per block, 2 = one wave per query tile (0..2: identical bits), -1 = environment / default."""
+        the single-pass kernel, longer ones on the loader-wave key-tiled kernel), 0 = that kernel with two heads per block for
+        every utterance, 1 = one head per block, 2 = one wave per query tile, 4 = k_attention_x for every utterance,
+        5 = single-pass + k_attention_x (0, 1, 2, 4: identical bits; 3, 5: identical bits), -1 = environment / default."""
         self._check(self.lib.qv_debug_attention_variant(int(mode)), "qv_debug_attention_variant")
 
     def kernel_variant(self, which: int, mode: int):

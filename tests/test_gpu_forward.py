@@ -378,7 +378,7 @@ def test_key_tiled_attention_kernels_agree_bit_for_bit(setup):
     dev = setup["audio"].cuda().contiguous()
     lp0, t0 = _forward_with_variant(eng, dev, LENS, 0)
     assert t0 == setup["t"]
-    for var in (1, 2):
+    for var in (1, 2, 4):
         lp, t = _forward_with_variant(eng, dev, LENS, var)
         assert t == t0
         for i, n in enumerate(t):
@@ -525,7 +525,7 @@ def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
             assert t1[0] == t[b] and torch.equal(one[0, : t[b]], lp[b, : t[b]]), frames[b]
         if precision == 0:
             lp0 = None
-            for var in (0, 1, 2):   # key-tiled kernels: two heads per block, one head per block, one wave per query tile
+            for var in (0, 1, 2, 4):   # key-tiled kernels: two heads per block, one head per block, one wave per query tile, self-staging waves (k_attention_x)
                 eng.attention_variant(var)
                 try:
                     lp2, _ = eng.forward(dev, lens)
@@ -544,6 +544,14 @@ def test_frame_count_boundaries_are_batch_invariant(precision, monkeypatch):
                 differ += not same
                 assert float((lp[b, : t[b]] - lp0[b, : t[b]]).abs().max()) <= 4e-3, frames[b]
             assert differ >= 4      # ... and it does run there (a one-frame softmax is the same in any kernel)
+            eng.attention_variant(5)    # k_attention_short + k_attention_x = the default (3: k_attention_short + the loader-wave kernel), bit for bit
+            try:
+                lp3, _ = eng.forward(dev, lens)
+                torch.cuda.synchronize()
+                for b in range(len(lens)):
+                    assert torch.equal(lp3[b, : t[b]], lp[b, : t[b]]), frames[b]
+            finally:
+                eng.attention_variant(-1)
     finally:
         eng.close()
 

@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<half_t> ref((size_t)M * QV_D), got((size_t)M * QV_D);
-    for (int variant : {0, 1, 2, 3}) {
+    for (int variant : {0, 1, 2, 4, 3}) {      // 4 = k_attention_x (no loader waves, two independent blocks per CU)
         if (variant == 3 && T > 128) continue;
         qv_attention_set_variant(variant);
         half_t *o = variant == 0 ? out : out2;
