@@ -237,7 +237,8 @@ struct QvCtx {
     bool stage_valid;
     // the post-logits chain (k_decode .. k_result, 13 kernels) as ONE hipGraph launch, keyed by what the kernel
     // arguments depend on; captured the first time a key is seen on this context
-    struct PostGraph { const float *lp; int batch, t_max; hipGraphExec_t exec; } post_graph[4];
+    struct PostGraph { const float *lp; int batch, t_max, variants; hipGraphExec_t exec; } post_graph[4];   // variants: the kernel variants in force (spans, CTC)
+    bool post_graph_off = false;   // a capture / instantiate failed on this context: plain launches from then on
     int n_post_graph;
 };
 

@@ -2168,27 +2168,41 @@ int qv_post_run(qv_engine *eng, const float *lp, int t_max, const int32_t *t_hos
     // host's ~3.5 us per launch is not what limits the step.
     static const bool use_graph = [] { const char *e = getenv("QVERSE_POST_GRAPH"); return e && atoi(e) != 0; }();
     QvCtx &gc = eng->ctx[eng->cur_ctx];
-    if (use_graph && eng->n_ctx > 1 && stream == gc.stream && lp == eng->logprobs_ws && !eng->profile_stages) {
+    if (use_graph && !gc.post_graph_off && eng->n_ctx > 1 && stream == gc.stream && lp == eng->logprobs_ws && !eng->profile_stages) {
+        // (the kernel variants that pick launches inside the chain are part of the key: a graph captured under another span pass
+        // or CTC wave program must not be replayed after qv_debug_kernel_variant changed it)
+        const int variants = qv_kernel_variant(QV_KV_SPANS) | (qv_kernel_variant(QV_KV_CTC) << 4);
         QvCtx::PostGraph *hit = nullptr;
         for (int i = 0; i < gc.n_post_graph; ++i)
-            if (gc.post_graph[i].lp == lp && gc.post_graph[i].batch == batch && gc.post_graph[i].t_max == t_max) hit = &gc.post_graph[i];
+            if (gc.post_graph[i].lp == lp && gc.post_graph[i].batch == batch && gc.post_graph[i].t_max == t_max && gc.post_graph[i].variants == variants)
+                hit = &gc.post_graph[i];
+        bool ran_plain = false;
         if (!hit && gc.n_post_graph < 4) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
-            QV_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            int rc = launch_chain();
-            hipError_t e1 = hipStreamEndCapture(stream, &graph);
-            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            QV_HIP(e1);
-            hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            QV_HIP(e2);
-            gc.post_graph[gc.n_post_graph] = {lp, batch, t_max, exec};
-            hit = &gc.post_graph[gc.n_post_graph++];
+            // as for the forward graph: a failure of the capture machinery is not a failure of the batch
+            hipError_t e0 = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal), e1 = hipSuccess, e2 = hipSuccess;
+            if (e0 == hipSuccess) {
+                int rc = launch_chain();
+                e1 = hipStreamEndCapture(stream, &graph);
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                if (e1 == hipSuccess) e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || !exec) {
+                (void)hipGetLastError();
+                gc.post_graph_off = true;
+                int rc = launch_chain();
+                if (rc) return rc;
+                ran_plain = true;
+            } else {
+                gc.post_graph[gc.n_post_graph] = {lp, batch, t_max, variants, exec};
+                hit = &gc.post_graph[gc.n_post_graph++];
+            }
         }
         if (hit) {
             QV_HIP(hipGraphLaunch(hit->exec, stream));
-        } else {
+        } else if (!ran_plain) {
             int rc = launch_chain();
             if (rc) return rc;
         }
