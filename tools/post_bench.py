@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=126)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--case", type=int, default=-1, help="run only this case (0 = clean / gate passes ... 3 = noisy); default all")
     args = ap.parse_args()
 
     import numpy as np
@@ -38,8 +39,9 @@ def main():
     rng = np.random.default_rng(20260630)
     n_verses = len(eng.tables.s["tok_off"]) // 6
     rows = []
-    for name, noise, boost in (("clean (gate passes)", 1.0, 8.0), ("corrupted", 2.0, 6.0), ("corrupted more", 2.4, 6.0),
-                               ("noisy (gate fails -> CTC rerank)", 3.5, 4.0)):
+    cases = (("clean (gate passes)", 1.0, 8.0), ("corrupted", 2.0, 6.0), ("corrupted more", 2.4, 6.0),
+             ("noisy (gate fails -> CTC rerank)", 3.5, 4.0))
+    for name, noise, boost in (cases if args.case < 0 else cases[args.case: args.case + 1]):
         lps, used = [], 0
         while len(lps) < B:
             v = int(rng.integers(0, n_verses))
